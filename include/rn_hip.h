@@ -1,0 +1,180 @@
+/*
+ * rn_hip.h -- C ABI of librn_hip.so: the MI355X (gfx950) engine for the ResNet forward/backward hot path.
+ *
+ * Boundary: the reference has no FFI; its hot path sits behind the torch.nn.Module
+ * contract of ResNet (/root/reference/resnet/architectures/resnet.py:25-32 constructor, :165-166 forward) and the
+ * autograd backward started at /root/reference/resnet/algos/training.py:100,102.  This library replaces what
+ * that forward/backward dispatches to (ATen Conv2d / BatchNorm2d / ReLU / Dropout / pools / Linear kernels and their
+ * autograd formulas) with hand-written HIP.  Plain pointers + sizes only: no torch types cross this boundary.
+ * The caller owns every buffer (device memory, allocated through its own allocator); every entry point is
+ * asynchronous on the given hipStream_t and returns 0 on success, non-zero on a rejected argument or launch
+ * failure (message: rn_last_error()).
+ *
+ * Layouts: activations NHWC, element type `dtype` (RN_F32 | RN_BF16); convolution weights KRSC (that is the
+ * physical order of a torch channels_last [K,C,R,S] tensor); statistics / BN coefficients / weight gradients /
+ * logits fp32; network input NCHW fp32 as the reference's data loader hands it over (training.py:94).
+ */
+#ifndef RN_HIP_H
+#define RN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rn_stream;                 /* a hipStream_t */
+
+enum { RN_F32 = 0, RN_BF16 = 1 };
+
+/* residual / merge operand addressing, shared by conv epilogues, bn_apply and bn_bwd_apply */
+enum {
+  RN_RES_NONE = 0,
+  RN_RES_SAME = 1,      /* res[n,h,w,c]                                    identity shortcut (residual_block.py:96)          */
+  RN_RES_DOWN2PAD = 2,  /* c < res_C ? res[n,2h,2w,c] : 0                  AvgPool(1,2) + zero-pad shortcut (:49,90,94)     */
+  RN_RES_UP2 = 3        /* (h,w even) ? res[n,h/2,w/2,c] : 0, c < res_C    its adjoint (backward of the line above)         */
+};
+
+/* ---- op kinds of a plan (one fused kernel launch each, a few expand to 2-4 launches) ---- */
+enum {
+  RN_OP_STEM_FWD = 1,       /* resnet.py:69-75   Conv2d(3->K,k,s,p,bias) on the NCHW fp32 image -> NHWC                       */
+  RN_OP_PACK_W = 2,         /* fp32 KRSC master -> compute-dtype KRSC (forward) and CRSK (dgrad) copies                       */
+  RN_OP_CONV_FWD = 3,       /* residual_block.py:34-57,129-159 Conv2d(bias=False) 3x3/1x1, stride 1|2, + residual epilogue   */
+  RN_OP_BN_STATS = 4,       /* BatchNorm2d train: per-channel partial (sum, sumsq)                                            */
+  RN_OP_BN_FINALIZE = 5,    /* -> coef = (scale, shift, mean, invstd); running-stat update (train) or running stats (eval)    */
+  RN_OP_BN_APPLY = 6,       /* y = [relu](x*scale+shift [+ res]) [* dropout]   (residual_block.py:70-72,81-83,96-98)          */
+  RN_OP_DROPOUT_FWD = 7,    /* standalone Dropout in front of a v1 block's first conv (residual_block.py:80)                  */
+  RN_OP_MAXPOOL_FWD = 8,    /* resnet.py:83-87                                                                                  */
+  RN_OP_POOL_FC_FWD = 9,    /* resnet.py:77-81 global AvgPool2d + :117-120 Flatten+Linear                                     */
+  RN_OP_POOL_FC_BWD = 10,
+  RN_OP_MAXPOOL_BWD = 11,
+  RN_OP_BN_BWD_REDUCE = 12, /* per-channel partial (sum g, sum g*xhat), g = dout * relu/dropout mask                          */
+  RN_OP_BN_BWD_FINALIZE = 13, /* partials -> (sum g, sum g*xhat) and the dgamma/dbeta gradients                               */
+  RN_OP_BN_BWD_APPLY = 14,  /* dx = scale*(g - mean(g) - xhat*mean(g*xhat)) [+ add operand]; optional copy of g              */
+  RN_OP_CONV_DGRAD = 15,
+  RN_OP_CONV_WGRAD = 16,
+  RN_OP_STEM_WGRAD = 17,
+  RN_OP_DROPOUT_BWD = 18,
+  RN_OP_SOFTMAX_CE = 19,    /* metrics.py:10-29: mean CE loss, top-1/top-5 error counts, dlogits                             */
+  RN_OP_ZERO = 20           /* memset of a buffer slot (split-K / accumulation targets)                                       */
+};
+
+/* flags */
+enum {
+  RN_F_RELU = 1 << 0,
+  RN_F_TRAIN = 1 << 1,        /* BN uses batch statistics                                   */
+  RN_F_ACCUM = 1 << 2,        /* destination += result                                      */
+  RN_F_WRITE_G = 1 << 3,      /* bn_bwd_apply also writes g = masked dout (v1 shortcut)     */
+  RN_F_NEED_DGRAD_PACK = 1 << 4,
+  RN_F_SKIP_FWD_PACK = 1 << 5,
+  RN_F_NO_DX = 1 << 6         /* pool_fc_bwd etc.: input gradient not needed                */
+};
+
+#define RN_OP_NBUF 8
+#define RN_OP_NDIM 20
+
+/* One op of a plan.  buf[] are indices into the plan's buffer table (-1 = absent); dim[] and fp[] are per-kind
+ * (documented next to each rn_* launcher below: the executor forwards them 1:1 to that launcher). */
+typedef struct rn_op {
+  int32_t kind;
+  int32_t flags;
+  int32_t buf[RN_OP_NBUF];
+  int32_t dim[RN_OP_NDIM];
+  float fp[4];
+  uint32_t seed;     /* dropout site id: mask = hash(step_seed, seed, element index) */
+  int32_t pad_;
+} rn_op;
+
+typedef struct rn_plan rn_plan;
+
+const char* rn_last_error(void);
+int rn_version(void);
+
+/* ---- plan executor: the per-batch forward / backward of ResNet.forward as ONE host call each ---- */
+int rn_plan_create(const rn_op* ops, int n_ops, int n_bufs, int dtype, rn_plan** out);
+int rn_plan_bind(rn_plan* plan, const void* const* device_ptrs, int n_bufs);
+/* runs ops [first, last) in order on `stream`; step_seed feeds the dropout hash (same value forward and backward) */
+int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_seed, rn_stream stream);
+int rn_plan_num_ops(const rn_plan* plan);
+void rn_plan_destroy(rn_plan* plan);
+
+/* ---- geometry of a (transposed) convolution as an implicit GEMM ---- */
+typedef struct rn_conv_geom {
+  int32_t N, H, W, C;      /* input  [N,H,W,C]  */
+  int32_t P, Q, K;         /* output [N,P,Q,K]  */
+  int32_t R, S, stride, pad;
+} rn_conv_geom;
+
+/* ---- single kernels (also the executor's building blocks; tests call these through one-op plans or directly) ---- */
+
+/* y[n,p,q,k] = bias[k] + sum x[n,c,p*s+r-pad,q*s+t-pad] * w[k,r,t,c];  x NCHW fp32, w KRSC fp32, y NHWC dtype */
+int rn_stem_conv_fwd(const float* x_nchw, const float* w_krsc, const float* bias, void* y, int dtype,
+                     const rn_conv_geom* g, rn_stream s);
+/* dw[k,r,t,c], db[k] (fp32, overwritten or accumulated); ws: >= rn_stem_wgrad_ws_bytes(g) bytes */
+int rn_stem_conv_wgrad(const float* x_nchw, const void* dy, int dtype, float* dw_krsc, float* dbias, void* ws,
+                       int accumulate, const rn_conv_geom* g, rn_stream s);
+size_t rn_stem_wgrad_ws_bytes(const rn_conv_geom* g);
+
+/* fp32 KRSC master -> w_fwd [K][R*S][C] and w_dgrad [C][R*S][K] in dtype (either may be NULL) */
+int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, int dtype, int K, int RS, int C, rn_stream s);
+
+/* y = conv(x, w_fwd) [+ res];  MFMA implicit GEMM, M = N*P*Q, N = K, K = R*S*C.  C % 8 == 0, K % 16 == 0 */
+int rn_conv_fwd(const void* x, const void* w_fwd, void* y, const void* res, int res_mode, int res_C, int dtype,
+                const rn_conv_geom* g, rn_stream s);
+/* dx = conv_transpose(dy, w) [+ res] ; flags: RN_F_ACCUM */
+int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* res, int res_mode, int res_C,
+                  int flags, int dtype, const rn_conv_geom* g, rn_stream s);
+/* dw[k,r,s,c] (fp32 KRSC) = sum_{n,p,q} dy * x ; split over pixels into ws, then reduced. flags: RN_F_ACCUM */
+int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void* ws, size_t ws_bytes, int flags, int dtype,
+                  const rn_conv_geom* g, rn_stream s);
+size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g);
+
+/* BatchNorm over a [M, C] view.  partial: [nblk][2][C] fp32, nblk = rn_bn_num_partials(M, C) */
+int rn_bn_num_partials(int64_t M, int C);
+int rn_bn_stats(const void* x, float* partial, int dtype, int64_t M, int C, rn_stream s);
+/* coef: [4][C] = scale, shift, mean, invstd.  train: batch stats from partial (count = number of rows over ALL
+ * ranks that contributed to `partial`), running_mean/var (momentum, unbiased var) and num_batches_tracked updated
+ * in place; eval: coef from running stats.  */
+int rn_bn_finalize(const float* partial, int nblk, double count, const float* gamma, const float* beta,
+                   float* running_mean, float* running_var, int64_t* num_batches_tracked, float* coef, int C,
+                   float eps, float momentum, int flags, rn_stream s);
+/* out = [relu](x*scale+shift [+ res]) [dropout(p)] ; geometry N,H,W of x for the residual mapping */
+int rn_bn_apply(const void* x, const float* coef, const void* res, void* out, int dtype, int N, int H, int W, int C,
+                int res_mode, int res_C, int flags, float drop_p, uint32_t site, uint64_t step_seed, rn_stream s);
+/* g = dout * gscale * [mask_src > 0] (mask only with RN_F_RELU; gscale = 1/(1-p)); partial [nblk][2][C] */
+int rn_bn_bwd_reduce(const void* dout, const void* x, const void* mask_src, const float* coef, float* partial,
+                     int dtype, int64_t M, int C, int flags, float gscale, rn_stream s);
+/* partial -> dsum [2][C]; dgamma/dbeta written (or accumulated with RN_F_ACCUM) */
+int rn_bn_bwd_finalize(const float* partial, int nblk, float* dsum, float* dgamma, float* dbeta, int C, int flags,
+                       rn_stream s);
+/* dx = scale*(g - dsum0/count - xhat*dsum1/count) [train] | scale*g [eval]  [+ add operand];  optional g_out */
+int rn_bn_bwd_apply(const void* dout, const void* x, const void* mask_src, const float* coef, const float* dsum,
+                    const void* add, void* dx, void* g_out, int dtype, int N, int H, int W, int C, int add_mode,
+                    int add_C, int flags, float gscale, double count, rn_stream s);
+
+int rn_dropout_fwd(const void* x, void* out, int dtype, int64_t n, float p, uint32_t site, uint64_t step_seed, rn_stream s);
+int rn_dropout_bwd(const void* dout, const void* out, void* din, int dtype, int64_t n, float p, rn_stream s);
+
+int rn_maxpool_fwd(const void* x, void* y, int dtype, int N, int H, int W, int C, int k, int stride, int pad, rn_stream s);
+int rn_maxpool_bwd(const void* dy, const void* x, void* dx, int dtype, int N, int H, int W, int C, int k, int stride,
+                   int pad, rn_stream s);
+
+/* logits[n,o] = b[o] + sum_c W[o,c] * mean_{hw} x[n,hw,c];  feat: [N][C] fp32 scratch kept for backward */
+int rn_pool_fc_fwd(const void* x, const float* w, const float* b, float* feat, float* logits, int dtype, int N, int HW,
+                   int C, int O, rn_stream s);
+int rn_pool_fc_bwd(const float* dlogits, const float* feat, const float* w, void* dx, float* dw, float* db, int dtype,
+                   int N, int HW, int C, int O, int flags, rn_stream s);
+
+/* out3 = (sum nll, #top1 wrong, #top5 wrong) over the batch (fp32, overwritten); dlogits = (softmax - onehot) * scale */
+int rn_softmax_ce(const float* logits, const int64_t* labels, float* out3, float* dlogits, int N, int O, float scale,
+                  rn_stream s);
+
+/* fused multi-tensor SGD over one flat fp32 buffer (torch.optim.SGD rule; optim_util.py:11-18, config.yaml:22-28) */
+int rn_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
+                float dampening, float weight_decay, int nesterov, int first_step, float grad_scale, rn_stream s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,448 @@
+"""
+Lowers a parsed ``architecture_spec`` to the plan IR: the list of fused HIP launches that make up one forward and one
+backward of the network, plus the table of device buffers they read and write.
+
+What is mirrored (semantics, not code): the module order of ``ResNet._parse_spec`` (/root/reference/resnet/
+architectures/resnet.py:122-158) and the data flow of ``ResidualBlock.forward`` (residual_block.py:67-99) and
+``BottleneckResidualBlock.forward`` (:173-215): v1 ``[drop] conv bn relu``, v2 ``bn relu [drop] conv``, shortcut from
+the raw block input (identity / subsample+zero-pad / subsample+1x1 projection), post-add ReLU only in v1.
+
+How it runs here: every BN+ReLU(+dropout) is one elementwise pass (BN_APPLY) fed by a statistics pass; the residual
+add rides in the epilogue of the block's last convolution (v2) or of the last BN_APPLY (v1); the backward is written
+out explicitly (no autograd inside the engine) and merges gradient forks in kernel epilogues instead of separate adds.
+Weight gradients are produced in the order recorded in ``Plan.grad_order`` so the flat gradient buffer can be
+all-reduced bucket by bucket while the backward is still running.
+"""
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+from ..architectures.spec import Component, block_convs, parse_spec
+from . import ir
+from .ir import Op, Slot, Hook
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1        # torch.nn.BatchNorm2d defaults, which the reference keeps (resnet.py:111-112)
+
+
+@dataclass
+class T:
+    """an NHWC activation tensor living in slot `s`."""
+    s: int
+    N: int
+    H: int
+    W: int
+    C: int
+
+    @property
+    def M(self):
+        return self.N * self.H * self.W
+
+
+@dataclass
+class Plan:
+    slots: List[Slot]
+    ops: List[Op]
+    n_fwd: int                       # ops[:n_fwd] forward, ops[n_fwd:] backward
+    hooks: List[Hook]
+    grad_order: List[str]            # parameter keys in the order their gradients are produced by the backward
+    param_keys: List[str]            # parameter keys in forward (state_dict) order
+    slot_of: Dict[str, int]          # well-known slots: 'x', 'logits', 'dlogits', 'labels', 'loss3', 'ws'
+    train: bool
+    meta: dict = field(default_factory=dict)
+
+
+def bn_partials(M: int, C: int) -> int:
+    """number of row-slabs a statistics pass is split into (one workgroup each)."""
+    rows_per = 256
+    return max(1, min(1024, (M + rows_per - 1) // rows_per))
+
+
+class Lowering:
+    def __init__(self, spec: str, preact: bool, use_proj: bool, dropout_prob: float, N: int, H: int, W: int,
+                 train: bool = True, need_grad: bool = True, sync_bn: bool = False, world_size: int = 1,
+                 fp32: bool = True, with_loss: bool = False):
+        self.comps = parse_spec(spec)
+        self.preact, self.use_proj, self.p = preact, use_proj, float(dropout_prob)
+        self.N, self.H, self.W = N, H, W
+        self.train, self.need_grad = train, need_grad
+        self.sync = sync_bn and world_size > 1 and train
+        self.world = world_size
+        self.fp32 = fp32
+        self.with_loss = with_loss
+        self.slots: List[Slot] = []
+        self.fwd: List[Op] = []
+        self.bwd: List[Op] = []
+        self.fwd_hooks: List[Hook] = []
+        self.bwd_hooks: List[Hook] = []
+        self._back = []                 # stack of backward emitters
+        self.grad_order: List[str] = []
+        self.param_keys: List[str] = []
+        self._named: Dict[str, int] = {}
+        self._site = 0
+        self._packed: Dict[str, Tuple[int, int]] = {}
+        self._ws_need = []              # geometries of ops that share the workspace slot
+
+    # ---- slots ------------------------------------------------------------------------------------------
+    def slot(self, name, role, shape, dtype, key=None):
+        self.slots.append(Slot(name, role, tuple(int(d) for d in shape), dtype, key))
+        return len(self.slots) - 1
+
+    def act(self, name, N, H, W, C):
+        return T(self.slot(name, 'act', (N, H, W, C), 'T'), N, H, W, C)
+
+    def f32(self, name, shape):
+        return self.slot(name, 'f32', shape, 'f32')
+
+    def param(self, key, shape):
+        if key not in self._named:
+            self._named[key] = self.slot(key, 'param', shape, 'f32', key)
+            self.param_keys.append(key)
+        return self._named[key]
+
+    def buffer(self, key, shape, dtype='f32'):
+        if key not in self._named:
+            self._named[key] = self.slot(key, 'buffer', shape, dtype, key)
+        return self._named[key]
+
+    def grad(self, key, shape):
+        g = 'grad:' + key
+        if g not in self._named:
+            self._named[g] = self.slot(g, 'grad', shape, 'f32', key)
+        if key not in self.grad_order:
+            self.grad_order.append(key)
+        return self._named[g]
+
+    def ws(self):
+        if 'ws' not in self._named:
+            self._named['ws'] = self.slot('workspace', 'ws', (0,), 'u8')
+        return self._named['ws']
+
+    # ---- small emitters ---------------------------------------------------------------------------------
+    def geom(self, x: T, K, k, stride, pad):
+        P = (x.H + 2 * pad - k) // stride + 1
+        Q = (x.W + 2 * pad - k) // stride + 1
+        return dict(N=x.N, H=x.H, W=x.W, C=x.C, P=P, Q=Q, K=K, R=k, S=k, stride=stride, pad=pad)
+
+    def packed_weights(self, key, K, k, C, need_dgrad):
+        """per-forward repack of one conv weight into the compute dtype (KRSC for fwd/wgrad, CRSK for dgrad).
+        fp32 plans read the master parameter directly as the forward operand."""
+        w = self.param(key, (K, k, k, C))
+        if key in self._packed:
+            return self._packed[key]
+        need_dgrad = need_dgrad and self.need_grad
+        wf = w if self.fp32 else self.slot(key + ':fwd', 'act', (K, k * k, C), 'T')
+        wd = self.slot(key + ':dgrad', 'act', (C, k * k, K), 'T') if need_dgrad else -1
+        if (not self.fp32) or need_dgrad:
+            flags = (ir.F_SKIP_FWD_PACK if self.fp32 else 0) | (ir.F_NEED_DGRAD_PACK if need_dgrad else 0)
+            self.fwd.append(Op(ir.OP_PACK_W, buf=dict(w=w, w_fwd=-1 if self.fp32 else wf, w_dgrad=wd),
+                               dim=dict(K=K, RS=k * k, C=C), flags=flags, note=key))
+        self._packed[key] = (wf, wd)
+        return wf, wd
+
+    def conv_fwd(self, x: T, key, K, k, stride, pad, name, res: Optional[T] = None, res_mode=ir.RES_NONE, need_dgrad=True):
+        g = self.geom(x, K, k, stride, pad)
+        wf, wd = self.packed_weights(key, K, k, x.C, need_dgrad)
+        y = self.act(name, x.N, g['P'], g['Q'], K)
+        self.fwd.append(Op(ir.OP_CONV_FWD, buf=dict(x=x.s, w_fwd=wf, y=y.s, res=res.s if res else -1),
+                           dim=dict(g, res_mode=res_mode, res_C=res.C if res else 0), note=key))
+        return y, g, wd
+
+    def conv_bwd(self, ops: List[Op], x: T, dy: T, key, g, wd, dx_name, need_dx=True, res: Optional[T] = None,
+                 res_mode=ir.RES_NONE, accum_into: Optional[T] = None):
+        """emits wgrad (+ dgrad).  returns dx tensor (or None)."""
+        dw = self.grad(key, (g['K'], g['R'], g['S'], g['C']))
+        ops.append(Op(ir.OP_CONV_WGRAD, buf=dict(x=x.s, dy=dy.s, dw=dw, ws=self.ws()), dim=dict(g), note=key))
+        self._ws_need.append(('wgrad', dict(g)))
+        self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
+        if not need_dx:
+            return None
+        dx = accum_into or self.act(dx_name, x.N, x.H, x.W, x.C)
+        ops.append(Op(ir.OP_CONV_DGRAD, buf=dict(dy=dy.s, w_dgrad=wd, dx=dx.s, res=res.s if res else -1),
+                      dim=dict(g, res_mode=res_mode, res_C=res.C if res else 0),
+                      flags=ir.F_ACCUM if accum_into else 0, note=key))
+        return dx
+
+    def bn_coef(self, x: T, pre: str):
+        """statistics (+ SyncBN hook) + finalize -> coef slot [4][C]."""
+        C = x.C
+        gamma, beta = self.param(pre + '.weight', (C,)), self.param(pre + '.bias', (C,))
+        rm, rv = self.buffer(pre + '.running_mean', (C,)), self.buffer(pre + '.running_var', (C,))
+        nbt = self.buffer(pre + '.num_batches_tracked', (), 'i64')
+        coef = self.f32(pre + ':coef', (4, C))
+        if self.train:
+            nblk = bn_partials(x.M, C)
+            part = self.f32(pre + ':partial', (nblk, 2, C))
+            self.fwd.append(Op(ir.OP_BN_STATS, buf=dict(x=x.s, partial=part), dim=dict(M=x.M, C=C, nblk=nblk), note=pre))
+            count = x.M
+            if self.sync:
+                # SyncBN: the partial sums are summed slab-by-slab across ranks (a sum of partials is still a set of
+                # partials), then every rank finalizes over the global row count
+                self.fwd_hooks.append(Hook(len(self.fwd), 'allreduce_f32', slot=part))
+                count = x.M * self.world
+            self.fwd.append(Op(ir.OP_BN_FINALIZE, buf=dict(partial=part, gamma=gamma, beta=beta, running_mean=rm,
+                                                           running_var=rv, nbt=nbt, coef=coef),
+                               dim=dict(nblk=nblk, count=count, C=C), fp=dict(eps=BN_EPS, momentum=BN_MOMENTUM),
+                               flags=ir.F_TRAIN, note=pre))
+        else:
+            self.fwd.append(Op(ir.OP_BN_FINALIZE, buf=dict(partial=-1, gamma=gamma, beta=beta, running_mean=rm,
+                                                           running_var=rv, nbt=nbt, coef=coef),
+                               dim=dict(nblk=0, count=x.M, C=C), fp=dict(eps=BN_EPS, momentum=BN_MOMENTUM), note=pre))
+        return coef
+
+    def bn_apply(self, x: T, coef, name, relu, drop=False, res: Optional[T] = None, res_mode=ir.RES_NONE):
+        out = self.act(name, x.N, x.H, x.W, x.C)
+        p = self.p if (drop and self.train) else 0.0
+        site = 0
+        if p > 0:
+            self._site += 1
+            site = self._site
+        self.fwd.append(Op(ir.OP_BN_APPLY, buf=dict(x=x.s, coef=coef, res=res.s if res else -1, out=out.s),
+                           dim=dict(N=x.N, H=x.H, W=x.W, C=x.C, res_mode=res_mode, res_C=res.C if res else 0),
+                           fp=dict(p=p), flags=ir.F_RELU if relu else 0, seed=site, note=name))
+        return out, p
+
+    def bn_bwd(self, ops, dout: T, x: T, mask: Optional[T], coef, pre, dx_name, p=0.0, add: Optional[T] = None,
+               add_mode=ir.RES_NONE, write_g_name=None):
+        """backward of out = [drop][relu](bn(x) [+ res]).  returns (dx, g or None)."""
+        C = x.C
+        gscale = 1.0 / (1.0 - p) if p > 0 else 1.0
+        nblk = bn_partials(x.M, C)
+        part = self.f32(pre + ':dpartial', (nblk, 2, C))
+        dsum = self.f32(pre + ':dsum', (2, C))
+        fl = (ir.F_RELU if mask is not None else 0) | (ir.F_TRAIN if self.train else 0)
+        ops.append(Op(ir.OP_BN_BWD_REDUCE, buf=dict(dout=dout.s, x=x.s, mask=mask.s if mask else -1, coef=coef, partial=part),
+                      dim=dict(M=x.M, C=C, nblk=nblk), fp=dict(gscale=gscale), flags=fl, note=pre))
+        dg, db = self.grad(pre + '.weight', (C,)), self.grad(pre + '.bias', (C,))
+        count = x.M
+        ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=dsum, dgamma=dg, dbeta=db), dim=dict(nblk=nblk, C=C), note=pre))
+        if self.sync:
+            # dgamma/dbeta stay local sums (the gradient all-reduce averages them); dsum must be global
+            self.bwd_hooks.append(Hook(len(ops), 'allreduce_f32', slot=dsum))
+            count = x.M * self.world
+        self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
+        dx = self.act(dx_name, x.N, x.H, x.W, C)
+        g = self.act(write_g_name, x.N, x.H, x.W, C) if write_g_name else None
+        ops.append(Op(ir.OP_BN_BWD_APPLY,
+                      buf=dict(dout=dout.s, x=x.s, mask=mask.s if mask else -1, coef=coef, dsum=dsum,
+                               add=add.s if add else -1, dx=dx.s, g_out=g.s if g else -1),
+                      dim=dict(N=x.N, H=x.H, W=x.W, C=C, add_mode=add_mode, add_C=add.C if add else 0, count=count),
+                      fp=dict(gscale=gscale), flags=fl | (ir.F_WRITE_G if g else 0), note=pre))
+        return dx, g
+
+    # ---- residual blocks --------------------------------------------------------------------------------
+    def block(self, bp: str, kind: str, cin: int, down: bool, i: T) -> T:
+        convs, norms, cout = block_convs(kind, cin, down, self.preact)
+        n = len(convs)
+        proj = down and self.use_proj
+        recs = []
+        sc_g = sc_wd = None
+        if self.preact:
+            x = i
+            for j, (ci, co, k, s, pd) in enumerate(convs, 1):
+                coef = self.bn_coef(x, f'{bp}._norm{j}')
+                a, p = self.bn_apply(x, coef, f'{bp}.a{j}', relu=True, drop=True)
+                res, mode = None, ir.RES_NONE
+                if j == n:
+                    if not down:
+                        res, mode = i, ir.RES_SAME
+                    elif proj:
+                        res, sc_g, sc_wd = self.conv_fwd(i, f'{bp}._proj.weight', cout, 1, 2, 0, f'{bp}.sc')
+                        mode = ir.RES_SAME
+                    else:
+                        res, mode = i, ir.RES_DOWN2PAD
+                y, g, wd = self.conv_fwd(a, f'{bp}._conv{j}.weight', co, k, s, pd, f'{bp}.y{j}', res, mode)
+                recs.append(dict(x=x, a=a, coef=coef, p=p, g=g, wd=wd, j=j))
+                x = y
+            h = x
+
+            def backward(dh: T, ops):
+                gcur = dh
+                for r in reversed(recs):
+                    j = r['j']
+                    da = self.conv_bwd(ops, r['a'], gcur, f'{bp}._conv{j}.weight', r['g'], r['wd'], f'{bp}.da{j}')
+                    add, mode = None, ir.RES_NONE
+                    if j == 1 and not proj:
+                        add, mode = dh, (ir.RES_SAME if not down else ir.RES_UP2)
+                    gcur, _ = self.bn_bwd(ops, da, r['x'], r['a'], r['coef'], f'{bp}._norm{j}', f'{bp}.dx{j}', r['p'], add, mode)
+                if proj:
+                    self.conv_bwd(ops, i, dh, f'{bp}._proj.weight', sc_g, sc_wd, None, accum_into=gcur)
+                return gcur
+        else:
+            x = i
+            p_in = 0.0
+            if self.p > 0 and self.train:
+                self._site += 1
+                x0 = self.act(f'{bp}.x0', i.N, i.H, i.W, i.C)
+                self.fwd.append(Op(ir.OP_DROPOUT_FWD, buf=dict(x=i.s, out=x0.s), dim=dict(n_lo=i.M * i.C & 0x7fffffff, n_hi=(i.M * i.C) >> 31),
+                                   fp=dict(p=self.p), seed=self._site, note=bp))
+                x, p_in = x0, self.p
+            h = None
+            for j, (ci, co, k, s, pd) in enumerate(convs, 1):
+                y, g, wd = self.conv_fwd(x, f'{bp}._conv{j}.weight', co, k, s, pd, f'{bp}.y{j}')
+                coef = self.bn_coef(y, f'{bp}._norm{j}')
+                rec = dict(x=x, y=y, coef=coef, g=g, wd=wd, j=j)
+                if j < n:
+                    a, p = self.bn_apply(y, coef, f'{bp}.a{j}', relu=True, drop=True)
+                    rec.update(out=a, p=p)
+                    x = a
+                else:
+                    if not down:
+                        res, mode = i, ir.RES_SAME
+                    elif proj:
+                        res, sc_g, sc_wd = self.conv_fwd(i, f'{bp}._proj.weight', cout, 1, 2, 0, f'{bp}.sc')
+                        mode = ir.RES_SAME
+                    else:
+                        res, mode = i, ir.RES_DOWN2PAD
+                    h, _ = self.bn_apply(y, coef, f'{bp}.h', relu=True, drop=False, res=res, res_mode=mode)
+                    rec.update(out=h, p=0.0)
+                recs.append(rec)
+
+            def backward(dh: T, ops):
+                gcur, gm = None, None
+                for r in reversed(recs):
+                    j = r['j']
+                    dout = dh if j == n else gcur
+                    dy, g_ = self.bn_bwd(ops, dout, r['y'], r['out'], r['coef'], f'{bp}._norm{j}', f'{bp}.dy{j}', r['p'],
+                                         write_g_name=f'{bp}.gm' if j == n else None)
+                    if j == n:
+                        gm = g_
+                    if j > 1:
+                        gcur = self.conv_bwd(ops, r['x'], dy, f'{bp}._conv{j}.weight', r['g'], r['wd'], f'{bp}.da{j - 1}')
+                    else:
+                        plain = p_in == 0.0
+                        res, mode = None, ir.RES_NONE
+                        if not proj:
+                            res, mode = gm, (ir.RES_SAME if not down else ir.RES_UP2)
+                        if plain:
+                            gcur = self.conv_bwd(ops, r['x'], dy, f'{bp}._conv{j}.weight', r['g'], r['wd'], f'{bp}.di', res=res, res_mode=mode)
+                        else:   # dropout1 sits between the block input and conv1: its mask applies before the merge
+                            t = self.conv_bwd(ops, r['x'], dy, f'{bp}._conv{j}.weight', r['g'], r['wd'], f'{bp}.dx0')
+                            gcur = self.act(f'{bp}.di', i.N, i.H, i.W, i.C)
+                            ops.append(Op(ir.OP_DROPOUT_BWD, buf=dict(dout=t.s, out=r['x'].s, din=gcur.s),
+                                          dim=dict(n_lo=i.M * i.C & 0x7fffffff, n_hi=(i.M * i.C) >> 31), fp=dict(p=p_in), note=bp))
+                            if res is not None:
+                                ops.append(Op(ir.OP_ADD_RES, buf=dict(dst=gcur.s, res=res.s),
+                                              dim=dict(N=i.N, H=i.H, W=i.W, C=i.C, res_mode=mode, res_C=res.C), note=bp))
+                        if proj:
+                            self.conv_bwd(ops, i, gm, f'{bp}._proj.weight', sc_g, sc_wd, None, accum_into=gcur)
+                return gcur
+        self._back.append(backward)
+        return h
+
+    # ---- whole network ----------------------------------------------------------------------------------
+    def lower(self) -> Plan:
+        comps = self.comps
+        cur: Optional[T] = None
+        named = {}
+        idx = 0
+        while idx < len(comps):
+            c = comps[idx]
+            pre = f'_architecture.{idx}'
+            if c.kind == 'conv':
+                if cur is not None:
+                    raise NotImplementedError("a top-level convolution after the first component is not on the accelerated path")
+                k, s, pd = c.args
+                xin = self.slot('x', 'input', (self.N, c.cin, self.H, self.W), 'f32')
+                named['x'] = xin
+                xt = T(xin, self.N, self.H, self.W, c.cin)
+                g = self.geom(xt, c.cout, k, s, pd)
+                w, b = self.param(pre + '.weight', (c.cout, k, k, c.cin)), self.param(pre + '.bias', (c.cout,))
+                y = self.act(pre + ':y', self.N, g['P'], g['Q'], c.cout)
+                self.fwd.append(Op(ir.OP_STEM_FWD, buf=dict(x=xin, w=w, bias=b, y=y.s), dim=dict(g), note=pre))
+
+                def stem_back(dy: T, ops, g=g, xin=xin, pre=pre):
+                    dw, db = self.grad(pre + '.weight', (g['K'], g['R'], g['S'], g['C'])), self.grad(pre + '.bias', (g['K'],))
+                    ops.append(Op(ir.OP_STEM_WGRAD, buf=dict(x=xin, dy=dy.s, dw=dw, db=db, ws=self.ws()), dim=dict(g), note=pre))
+                    self._ws_need.append(('stem', dict(g)))
+                    self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
+                    return None
+                self._back.append(stem_back)
+                cur = y
+            elif c.kind == 'norm':
+                relu = idx + 1 < len(comps) and comps[idx + 1].kind == 'act'
+                coef = self.bn_coef(cur, pre)
+                out, _ = self.bn_apply(cur, coef, pre + ':out', relu=relu)
+
+                def norm_back(dout: T, ops, x=cur, out=out, coef=coef, pre=pre, relu=relu):
+                    dx, _ = self.bn_bwd(ops, dout, x, out if relu else None, coef, pre, pre + ':dx')
+                    return dx
+                self._back.append(norm_back)
+                cur = out
+                if relu:
+                    idx += 1
+            elif c.kind == 'act':
+                raise NotImplementedError("a standalone 'a' that does not follow 'n' is not on the accelerated path")
+            elif c.kind == 'maxpool':
+                k, s, pd = c.args
+                P, Q = (cur.H + 2 * pd - k) // s + 1, (cur.W + 2 * pd - k) // s + 1
+                y = self.act(pre + ':y', cur.N, P, Q, cur.C)
+                d = dict(N=cur.N, H=cur.H, W=cur.W, C=cur.C, k=k, stride=s, pad=pd)
+                self.fwd.append(Op(ir.OP_MAXPOOL_FWD, buf=dict(x=cur.s, y=y.s), dim=d, note=pre))
+
+                def mp_back(dy: T, ops, x=cur, d=d, pre=pre):
+                    dx = self.act(pre + ':dx', x.N, x.H, x.W, x.C)
+                    ops.append(Op(ir.OP_MAXPOOL_BWD, buf=dict(dy=dy.s, x=x.s, dx=dx.s), dim=d, note=pre))
+                    return dx
+                self._back.append(mp_back)
+                cur = y
+            elif c.kind == 'avgpool':
+                k, s, pd = c.args
+                nxt = comps[idx + 1] if idx + 1 < len(comps) else None
+                if not (nxt is not None and nxt.kind == 'fc' and pd == 0 and k == cur.H == cur.W):
+                    raise NotImplementedError("only a global average pool directly followed by 'f' is on the accelerated path")
+                fpre = f'_architecture.{idx + 1}'
+                O = nxt.cout
+                if nxt.cin != cur.C:
+                    raise ValueError(f"fc input width {nxt.cin} does not match {cur.C} pooled channels")
+                w, b = self.param(fpre + '.1.weight', (O, cur.C)), self.param(fpre + '.1.bias', (O,))
+                feat = self.f32('feat', (cur.N, cur.C))
+                logits = self.slot('logits', 'f32', (cur.N, O), 'f32')
+                named['logits'] = logits
+                d = dict(N=cur.N, HW=cur.H * cur.W, C=cur.C, O=O)
+                self.fwd.append(Op(ir.OP_POOL_FC_FWD, buf=dict(x=cur.s, w=w, b=b, feat=feat, logits=logits), dim=d, note=fpre))
+
+                def fc_back(_, ops, x=cur, d=d, feat=feat, w=w, fpre=fpre):
+                    dl = named['dlogits']
+                    dw, db = self.grad(fpre + '.1.weight', (d['O'], d['C'])), self.grad(fpre + '.1.bias', (d['O'],))
+                    dx = self.act(fpre + ':dx', x.N, x.H, x.W, x.C)
+                    ops.append(Op(ir.OP_POOL_FC_BWD, buf=dict(dlogits=dl, feat=feat, w=w, dx=dx.s, dw=dw, db=db), dim=d, note=fpre))
+                    self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
+                    return dx
+                self._back.append(fc_back)
+                cur = None
+                idx += 1
+            elif c.kind == 'fc':
+                raise NotImplementedError("'f' without a preceding global 'ap' is not on the accelerated path")
+            else:
+                for b_ in range(c.depth):
+                    cin = c.cin if b_ == 0 else c.cout
+                    cur = self.block(f'{pre}.{b_}', c.kind, cin, c.down and b_ == 0, cur)
+            idx += 1
+        if 'logits' not in named:
+            raise NotImplementedError("the network must end in 'apK,1,0 fI,O'")
+        n_logits = self.slots[named['logits']].shape
+        if self.with_loss:
+            named['labels'] = self.slot('labels', 'labels', (n_logits[0],), 'i64')
+            named['loss3'] = self.f32('loss3', (4,))
+        ops_b: List[Op] = []
+        if self.need_grad:
+            named['dlogits'] = self.slot('dlogits', 'f32', n_logits, 'f32')
+            if self.with_loss:
+                self.fwd.append(Op(ir.OP_SOFTMAX_CE, buf=dict(logits=named['logits'], labels=named['labels'], out3=named['loss3'],
+                                                              dlogits=named['dlogits']),
+                                   dim=dict(N=n_logits[0], O=n_logits[1]), fp=dict(scale=1.0 / n_logits[0])))
+            g = None
+            for back in reversed(self._back):
+                g = back(g, ops_b)
+        elif self.with_loss:
+            self.fwd.append(Op(ir.OP_SOFTMAX_CE, buf=dict(logits=named['logits'], labels=named['labels'], out3=named['loss3'], dlogits=-1),
+                               dim=dict(N=n_logits[0], O=n_logits[1]), fp=dict(scale=1.0 / n_logits[0])))
+        n_fwd = len(self.fwd)
+        hooks = list(self.fwd_hooks) + [Hook(h.at + n_fwd, h.action, h.slot, h.arg) for h in self.bwd_hooks]
+        if 'ws' in self._named:
+            named['ws'] = self._named['ws']
+        return Plan(self.slots, self.fwd + ops_b, n_fwd, hooks, self.grad_order, self.param_keys, named, self.train,
+                    meta=dict(ws_need=self._ws_need, N=self.N, H=self.H, W=self.W, fp32=self.fp32))
+
+
+def lower(spec, preact, use_proj, dropout_prob, N, H, W, **kw) -> Plan:
+    return Lowering(spec, preact, use_proj, dropout_prob, N, H, W, **kw).lower()

@@ -1,0 +1,249 @@
+"""
+Executable specification of the plan IR: runs a lowered Plan op by op on numpy arrays using the oracle's formulas.
+
+Used (a) on CPU to prove the lowering (data flow, fusion flags, gradient merges) against the golden vectors before any
+kernel exists, and (b) on the GPU box as the per-op checker for the HIP kernels (tests run one-op plans through both).
+Test infrastructure: imports oracle/, never imported by the product.
+"""
+import numpy as np
+
+from oracle import np_ops as ops
+from pytorch_ddp_resnet_amd.engine import ir
+
+
+def lowbias32(x):
+    x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16
+    x = (x * 0x7FEB352D) & 0xFFFFFFFF
+    x ^= x >> 15
+    x = (x * 0x846CA68B) & 0xFFFFFFFF
+    x ^= x >> 16
+    return x
+
+
+def keep_mask(n, p, site, step_seed):
+    """must match csrc/common.h: rn_keep().  keep iff hash >= p * 2^32."""
+    key = lowbias32((site * 0x9E3779B9) ^ (step_seed & 0xFFFFFFFF) ^ ((step_seed >> 32) * 0x85EBCA6B))
+    h = lowbias32(np.arange(n, dtype=np.uint64) ^ key)
+    thr = np.uint64(min(int(p * 4294967296.0), 0xFFFFFFFF))
+    return h >= thr
+
+
+def res_read(res, mode, N, H, W, C):
+    """the residual / merge operand as seen from a destination of shape [N,H,W,C]."""
+    if mode == ir.RES_SAME:
+        return res
+    out = np.zeros((N, H, W, C), dtype=res.dtype)
+    if mode == ir.RES_DOWN2PAD:
+        cr = res.shape[3]
+        out[..., :cr] = res[:, ::2, ::2, :][:, :H, :W, :]
+    elif mode == ir.RES_UP2:
+        out[:, ::2, ::2, :] = res[..., :C]
+    return out
+
+
+class NumpyPlan:
+    def __init__(self, plan, dtype=np.float64):
+        self.plan = plan
+        self.dtype = dtype
+        self.bufs = [None] * len(plan.slots)
+        for i, s in enumerate(plan.slots):
+            if s.role == 'ws':
+                continue
+            dt = {'T': dtype, 'f32': dtype, 'i64': np.int64, 'u8': np.uint8}[s.dtype]
+            self.bufs[i] = np.zeros(s.shape, dtype=dt)
+
+    # -- binding helpers -----------------------------------------------------------------------------------
+    def load_state(self, state):
+        """state: reference-keyed dict (conv weights KCRS)."""
+        for i, s in enumerate(self.plan.slots):
+            if s.role in ('param', 'buffer'):
+                v = np.asarray(state[s.key])
+                if v.ndim == 4:
+                    v = np.transpose(v, (0, 2, 3, 1))
+                self.bufs[i] = v.astype(self.dtype if v.dtype.kind == 'f' else v.dtype).reshape(s.shape).copy()
+
+    def grads(self):
+        """-> dict key -> gradient in reference layout (KCRS)."""
+        out = {}
+        for i, s in enumerate(self.plan.slots):
+            if s.role == 'grad':
+                v = self.bufs[i]
+                out[s.key] = np.transpose(v, (0, 3, 1, 2)) if v.ndim == 4 else v
+        return out
+
+    def state(self):
+        return {s.key: self.bufs[i] for i, s in enumerate(self.plan.slots) if s.role == 'buffer'}
+
+    def __getitem__(self, name):
+        return self.bufs[self.plan.slot_of[name]]
+
+    def __setitem__(self, name, v):
+        self.bufs[self.plan.slot_of[name]] = np.asarray(v)
+
+    # -- execution -----------------------------------------------------------------------------------------
+    def run(self, first, last, step_seed=0, hook_fn=None):
+        hooks = {}
+        for h in self.plan.hooks:
+            hooks.setdefault(h.at, []).append(h)
+        for i in range(first, last):
+            for h in hooks.get(i, []):
+                if hook_fn:
+                    hook_fn(self, h)
+            self.exec_op(self.plan.ops[i], step_seed)
+
+    def forward(self, **kw):
+        self.run(0, self.plan.n_fwd, **kw)
+
+    def backward(self, **kw):
+        self.run(self.plan.n_fwd, len(self.plan.ops), **kw)
+
+    def exec_op(self, op, step_seed):
+        B = lambda n: (self.bufs[op.buf[n]] if op.buf.get(n, -1) >= 0 else None)   # noqa: E731
+        d, k = op.dim, op.kind
+
+        def put(n, v):
+            self.bufs[op.buf[n]] = np.asarray(v, dtype=self.bufs[op.buf[n]].dtype).reshape(self.bufs[op.buf[n]].shape)
+
+        def w_kcrs(w, K, R, S, C):
+            return np.transpose(w.reshape(K, R, S, C), (0, 3, 1, 2))
+
+        if k == ir.OP_STEM_FWD:
+            x = np.transpose(B('x'), (0, 2, 3, 1)).astype(self.dtype)
+            put('y', ops.conv2d_fwd(x, w_kcrs(B('w'), d['K'], d['R'], d['S'], d['C']), d['stride'], d['pad'], B('bias')))
+        elif k == ir.OP_PACK_W:
+            w = B('w').reshape(d['K'], d['RS'], d['C'])
+            if op.buf.get('w_fwd', -1) >= 0:
+                put('w_fwd', w)
+            if op.buf.get('w_dgrad', -1) >= 0:
+                put('w_dgrad', np.transpose(w, (2, 1, 0)))
+        elif k == ir.OP_CONV_FWD:
+            y = ops.conv2d_fwd(B('x'), w_kcrs(B('w_fwd'), d['K'], d['R'], d['S'], d['C']), d['stride'], d['pad'])
+            if d.get('res_mode', 0):
+                y = y + res_read(B('res'), d['res_mode'], d['N'], d['P'], d['Q'], d['K'])
+            put('y', y)
+        elif k == ir.OP_BN_STATS:
+            x = B('x').reshape(d['M'], d['C'])
+            nblk = d['nblk']
+            rows = (d['M'] + nblk - 1) // nblk
+            part = np.zeros((nblk, 2, d['C']), dtype=self.dtype)
+            for b in range(nblk):
+                xb = x[b * rows:(b + 1) * rows]
+                part[b, 0], part[b, 1] = xb.sum(0), (xb * xb).sum(0)
+            put('partial', part)
+        elif k == ir.OP_BN_FINALIZE:
+            C = d['C']
+            gamma, beta = B('gamma'), B('beta')
+            if op.flags & ir.F_TRAIN:
+                part = B('partial').reshape(-1, 2, C)[:d['nblk']]
+                m = d['count']
+                mean = part[:, 0].sum(0) / m
+                var = np.maximum(part[:, 1].sum(0) / m - mean * mean, 0.0)
+                self.bufs[op.buf['running_mean']] = (1 - op.fp['momentum']) * B('running_mean') + op.fp['momentum'] * mean
+                self.bufs[op.buf['running_var']] = (1 - op.fp['momentum']) * B('running_var') + op.fp['momentum'] * var * (m / max(m - 1, 1))
+                self.bufs[op.buf['nbt']] = B('nbt') + 1
+            else:
+                mean, var = B('running_mean'), B('running_var')
+            invstd = 1.0 / np.sqrt(var + op.fp['eps'])
+            scale = gamma * invstd
+            put('coef', np.stack([scale, beta - mean * scale, mean, invstd]))
+        elif k == ir.OP_BN_APPLY:
+            coef = B('coef')
+            y = B('x') * coef[0] + coef[1]
+            if d.get('res_mode', 0):
+                y = y + res_read(B('res'), d['res_mode'], d['N'], d['H'], d['W'], d['C'])
+            if op.flags & ir.F_RELU:
+                y = np.maximum(y, 0)
+            p = op.fp.get('p', 0.0)
+            if p > 0:
+                y = y * keep_mask(y.size, p, op.seed, step_seed).reshape(y.shape) / (1.0 - p)
+            put('out', y)
+        elif k == ir.OP_DROPOUT_FWD:
+            x, p = B('x'), op.fp['p']
+            put('out', x * keep_mask(x.size, p, op.seed, step_seed).reshape(x.shape) / (1.0 - p))
+        elif k == ir.OP_DROPOUT_BWD:
+            p = op.fp['p']
+            put('din', B('dout') * (B('out') != 0) / (1.0 - p))
+        elif k == ir.OP_ADD_RES:
+            put('dst', B('dst') + res_read(B('res'), d['res_mode'], d['N'], d['H'], d['W'], d['C']))
+        elif k == ir.OP_MAXPOOL_FWD:
+            y, _ = ops.maxpool_fwd(B('x'), d['k'], d['stride'], d['pad'])
+            put('y', y)
+        elif k == ir.OP_MAXPOOL_BWD:
+            _, arg = ops.maxpool_fwd(B('x'), d['k'], d['stride'], d['pad'])
+            put('dx', ops.maxpool_bwd(B('dy'), arg, d['k'], d['stride'], d['pad'], d['H'], d['W']))
+        elif k == ir.OP_POOL_FC_FWD:
+            feat = B('x').reshape(d['N'], d['HW'], d['C']).mean(1)
+            put('feat', feat)
+            put('logits', ops.linear_fwd(feat, B('w'), B('b')))
+        elif k == ir.OP_POOL_FC_BWD:
+            df, dw, db = ops.linear_bwd(B('dlogits'), B('feat'), B('w'))
+            put('dw', dw); put('db', db)
+            if not (op.flags & ir.F_NO_DX):
+                dx = np.repeat(df[:, None, :] / d['HW'], d['HW'], axis=1)
+                put('dx', dx)
+        elif k in (ir.OP_BN_BWD_REDUCE, ir.OP_BN_BWD_APPLY):
+            coef = B('coef')
+            g = B('dout') * op.fp.get('gscale', 1.0)
+            if op.flags & ir.F_RELU:
+                g = g * (B('mask') > 0)
+            elif op.fp.get('gscale', 1.0) != 1.0:
+                g = g * (B('mask') != 0)
+            xhat = (B('x') - coef[2]) * coef[3]
+            C = d['C']
+            if k == ir.OP_BN_BWD_REDUCE:
+                nblk, M = d['nblk'], d['M']
+                rows = (M + nblk - 1) // nblk
+                gm, xm = g.reshape(M, C), xhat.reshape(M, C)
+                part = np.zeros((nblk, 2, C), dtype=self.dtype)
+                for b in range(nblk):
+                    part[b, 0] = gm[b * rows:(b + 1) * rows].sum(0)
+                    part[b, 1] = (gm[b * rows:(b + 1) * rows] * xm[b * rows:(b + 1) * rows]).sum(0)
+                put('partial', part)
+            else:
+                dsum = B('dsum')
+                if op.flags & ir.F_TRAIN:
+                    m = d['count']
+                    dx = coef[0] * (g - dsum[0] / m - xhat * (dsum[1] / m))
+                else:
+                    dx = coef[0] * g
+                if d.get('add_mode', 0):
+                    dx = dx + res_read(B('add'), d['add_mode'], d['N'], d['H'], d['W'], C)
+                put('dx', dx)
+                if op.flags & ir.F_WRITE_G:
+                    put('g_out', g)
+        elif k == ir.OP_BN_BWD_FINALIZE:
+            part = B('partial').reshape(-1, 2, d['C'])[:d['nblk']]
+            s = part.sum(0)
+            put('dsum', s)
+            put('dbeta', s[0]); put('dgamma', s[1])
+        elif k == ir.OP_CONV_DGRAD:
+            dx = ops.conv2d_dgrad(B('dy'), np.transpose(B('w_dgrad').reshape(d['C'], d['R'], d['S'], d['K']), (3, 0, 1, 2)),
+                                  d['stride'], d['pad'], d['H'], d['W'])
+            if d.get('res_mode', 0):
+                dx = dx + res_read(B('res'), d['res_mode'], d['N'], d['H'], d['W'], d['C'])
+            if op.flags & ir.F_ACCUM:
+                dx = dx + B('dx')
+            put('dx', dx)
+        elif k == ir.OP_CONV_WGRAD:
+            dw = ops.conv2d_wgrad(B('x'), B('dy'), d['R'], d['S'], d['stride'], d['pad'])   # KCRS
+            put('dw', np.transpose(dw, (0, 2, 3, 1)))
+        elif k == ir.OP_STEM_WGRAD:
+            x = np.transpose(B('x'), (0, 2, 3, 1)).astype(self.dtype)
+            dw = ops.conv2d_wgrad(x, B('dy'), d['R'], d['S'], d['stride'], d['pad'])
+            put('dw', np.transpose(dw, (0, 2, 3, 1)))
+            put('db', ops.bias_grad(B('dy')))
+        elif k == ir.OP_SOFTMAX_CE:
+            lg, lb = B('logits').astype(np.float64), B('labels')
+            n = len(lb)
+            out = np.zeros(4)
+            out[0] = ops.cross_entropy_fwd(lg, lb) * n
+            out[1] = ops.topk_err(lg, lb, 1) * n
+            out[2] = ops.topk_err(lg, lb, min(5, lg.shape[1])) * n
+            put('out3', out)
+            if op.buf.get('dlogits', -1) >= 0:
+                put('dlogits', ops.cross_entropy_bwd(lg, lb) * n * op.fp['scale'])
+        elif k == ir.OP_ZERO:
+            self.bufs[op.buf['dst']][...] = 0
+        else:
+            raise NotImplementedError(ir.OP_NAMES[k])
