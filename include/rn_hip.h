@@ -57,7 +57,8 @@ enum {
   RN_OP_STEM_WGRAD = 17,
   RN_OP_DROPOUT_BWD = 18,
   RN_OP_SOFTMAX_CE = 19,    /* metrics.py:10-29: mean CE loss, top-1/top-5 error counts, dlogits                             */
-  RN_OP_ZERO = 20           /* memset of a buffer slot (split-K / accumulation targets)                                       */
+  RN_OP_ZERO = 20,          /* memset of a buffer slot (split-K / accumulation targets)                                       */
+  RN_OP_ADD_RES = 21        /* dst += res (mapped): gradient merge behind a standalone v1 dropout                             */
 };
 
 /* flags */
@@ -94,6 +95,8 @@ int rn_version(void);
 /* ---- plan executor: the per-batch forward / backward of ResNet.forward as ONE host call each ---- */
 int rn_plan_create(const rn_op* ops, int n_ops, int n_bufs, int dtype, rn_plan** out);
 int rn_plan_bind(rn_plan* plan, const void* const* device_ptrs, int n_bufs);
+/* bytes available behind a workspace slot (wgrad split slabs): checked before every launch that uses it */
+int rn_plan_set_bytes(rn_plan* plan, int slot, size_t bytes);
 /* runs ops [first, last) in order on `stream`; step_seed feeds the dropout hash (same value forward and backward) */
 int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_seed, rn_stream stream);
 int rn_plan_num_ops(const rn_plan* plan);
@@ -130,9 +133,9 @@ int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void* ws, size_
                   const rn_conv_geom* g, rn_stream s);
 size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g);
 
-/* BatchNorm over a [M, C] view.  partial: [nblk][2][C] fp32, nblk = rn_bn_num_partials(M, C) */
-int rn_bn_num_partials(int64_t M, int C);
-int rn_bn_stats(const void* x, float* partial, int dtype, int64_t M, int C, rn_stream s);
+/* BatchNorm over a [M, C] view.  partial: [nblk][2][C] fp32 (sum, sum of squares) of nblk row slabs; the caller picks
+ * nblk (one workgroup per slab) */
+int rn_bn_stats(const void* x, float* partial, int nblk, int dtype, int64_t M, int C, rn_stream s);
 /* coef: [4][C] = scale, shift, mean, invstd.  train: batch stats from partial (count = number of rows over ALL
  * ranks that contributed to `partial`), running_mean/var (momentum, unbiased var) and num_batches_tracked updated
  * in place; eval: coef from running stats.  */
@@ -144,7 +147,7 @@ int rn_bn_apply(const void* x, const float* coef, const void* res, void* out, in
                 int res_mode, int res_C, int flags, float drop_p, uint32_t site, uint64_t step_seed, rn_stream s);
 /* g = dout * gscale * [mask_src > 0] (mask only with RN_F_RELU; gscale = 1/(1-p)); partial [nblk][2][C] */
 int rn_bn_bwd_reduce(const void* dout, const void* x, const void* mask_src, const float* coef, float* partial,
-                     int dtype, int64_t M, int C, int flags, float gscale, rn_stream s);
+                     int nblk, int dtype, int64_t M, int C, int flags, float gscale, rn_stream s);
 /* partial -> dsum [2][C]; dgamma/dbeta written (or accumulated with RN_F_ACCUM) */
 int rn_bn_bwd_finalize(const float* partial, int nblk, float* dsum, float* dgamma, float* dbeta, int C, int flags,
                        rn_stream s);
@@ -155,6 +158,8 @@ int rn_bn_bwd_apply(const void* dout, const void* x, const void* mask_src, const
 
 int rn_dropout_fwd(const void* x, void* out, int dtype, int64_t n, float p, uint32_t site, uint64_t step_seed, rn_stream s);
 int rn_dropout_bwd(const void* dout, const void* out, void* din, int dtype, int64_t n, float p, rn_stream s);
+/* dst[n,h,w,c] += res (RN_RES_* mapping) */
+int rn_add_res(void* dst, const void* res, int dtype, int N, int H, int W, int C, int res_mode, int res_C, rn_stream s);
 
 int rn_maxpool_fwd(const void* x, void* y, int dtype, int N, int H, int W, int C, int k, int stride, int pad, rn_stream s);
 int rn_maxpool_bwd(const void* dy, const void* x, void* dx, int dtype, int N, int H, int W, int C, int k, int stride,

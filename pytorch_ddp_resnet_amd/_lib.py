@@ -1,0 +1,62 @@
+"""ctypes binding of librn_hip.so (include/rn_hip.h).  Fails loudly when the library is missing: there is no
+CPU or eager-PyTorch fallback for the hot path."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'librn_hip.so')
+
+OP_NBUF, OP_NDIM = 8, 20
+
+
+class RnOp(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('flags', C.c_int32), ('buf', C.c_int32 * OP_NBUF), ('dim', C.c_int32 * OP_NDIM),
+                ('fp', C.c_float * 4), ('seed', C.c_uint32), ('pad_', C.c_int32)]
+
+
+class RnConvGeom(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in 'N H W C P Q K R S stride pad'.split()]
+
+
+class RnError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RnError(f"{LIB_PATH} not found: build the HIP engine first (python -c 'import __graft_entry__ as g; g.build()' "
+                      f"or make -C pytorch_ddp_resnet_amd/csrc). There is no fallback path.")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, u64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double, C.c_size_t
+    L.rn_last_error.restype = C.c_char_p
+    L.rn_version.restype = i32
+    L.rn_plan_create.argtypes = [C.POINTER(RnOp), i32, i32, i32, C.POINTER(vp)]
+    L.rn_plan_bind.argtypes = [vp, C.POINTER(vp), i32]
+    L.rn_plan_set_bytes.argtypes = [vp, i32, sz]
+    L.rn_plan_run.argtypes = [vp, i32, i32, u64, vp]
+    L.rn_plan_num_ops.argtypes = [vp]
+    L.rn_plan_destroy.argtypes = [vp]
+    L.rn_plan_destroy.restype = None
+    L.rn_conv_wgrad_ws_bytes.argtypes = [C.POINTER(RnConvGeom)]
+    L.rn_conv_wgrad_ws_bytes.restype = sz
+    L.rn_stem_wgrad_ws_bytes.argtypes = [C.POINTER(RnConvGeom)]
+    L.rn_stem_wgrad_ws_bytes.restype = sz
+    L.rn_softmax_ce.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
+    L.rn_sgd_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, f32, vp]
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        raise RnError(lib().rn_last_error().decode())
+
+
+def geom_struct(d):
+    return RnConvGeom(*[int(d[n]) for n in 'N H W C P Q K R S stride pad'.split()])

@@ -1,0 +1,131 @@
+"""
+``ResNet(architecture_spec, preact, use_proj, dropout_prob)`` -- the drop-in boundary of the hot path.
+
+Mirrors /root/reference/resnet/architectures/resnet.py: constructor (:25-32), spec grammar (:122-158, see spec.py),
+top-level module order / indices and therefore every ``state_dict`` key (``_architecture.{i}...``), weight init
+(:160-163: Kaiming-normal on top-level convs only, torch defaults elsewhere), ``forward(x)`` taking NCHW fp32 and
+returning fp32 logits that support autograd (:165-166), ``train()/eval()`` semantics of BatchNorm and Dropout.
+
+What differs is how forward/backward run: the spec is lowered once per input shape to a plan of fused HIP kernels
+(engine/lowering.py) executed by librn_hip.so; a single autograd.Function hands the parameter gradients back to
+PyTorch so optimizers, DistributedDataParallel hooks and checkpoints keep working unchanged.  There is no CPU or
+eager fallback: on a non-GPU device forward raises.
+"""
+from typing import Dict, Tuple
+
+import torch
+from torch import nn
+
+from .residual_block import ResidualBlock, BottleneckResidualBlock, _conv_holder
+from .spec import parse_spec
+
+_DTYPES = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16}
+
+
+class _EngineFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, seed, need_grad, *params):
+        eng = model._engine(x.shape, model.training, need_grad)
+        eng.bind(model._named_tensors(), x=x)
+        eng.forward(step_seed=seed, hook_fn=model._hook_fn)
+        ctx.eng, ctx.gen, ctx.seed, ctx.model = eng, eng.generation, seed, model
+        ctx.keys = model._param_keys
+        return eng.t('logits').clone()
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        eng = ctx.eng
+        if eng.generation != ctx.gen:
+            raise RuntimeError("the engine's activation buffers were overwritten by a later forward of the same shape/mode; "
+                               "call backward before the next forward")
+        if 'dlogits' not in eng.plan.slot_of:
+            raise RuntimeError("forward ran without gradient support")
+        eng.t('dlogits').copy_(dlogits)
+        eng.backward(step_seed=ctx.seed, hook_fn=ctx.model._hook_fn)
+        return (None, None, None, None) + tuple(eng.grad_view(k) for k in ctx.keys)
+
+
+class ResNet(nn.Module):
+    def __init__(self, architecture_spec: str, preact: bool, use_proj: bool, dropout_prob: float,
+                 compute_dtype: str = 'bf16', sync_bn: bool = False):
+        """:param compute_dtype: 'bf16' (bf16 MFMA, fp32 accumulate/statistics/master weights) or 'fp32' (exact-f32 MFMA:
+        the parity mode).  :param sync_bn: all-reduce BatchNorm statistics over the default process group."""
+        super().__init__()
+        self._architecture_spec = architecture_spec
+        self._preact, self._use_proj, self._dropout_prob = preact, use_proj, dropout_prob
+        self._compute_dtype = _DTYPES[compute_dtype]
+        self._sync_bn = sync_bn
+        self._architecture = self._parse_spec(architecture_spec)
+        self._init_weights()
+        self._engines: Dict[Tuple, object] = {}
+        self._param_keys = [k for k, _ in self.named_parameters()]
+        self._step = 0
+        self._seed_base = int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFF
+        self._hook_fn = None
+
+    # ---- construction (module order == reference order) ---------------------------------------------------------
+    def _parse_spec(self, spec: str) -> nn.Sequential:
+        ms = []
+        for comp in parse_spec(spec):
+            if comp.kind == 'conv':
+                k, s, p = comp.args
+                ms.append(_conv_holder(comp.cin, comp.cout, k, s, p, bias=True))
+            elif comp.kind == 'maxpool':
+                ms.append(nn.MaxPool2d(comp.args[0], comp.args[1], comp.args[2]))
+            elif comp.kind == 'avgpool':
+                ms.append(nn.AvgPool2d(comp.args[0], comp.args[1], comp.args[2]))
+            elif comp.kind in ('basic', 'bottleneck'):
+                cls = ResidualBlock if comp.kind == 'basic' else BottleneckResidualBlock
+                ms.append(nn.Sequential(*[
+                    cls(channels=comp.cin if b == 0 else comp.cout, downsample=comp.down and b == 0, preact=self._preact,
+                        use_proj=self._use_proj, dropout_prob=self._dropout_prob) for b in range(comp.depth)]))
+            elif comp.kind == 'norm':
+                ms.append(nn.BatchNorm2d(comp.cin))
+            elif comp.kind == 'act':
+                ms.append(nn.ReLU())
+            else:
+                ms.append(nn.Sequential(nn.Flatten(), nn.Linear(comp.cin, comp.cout)))
+        return nn.Sequential(*ms)
+
+    def _init_weights(self):
+        for m in self._architecture:
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight)
+
+    # ---- engine plumbing ---------------------------------------------------------------------------------------------
+    def _named_tensors(self):
+        d = dict(self.named_parameters())
+        d.update(dict(self.named_buffers()))
+        return d
+
+    def _engine(self, xshape, train: bool, need_grad: bool):
+        from ..engine.lowering import lower
+        from ..engine.executor import Engine
+        dev = next(self.parameters()).device
+        world = torch.distributed.get_world_size() if (self._sync_bn and torch.distributed.is_initialized()) else 1
+        key = (tuple(xshape), train, need_grad, str(dev), self._compute_dtype, world)
+        eng = self._engines.get(key)
+        if eng is None:
+            N, C, H, W = xshape
+            plan = lower(self._architecture_spec, self._preact, self._use_proj, self._dropout_prob, N, H, W, train=train,
+                         need_grad=need_grad, sync_bn=self._sync_bn, world_size=world, fp32=self._compute_dtype == torch.float32)
+            eng = Engine(plan, dev, self._compute_dtype)
+            self._engines[key] = eng
+        return eng
+
+    def _apply(self, fn, *a, **kw):
+        self._engines = {}          # device / dtype moves invalidate the bound buffers
+        return super()._apply(fn, *a, **kw)
+
+    def forward(self, x):
+        p0 = next(self.parameters())
+        if p0.device.type != 'cuda' or x.device != p0.device:
+            raise RuntimeError("ResNet.forward runs only on an MI355X ('cuda') device through librn_hip.so; "
+                               "there is no CPU / eager fallback (model on %s, input on %s)" % (p0.device, x.device))
+        if x.dtype != torch.float32 or not x.is_contiguous():
+            x = x.float().contiguous()
+        self._step += 1
+        seed = (self._seed_base + self._step) & 0x7FFFFFFFFFFFFFFF
+        params = [p for _, p in self.named_parameters()]
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # (grad mode is off inside Function.forward)
+        return _EngineFn.apply(self, x, seed, need_grad, *params)

@@ -1,0 +1,402 @@
+// BatchNorm2d (+ReLU, +Dropout, +residual) forward/backward as HBM-bound passes over an NHWC [M, C] view, gfx950.
+// Reference call sites: resnet.py:111-115 (top-level n a), residual_block.py:58-65,70-72,76-77,81-87,96-98 (basic),
+// :160-171,176-203,212-214 (bottleneck).  torch semantics kept: eps 1e-5, momentum 0.1, biased variance for
+// normalisation, unbiased variance into running_var, num_batches_tracked += 1.
+//
+// Every kernel moves 16 bytes per lane per access (8 bf16 / 4 f32), consecutive lanes on consecutive channel chunks
+// of one pixel row, so a wave reads/writes whole 1 KiB rows-of-rows; statistics are wave/LDS-reduced per workgroup
+// into [nblk][2][C] partial sums and combined in double by the finalize kernels (no float atomics: bitwise stable).
+#include "common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---- per-channel partial reductions over a slab of rows --------------------------------------------------
+// MODE 0: (sum x, sum x^2)            MODE 1: (sum g, sum g*xhat), g = dout*gscale*[mask>0]
+template <typename T, int MODE>
+__global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dout, const T* __restrict__ mask,
+                                                       const float* __restrict__ coef, float* __restrict__ partial, int M, int C,
+                                                       int rows_per_blk, int use_mask, float gscale) {
+  constexpr int CE = Elem<T>::CE;
+  __shared__ float red[2][NT][CE + 1];
+  const int CC = C / CE;
+  const int tid = threadIdx.x;
+  const int r_begin = blockIdx.x * rows_per_blk;
+  const int r_end = min(M, r_begin + rows_per_blk);
+  const int lanes = CC >= NT ? 1 : NT / CC;        // row lanes per chunk column
+  const int cols_per_pass = CC >= NT ? NT : CC;
+  for (int cbase = 0; cbase < CC; cbase += cols_per_pass) {
+    const int cg = cbase + (tid % cols_per_pass);
+    const int rl = tid / cols_per_pass;
+    float s0[CE], s1[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) s0[e] = s1[e] = 0.f;
+    const bool active = rl < lanes && cg < CC;
+    if (active) {
+      float mean[CE], invstd[CE];
+      if (MODE == 1) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { mean[e] = coef[2 * C + cg * CE + e]; invstd[e] = coef[3 * C + cg * CE + e]; }
+      }
+      for (int r = r_begin + rl; r < r_end; r += lanes) {
+        const size_t off = (size_t)r * C + (size_t)cg * CE;
+        Chunk<T> cx = load_chunk<T>(x + off);
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < CE; ++e) { float v = Elem<T>::to_f(cx.e[e]); s0[e] += v; s1[e] += v * v; }
+        } else {
+          Chunk<T> cd = load_chunk<T>(dout + off);
+          Chunk<T> cm;
+          if (use_mask) cm = load_chunk<T>(mask + off);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) {
+            float g = Elem<T>::to_f(cd.e[e]) * gscale;
+            if (use_mask && !(Elem<T>::to_f(cm.e[e]) > 0.f)) g = 0.f;
+            float xh = (Elem<T>::to_f(cx.e[e]) - mean[e]) * invstd[e];
+            s0[e] += g; s1[e] += g * xh;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { red[0][tid][e] = s0[e]; red[1][tid][e] = s1[e]; }
+    __syncthreads();
+    if (tid < cols_per_pass && cg < CC) {
+      float t0[CE], t1[CE];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) t0[e] = t1[e] = 0.f;
+      for (int l = 0; l < lanes; ++l) {
+        const int src = l * cols_per_pass + tid;
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { t0[e] += red[0][src][e]; t1[e] += red[1][src][e]; }
+      }
+      float* p0 = partial + ((size_t)blockIdx.x * 2 + 0) * C + cg * CE;
+      float* p1 = partial + ((size_t)blockIdx.x * 2 + 1) * C + cg * CE;
+#pragma unroll
+      for (int e = 0; e < CE; ++e) { p0[e] = t0[e]; p1[e] = t1[e]; }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                   long long* __restrict__ nbt, float* __restrict__ coef, int C, float eps, float momentum, int train) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c == 0 && train && nbt) nbt[0] += 1;
+  if (c >= C) return;
+  double mean, var;
+  if (train) {
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) { s += (double)partial[((size_t)b * 2) * C + c]; ss += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    mean = s / count;
+    var = ss / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+    rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
+    rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unbiased);
+  } else {
+    mean = (double)rmean[c];
+    var = (double)rvar[c];
+  }
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double scale = (double)gamma[c] * invstd;
+  coef[c] = (float)scale;
+  coef[C + c] = (float)((double)beta[c] - mean * scale);
+  coef[2 * C + c] = (float)mean;
+  coef[3 * C + c] = (float)invstd;
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dsum, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int C, int accum) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < nblk; ++b) { s += (double)partial[((size_t)b * 2) * C + c]; ss += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+  dsum[c] = (float)s;
+  dsum[C + c] = (float)ss;
+  if (accum) { dbeta[c] += (float)s; dgamma[c] += (float)ss; }
+  else { dbeta[c] = (float)s; dgamma[c] = (float)ss; }
+}
+
+// ---- elementwise passes: one 16-byte chunk per thread-iteration --------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef, ResDesc res, T* __restrict__ out,
+                                                      int H, int W, int C, long nchunks, int relu, float inv_keep, uint32_t key, uint32_t thr) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < nchunks; i += (long)gridDim.x * NT) {
+    const long pix = i / CC;
+    const int c0 = (int)(i - pix * CC) * CE;
+    Chunk<T> cx = load_chunk<T>(x + i * CE);
+    float v[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) v[e] = Elem<T>::to_f(cx.e[e]) * coef[c0 + e] + coef[C + c0 + e];
+    if (res.mode != RN_RES_NONE) {
+      const int hw = H * W;
+      const int n = (int)(pix / hw), rem = (int)(pix - (long)n * hw);
+      const int h = rem / W, w = rem - h * W;
+      res_add_chunk<T>(res, n, h, w, c0, v);
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+    if (thr) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e) v[e] = rn_keep(key, (uint32_t)(i * CE + e), thr) ? v[e] * inv_keep : 0.f;
+    }
+    Chunk<T> co;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) co.e[e] = Elem<T>::from_f(v[e]);
+    store_chunk<T>(out + i * CE, co);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ mask,
+                                                          const float* __restrict__ coef, const float* __restrict__ dsum, ResDesc add,
+                                                          T* __restrict__ dx, T* __restrict__ g_out, int H, int W, int C, long nchunks,
+                                                          int use_mask, int train, float gscale, float inv_count) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < nchunks; i += (long)gridDim.x * NT) {
+    const long pix = i / CC;
+    const int c0 = (int)(i - pix * CC) * CE;
+    Chunk<T> cd = load_chunk<T>(dout + i * CE);
+    Chunk<T> cx = load_chunk<T>(x + i * CE);
+    Chunk<T> cm;
+    if (use_mask) cm = load_chunk<T>(mask + i * CE);
+    float v[CE], g[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+      float gg = Elem<T>::to_f(cd.e[e]) * gscale;
+      if (use_mask && !(Elem<T>::to_f(cm.e[e]) > 0.f)) gg = 0.f;
+      g[e] = gg;
+      const float scale = coef[c0 + e];
+      if (train) {
+        const float xh = (Elem<T>::to_f(cx.e[e]) - coef[2 * C + c0 + e]) * coef[3 * C + c0 + e];
+        v[e] = scale * (gg - dsum[c0 + e] * inv_count - xh * (dsum[C + c0 + e] * inv_count));
+      } else {
+        v[e] = scale * gg;
+      }
+    }
+    if (add.mode != RN_RES_NONE) {
+      const int hw = H * W;
+      const int n = (int)(pix / hw), rem = (int)(pix - (long)n * hw);
+      const int h = rem / W, w = rem - h * W;
+      res_add_chunk<T>(add, n, h, w, c0, v);
+    }
+    Chunk<T> co;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) co.e[e] = Elem<T>::from_f(v[e]);
+    store_chunk<T>(dx + i * CE, co);
+    if (g_out) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e) co.e[e] = Elem<T>::from_f(g[e]);
+      store_chunk<T>(g_out + i * CE, co);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, long nchunks, float inv_keep, uint32_t key,
+                                                         uint32_t thr) {
+  constexpr int CE = Elem<T>::CE;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < nchunks; i += (long)gridDim.x * NT) {
+    Chunk<T> c = load_chunk<T>(x + i * CE);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) c.e[e] = Elem<T>::from_f(rn_keep(key, (uint32_t)(i * CE + e), thr) ? Elem<T>::to_f(c.e[e]) * inv_keep : 0.f);
+    store_chunk<T>(out + i * CE, c);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void dropout_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ out, T* __restrict__ din, long nchunks,
+                                                         float inv_keep) {
+  constexpr int CE = Elem<T>::CE;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < nchunks; i += (long)gridDim.x * NT) {
+    Chunk<T> d = load_chunk<T>(dout + i * CE);
+    Chunk<T> o = load_chunk<T>(out + i * CE);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) d.e[e] = Elem<T>::from_f(Elem<T>::to_f(o.e[e]) != 0.f ? Elem<T>::to_f(d.e[e]) * inv_keep : 0.f);
+    store_chunk<T>(din + i * CE, d);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(NT) void add_res_kernel(T* __restrict__ dst, ResDesc res, int H, int W, int C, long nchunks) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < nchunks; i += (long)gridDim.x * NT) {
+    const long pix = i / CC;
+    const int c0 = (int)(i - pix * CC) * CE;
+    Chunk<T> c = load_chunk<T>(dst + i * CE);
+    float v[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) v[e] = Elem<T>::to_f(c.e[e]);
+    const int hw = H * W;
+    const int n = (int)(pix / hw), rem = (int)(pix - (long)n * hw);
+    const int h = rem / W, w = rem - h * W;
+    res_add_chunk<T>(res, n, h, w, c0, v);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) c.e[e] = Elem<T>::from_f(v[e]);
+    store_chunk<T>(dst + i * CE, c);
+  }
+}
+
+inline int ew_grid(long nchunks) {
+  long b = (nchunks + NT - 1) / NT;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+inline void make_res(ResDesc& r, const void* p, int mode, int res_C, int H, int W, int C) {
+  r.ptr = p;
+  r.mode = p ? mode : RN_RES_NONE;
+  if (r.mode == RN_RES_SAME) { r.C = C; r.H = H; r.W = W; }
+  else if (r.mode == RN_RES_DOWN2PAD) { r.C = res_C; r.H = 2 * H; r.W = 2 * W; }
+  else if (r.mode == RN_RES_UP2) { r.C = res_C; r.H = (H + 1) / 2; r.W = (W + 1) / 2; }
+  else { r.C = r.H = r.W = 0; }
+}
+
+inline int check_mc(int dtype, long M, int C, const char* who) {
+  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "%s: bad dtype %d", who, dtype);
+  RN_CHECK_ARG(M > 0 && C > 0 && C % (dtype == RN_F32 ? 4 : 8) == 0, "%s: bad shape M=%ld C=%d", who, M, C);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int rn_bn_stats(const void* x, float* partial, int nblk, int dtype, int64_t M, int C, rn_stream s) {
+  if (int e = check_mc(dtype, M, C, "rn_bn_stats")) return e;
+  RN_CHECK_ARG(x && partial && nblk > 0 && M < (1L << 31), "rn_bn_stats: bad argument");
+  const int rows = (int)((M + nblk - 1) / nblk);
+  if (dtype == RN_F32)
+    hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const float*)x, nullptr, nullptr, nullptr, partial, (int)M, C, rows, 0, 1.f);
+  else
+    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const bf16_t*)x, nullptr, nullptr, nullptr, partial, (int)M, C, rows, 0, 1.f);
+  RN_CHECK_LAUNCH("bn_stats");
+  return 0;
+}
+
+extern "C" int rn_bn_finalize(const float* partial, int nblk, double count, const float* gamma, const float* beta, float* running_mean,
+                              float* running_var, int64_t* nbt, float* coef, int C, float eps, float momentum, int flags, rn_stream s) {
+  const int train = (flags & RN_F_TRAIN) ? 1 : 0;
+  RN_CHECK_ARG(gamma && beta && running_mean && running_var && coef && C > 0, "rn_bn_finalize: null pointer");
+  RN_CHECK_ARG(!train || (partial && nblk > 0 && count > 0), "rn_bn_finalize: train mode needs partial sums");
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, as_stream(s), partial, nblk, count, gamma, beta, running_mean, running_var,
+                     (long long*)nbt, coef, C, eps, momentum, train);
+  RN_CHECK_LAUNCH("bn_finalize");
+  return 0;
+}
+
+extern "C" int rn_bn_apply(const void* x, const float* coef, const void* res, void* out, int dtype, int N, int H, int W, int C, int res_mode,
+                           int res_C, int flags, float drop_p, uint32_t site, uint64_t step_seed, rn_stream s) {
+  const long M = (long)N * H * W;
+  if (int e = check_mc(dtype, M, C, "rn_bn_apply")) return e;
+  RN_CHECK_ARG(x && coef && out && drop_p >= 0.f && drop_p < 1.f, "rn_bn_apply: bad argument");
+  ResDesc r;
+  make_res(r, res, res_mode, res_C, H, W, C);
+  const int ce = dtype == RN_F32 ? 4 : 8;
+  const long nchunks = M * (C / ce);
+  RN_CHECK_ARG(drop_p == 0.f || M * C < (1L << 32), "rn_bn_apply: dropout index space exceeds 2^32 elements");
+  const uint32_t thr = drop_p > 0.f ? rn_drop_threshold(drop_p) : 0u;
+  const uint32_t key = rn_drop_key(site, step_seed);
+  const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+  const int relu = (flags & RN_F_RELU) ? 1 : 0;
+  if (dtype == RN_F32)
+    hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const float*)x, coef, r, (float*)out, H, W, C, nchunks, relu, inv_keep, key, thr);
+  else
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const bf16_t*)x, coef, r, (bf16_t*)out, H, W, C, nchunks, relu, inv_keep, key, thr);
+  RN_CHECK_LAUNCH("bn_apply");
+  return 0;
+}
+
+extern "C" int rn_bn_bwd_reduce(const void* dout, const void* x, const void* mask_src, const float* coef, float* partial, int nblk, int dtype,
+                                int64_t M, int C, int flags, float gscale, rn_stream s) {
+  if (int e = check_mc(dtype, M, C, "rn_bn_bwd_reduce")) return e;
+  const int use_mask = (flags & RN_F_RELU) ? 1 : 0;
+  RN_CHECK_ARG(dout && x && coef && partial && nblk > 0 && (!use_mask || mask_src) && M < (1L << 31), "rn_bn_bwd_reduce: bad argument");
+  const int rows = (int)((M + nblk - 1) / nblk);
+  if (dtype == RN_F32)
+    hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), dim3(nblk), dim3(NT), 0, as_stream(s), (const float*)x, (const float*)dout, (const float*)mask_src, coef, partial, (int)M, C, rows, use_mask, gscale);
+  else
+    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), dim3(nblk), dim3(NT), 0, as_stream(s), (const bf16_t*)x, (const bf16_t*)dout, (const bf16_t*)mask_src, coef, partial, (int)M, C, rows, use_mask, gscale);
+  RN_CHECK_LAUNCH("bn_bwd_reduce");
+  return 0;
+}
+
+extern "C" int rn_bn_bwd_finalize(const float* partial, int nblk, float* dsum, float* dgamma, float* dbeta, int C, int flags, rn_stream s) {
+  RN_CHECK_ARG(partial && dsum && dgamma && dbeta && nblk > 0 && C > 0, "rn_bn_bwd_finalize: bad argument");
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, as_stream(s), partial, nblk, dsum, dgamma, dbeta, C, (flags & RN_F_ACCUM) ? 1 : 0);
+  RN_CHECK_LAUNCH("bn_bwd_finalize");
+  return 0;
+}
+
+extern "C" int rn_bn_bwd_apply(const void* dout, const void* x, const void* mask_src, const float* coef, const float* dsum, const void* add,
+                               void* dx, void* g_out, int dtype, int N, int H, int W, int C, int add_mode, int add_C, int flags, float gscale,
+                               double count, rn_stream s) {
+  const long M = (long)N * H * W;
+  if (int e = check_mc(dtype, M, C, "rn_bn_bwd_apply")) return e;
+  const int use_mask = (flags & RN_F_RELU) ? 1 : 0, train = (flags & RN_F_TRAIN) ? 1 : 0;
+  RN_CHECK_ARG(dout && x && coef && dx && (!train || dsum) && (!use_mask || mask_src) && count > 0, "rn_bn_bwd_apply: bad argument");
+  RN_CHECK_ARG(!(flags & RN_F_WRITE_G) || g_out, "rn_bn_bwd_apply: RN_F_WRITE_G without g_out");
+  ResDesc r;
+  make_res(r, add, add_mode, add_C, H, W, C);
+  const int ce = dtype == RN_F32 ? 4 : 8;
+  const long nchunks = M * (C / ce);
+  void* g = (flags & RN_F_WRITE_G) ? g_out : nullptr;
+  const float inv_count = (float)(1.0 / count);
+  if (dtype == RN_F32)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const float*)dout, (const float*)x, (const float*)mask_src, coef, dsum, r, (float*)dx, (float*)g, H, W, C, nchunks, use_mask, train, gscale, inv_count);
+  else
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const bf16_t*)dout, (const bf16_t*)x, (const bf16_t*)mask_src, coef, dsum, r, (bf16_t*)dx, (bf16_t*)g, H, W, C, nchunks, use_mask, train, gscale, inv_count);
+  RN_CHECK_LAUNCH("bn_bwd_apply");
+  return 0;
+}
+
+extern "C" int rn_dropout_fwd(const void* x, void* out, int dtype, int64_t n, float p, uint32_t site, uint64_t step_seed, rn_stream s) {
+  RN_CHECK_ARG(x && out && p > 0.f && p < 1.f && n > 0 && n < (1L << 32), "rn_dropout_fwd: bad argument");
+  const int ce = dtype == RN_F32 ? 4 : 8;
+  RN_CHECK_ARG(n % ce == 0, "rn_dropout_fwd: n must be a multiple of %d", ce);
+  const long nchunks = n / ce;
+  const uint32_t thr = rn_drop_threshold(p), key = rn_drop_key(site, step_seed);
+  if (dtype == RN_F32)
+    hipLaunchKernelGGL((dropout_fwd_kernel<float>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const float*)x, (float*)out, nchunks, 1.f / (1.f - p), key, thr);
+  else
+    hipLaunchKernelGGL((dropout_fwd_kernel<bf16_t>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const bf16_t*)x, (bf16_t*)out, nchunks, 1.f / (1.f - p), key, thr);
+  RN_CHECK_LAUNCH("dropout_fwd");
+  return 0;
+}
+
+extern "C" int rn_dropout_bwd(const void* dout, const void* out, void* din, int dtype, int64_t n, float p, rn_stream s) {
+  RN_CHECK_ARG(dout && out && din && p > 0.f && p < 1.f && n > 0, "rn_dropout_bwd: bad argument");
+  const int ce = dtype == RN_F32 ? 4 : 8;
+  RN_CHECK_ARG(n % ce == 0, "rn_dropout_bwd: n must be a multiple of %d", ce);
+  const long nchunks = n / ce;
+  if (dtype == RN_F32)
+    hipLaunchKernelGGL((dropout_bwd_kernel<float>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const float*)dout, (const float*)out, (float*)din, nchunks, 1.f / (1.f - p));
+  else
+    hipLaunchKernelGGL((dropout_bwd_kernel<bf16_t>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const bf16_t*)dout, (const bf16_t*)out, (bf16_t*)din, nchunks, 1.f / (1.f - p));
+  RN_CHECK_LAUNCH("dropout_bwd");
+  return 0;
+}
+
+extern "C" int rn_add_res(void* dst, const void* res, int dtype, int N, int H, int W, int C, int res_mode, int res_C, rn_stream s) {
+  const long M = (long)N * H * W;
+  if (int e = check_mc(dtype, M, C, "rn_add_res")) return e;
+  RN_CHECK_ARG(dst && res && res_mode != RN_RES_NONE, "rn_add_res: bad argument");
+  ResDesc r;
+  make_res(r, res, res_mode, res_C, H, W, C);
+  const int ce = dtype == RN_F32 ? 4 : 8;
+  const long nchunks = M * (C / ce);
+  if (dtype == RN_F32)
+    hipLaunchKernelGGL((add_res_kernel<float>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (float*)dst, r, H, W, C, nchunks);
+  else
+    hipLaunchKernelGGL((add_res_kernel<bf16_t>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (bf16_t*)dst, r, H, W, C, nchunks);
+  RN_CHECK_LAUNCH("add_res");
+  return 0;
+}

@@ -1,0 +1,127 @@
+// Shared device/host helpers for librn_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/rn_hip.h"
+
+#define RN_OP_ADD_RES 21
+
+typedef __bf16 bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+void rn_set_error(const char* fmt, ...);
+
+#define RN_CHECK_ARG(cond, ...)              \
+  do {                                       \
+    if (!(cond)) {                           \
+      rn_set_error(__VA_ARGS__);             \
+      return 1;                              \
+    }                                        \
+  } while (0)
+
+#define RN_CHECK_LAUNCH(name)                                                   \
+  do {                                                                          \
+    hipError_t e__ = hipGetLastError();                                         \
+    if (e__ != hipSuccess) {                                                    \
+      rn_set_error("%s: launch failed: %s", name, hipGetErrorString(e__));     \
+      return 2;                                                                 \
+    }                                                                           \
+  } while (0)
+
+// ---- element traits: 16-byte chunks are the unit of every global / LDS access ----
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int CE = 4;  // elements per 16-byte chunk
+  __device__ static inline float to_f(float v) { return v; }
+  __device__ static inline float from_f(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int CE = 8;
+  __device__ static inline float to_f(bf16_t v) { return (float)v; }
+  __device__ static inline bf16_t from_f(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
+};
+
+// a 16-byte chunk viewed as CE elements of T
+template <typename T> struct Chunk {
+  union {
+    uint4 u;
+    T e[Elem<T>::CE];
+  };
+  __device__ Chunk() {}
+};
+
+template <typename T> __device__ inline Chunk<T> load_chunk(const T* p) {
+  Chunk<T> c;
+  c.u = *reinterpret_cast<const uint4*>(p);
+  return c;
+}
+template <typename T> __device__ inline void store_chunk(T* p, const Chunk<T>& c) {
+  *reinterpret_cast<uint4*>(p) = c.u;
+}
+
+// ---- dropout: counter-based keep mask, recomputed in the backward (tests/np_interp.py keep_mask is the spec) ----
+__host__ __device__ inline uint32_t rn_lowbias32(uint32_t x) {
+  x ^= x >> 16;
+  x *= 0x7FEB352Du;
+  x ^= x >> 15;
+  x *= 0x846CA68Bu;
+  x ^= x >> 16;
+  return x;
+}
+__host__ __device__ inline uint32_t rn_drop_key(uint32_t site, uint64_t step_seed) {
+  return rn_lowbias32((site * 0x9E3779B9u) ^ (uint32_t)(step_seed & 0xFFFFFFFFu) ^ ((uint32_t)(step_seed >> 32) * 0x85EBCA6Bu));
+}
+__host__ __device__ inline uint32_t rn_drop_threshold(float p) {
+  double t = (double)p * 4294967296.0;
+  return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+}
+__device__ inline bool rn_keep(uint32_t key, uint32_t idx, uint32_t thr) { return rn_lowbias32(idx ^ key) >= thr; }
+
+// ---- residual / merge operand (RN_RES_*): value seen at destination (n,h,w,c) of a [N,H,W,C] tensor ----
+struct ResDesc {
+  const void* ptr;
+  int mode;
+  int C;      // channels of the residual tensor
+  int H, W;   // spatial size of the residual tensor
+};
+
+template <typename T>
+__device__ inline float res_load1(const ResDesc& r, int n, int h, int w, int c) {
+  const T* p = reinterpret_cast<const T*>(r.ptr);
+  if (r.mode == RN_RES_SAME) {
+    return Elem<T>::to_f(p[(((size_t)n * r.H + h) * r.W + w) * r.C + c]);
+  } else if (r.mode == RN_RES_DOWN2PAD) {
+    if (c >= r.C) return 0.f;
+    return Elem<T>::to_f(p[(((size_t)n * r.H + 2 * h) * r.W + 2 * w) * r.C + c]);
+  } else {  // RN_RES_UP2
+    if ((h | w) & 1) return 0.f;
+    return Elem<T>::to_f(p[(((size_t)n * r.H + (h >> 1)) * r.W + (w >> 1)) * r.C + c]);
+  }
+}
+
+// chunk version: c is a multiple of CE; whole chunk is in or out (res C is a multiple of CE)
+template <typename T>
+__device__ inline void res_add_chunk(const ResDesc& r, int n, int h, int w, int c, float* v) {
+  constexpr int CE = Elem<T>::CE;
+  const T* p = reinterpret_cast<const T*>(r.ptr);
+  size_t off;
+  if (r.mode == RN_RES_SAME) {
+    off = (((size_t)n * r.H + h) * r.W + w) * r.C + c;
+  } else if (r.mode == RN_RES_DOWN2PAD) {
+    if (c >= r.C) return;
+    off = (((size_t)n * r.H + 2 * h) * r.W + 2 * w) * r.C + c;
+  } else {
+    if ((h | w) & 1) return;
+    off = (((size_t)n * r.H + (h >> 1)) * r.W + (w >> 1)) * r.C + c;
+  }
+  Chunk<T> ch = load_chunk<T>(p + off);
+#pragma unroll
+  for (int i = 0; i < CE; ++i) v[i] += Elem<T>::to_f(ch.e[i]);
+}
+
+static inline hipStream_t as_stream(rn_stream s) { return reinterpret_cast<hipStream_t>(s); }
+static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }

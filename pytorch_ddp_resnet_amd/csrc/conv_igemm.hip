@@ -1,0 +1,325 @@
+// Implicit-GEMM convolution on MFMA (gfx950): forward conv and data-gradient (transposed conv) of the block
+// convolutions of the reference (residual_block.py:34-57 3x3 s1|s2 p1 and 1x1 projections, :129-159 bottleneck
+// 1x1/3x3/1x1; bias=False everywhere).  One kernel covers all of them through a "tap table":
+//
+//   dst[n, p*ds+oh, q*ds+ow, k] (+)= sum_t sum_c src[n, p*ss+dh[t], q*ss+dw[t], c] * wt[k][widx[t]][c]   (+ res)
+//
+// GEMM view: M = N*Pc*Qc compute-grid pixels (MFMA rows), N = Kd output channels (MFMA columns), K = taps*Cs.
+// forward:  ss=stride, taps=(r-pad, s-pad), ds=1.   dgrad stride 1: ss=1, taps=(pad-r, pad-s), wt=CRSK pack.
+// dgrad stride 2: one launch per output parity class (ds=2, (oh,ow) in {0,1}^2) with that class's tap subset, so no
+// MFMA work is spent on structural zeros.
+//
+// Tiling: BM x BN block tile, 4 waves (WM x WN), 32x32 MFMA tiles per wave; K streamed in 64-byte rows (32 bf16 / 16
+// f32) through a double-buffered, XOR-swizzled LDS image; global->register loads of tile i+1 are issued before the
+// MFMAs of tile i and written to LDS after them (one barrier per K tile).  f32 uses v_mfma_f32_32x32x2_f32 (exact
+// f32 FMA chain), bf16 v_mfma_f32_32x32x16_bf16, both fed by one 16-byte ds_read_b128 per operand per k-step.
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_TAPS = 9;
+constexpr int CPR = 4;  // 16-byte chunks per LDS row
+
+struct IgemmArgs {
+  const void* src;
+  const void* wt;
+  void* dst;
+  ResDesc res;
+  int N, Hs, Ws, Cs;
+  int Pc, Qc, M;
+  int Hd, Wd, Kd;
+  int ss, ds, oh, ow;
+  int nt, wrs, cpt, nk;
+  int accum;
+  int dh[MAX_TAPS], dw[MAX_TAPS], widx[MAX_TAPS];
+};
+
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    const float* af = reinterpret_cast<const float*>(&a);
+    const float* bf = reinterpret_cast<const float*>(&b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<bf16_t> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  }
+};
+
+__device__ inline int swz(int row, int chunk) { return row * CPR + (chunk ^ ((row >> 2) & 3)); }
+
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+  constexpr int CE = Elem<T>::CE;
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int AR = BM / 64, BR = (BN + 63) / 64;
+  static_assert(WM * WN == 4 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && BM % 64 == 0, "tile");
+  __shared__ uint4 lds[2][(BM + BN) * CPR];
+  __shared__ int tap_src[MAX_TAPS + 1], tap_w[MAX_TAPS + 1];
+
+  const int tid = threadIdx.x;
+  const int nmt = (a.M + BM - 1) / BM;
+  const int mt = blockIdx.x % nmt, ntile = blockIdx.x / nmt;
+  const int m0 = mt * BM, n0 = ntile * BN;
+  const T* __restrict__ src = reinterpret_cast<const T*>(a.src);
+  const T* __restrict__ wt = reinterpret_cast<const T*>(a.wt);
+
+  if (tid <= MAX_TAPS) {
+    int t = tid < a.nt ? tid : 0;
+    tap_src[tid] = tid < a.nt ? (a.dh[t] * a.Ws + a.dw[t]) * a.Cs : 0;
+    tap_w[tid] = tid < a.nt ? a.widx[t] * a.Cs : 0;
+  }
+
+  // ---- per-thread staging roles: chunk column c of rows r0 + 64*i ----
+  const int c = tid & 3, r0 = tid >> 2;
+  long abase[AR];
+  unsigned amask[AR];
+#pragma unroll
+  for (int i = 0; i < AR; ++i) {
+    int m = m0 + r0 + 64 * i;
+    amask[i] = 0;
+    abase[i] = 0;
+    if (m < a.M) {
+      int pq = a.Pc * a.Qc;
+      int n = m / pq, rem = m - n * pq;
+      int p = rem / a.Qc, q = rem - p * a.Qc;
+      int hb = p * a.ss, wb = q * a.ss;
+      abase[i] = (((long)n * a.Hs + hb) * a.Ws + wb) * a.Cs;
+      unsigned mk = 0;
+      for (int t = 0; t < a.nt; ++t) {
+        int h = hb + a.dh[t], w = wb + a.dw[t];
+        if ((unsigned)h < (unsigned)a.Hs && (unsigned)w < (unsigned)a.Ws) mk |= 1u << t;
+      }
+      amask[i] = mk;
+    }
+  }
+  long bbase[BR];
+  bool bok[BR];
+#pragma unroll
+  for (int i = 0; i < BR; ++i) {
+    int rn = r0 + 64 * i;
+    int k = n0 + rn;
+    bok[i] = (rn < BN) && (k < a.Kd);
+    bbase[i] = (long)k * a.wrs * a.Cs;
+  }
+  __syncthreads();
+
+  uint4 ra[AR], rb[BR];
+  int tap = 0, cc = c;
+  while (cc >= a.cpt) { cc -= a.cpt; ++tap; }
+
+  auto load_tile = [&]() {
+    const bool kv = tap < a.nt;
+    const int tp = kv ? tap : 0;
+    const int so = tap_src[tp] + cc * CE, wo = tap_w[tp] + cc * CE;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      ra[i] = make_uint4(0, 0, 0, 0);
+      if (kv && ((amask[i] >> tp) & 1)) ra[i] = *reinterpret_cast<const uint4*>(src + abase[i] + so);
+    }
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      rb[i] = make_uint4(0, 0, 0, 0);
+      if (kv && bok[i]) rb[i] = *reinterpret_cast<const uint4*>(wt + bbase[i] + wo);
+    }
+    cc += CPR;
+    while (cc >= a.cpt) { cc -= a.cpt; ++tap; }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) lds[buf][swz(r0 + 64 * i, c)] = ra[i];
+#pragma unroll
+    for (int i = 0; i < BR; ++i) {
+      int rn = r0 + 64 * i;
+      if (rn < BN) lds[buf][BM * CPR + swz(rn, c)] = rb[i];
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wave = tid >> 6, lane = tid & 63;
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int arow0 = wm * (BM / WM) + lr, brow0 = wn * (BN / WN) + lr;
+
+  if (a.nk > 0) {
+    load_tile();
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int it = 0; it < a.nk; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < a.nk) load_tile();
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int ch = 2 * ks + lh;
+      uint4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = lds[buf][swz(arow0 + 32 * i, ch)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = lds[buf][BM * CPR + swz(brow0 + 32 * j, ch)];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+    }
+    if (it + 1 < a.nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
+  T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
+  const bool dense = (a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + row;
+      if (m >= a.M) continue;
+      size_t pix;
+      int n = 0, hd = 0, wd = 0;
+      if (dense) {
+        pix = (size_t)m;
+      } else {
+        int pq = a.Pc * a.Qc;
+        n = m / pq;
+        int rem = m - n * pq;
+        int p = rem / a.Qc, q = rem - p * a.Qc;
+        hd = p * a.ds + a.oh;
+        wd = q * a.ds + a.ow;
+        pix = ((size_t)n * a.Hd + hd) * a.Wd + wd;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int k = n0 + wn * (BN / WN) + 32 * j + lr;
+        if (k >= a.Kd) continue;
+        float v = acc[i][j][r];
+        const size_t off = pix * a.Kd + k;
+        if (a.res.mode != RN_RES_NONE) {
+          if (dense) v += Elem<T>::to_f(reinterpret_cast<const T*>(a.res.ptr)[off]);
+          else v += res_load1<T>(a.res, n, hd, wd, k);
+        }
+        if (a.accum) v += Elem<T>::to_f(dst[off]);
+        dst[off] = Elem<T>::from_f(v);
+      }
+    }
+  }
+}
+
+template <typename T, int BM, int BN, int WM, int WN>
+int launch_cfg(const IgemmArgs& a, hipStream_t s) {
+  int nmt = cdiv(a.M, BM), nnt = cdiv(a.Kd, BN);
+  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN>), dim3(nmt * nnt), dim3(256), 0, s, a);
+  RN_CHECK_LAUNCH("igemm");
+  return 0;
+}
+
+template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
+  if (a.M <= 0) return 0;
+  const int K = a.Kd;
+  // column tile: the widest of {160,128,96,64,32} that wastes no 32-column MFMA tile
+  if (K % 160 == 0) return launch_cfg<T, 128, 160, 4, 1>(a, s);
+  if (K % 128 == 0) return launch_cfg<T, 128, 128, 2, 2>(a, s);
+  if (K % 96 == 0) return launch_cfg<T, 128, 96, 4, 1>(a, s);
+  if (K > 32) return launch_cfg<T, 128, 64, 2, 2>(a, s);
+  return launch_cfg<T, 128, 32, 4, 1>(a, s);
+}
+
+int check_geom(const rn_conv_geom* g, int dtype, const char* who) {
+  RN_CHECK_ARG(g != nullptr, "%s: null geometry", who);
+  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "%s: bad dtype %d", who, dtype);
+  const int ce = dtype == RN_F32 ? 4 : 8;
+  RN_CHECK_ARG(g->N > 0 && g->H > 0 && g->W > 0 && g->C > 0 && g->K > 0, "%s: non-positive shape", who);
+  RN_CHECK_ARG(g->C % ce == 0 && g->K % ce == 0, "%s: C=%d and K=%d must be multiples of %d for this dtype", who, g->C, g->K, ce);
+  RN_CHECK_ARG(g->R == g->S && g->R * g->S <= MAX_TAPS, "%s: kernel %dx%d unsupported", who, g->R, g->S);
+  RN_CHECK_ARG(g->stride == 1 || g->stride == 2, "%s: stride %d unsupported", who, g->stride);
+  RN_CHECK_ARG(g->P == (g->H + 2 * g->pad - g->R) / g->stride + 1 && g->Q == (g->W + 2 * g->pad - g->S) / g->stride + 1,
+               "%s: inconsistent output size", who);
+  RN_CHECK_ARG((long)g->N * g->H * g->W < (1L << 31) && (long)g->N * g->P * g->Q < (1L << 31), "%s: too many pixels", who);
+  return 0;
+}
+
+void fill_res(ResDesc& r, const void* res, int mode, int res_C, int dN, int dH, int dW, int dC) {
+  r.ptr = res;
+  r.mode = res ? mode : RN_RES_NONE;
+  if (r.mode == RN_RES_SAME) { r.C = dC; r.H = dH; r.W = dW; }
+  else if (r.mode == RN_RES_DOWN2PAD) { r.C = res_C; r.H = dH * 2; r.W = dW * 2; }
+  else if (r.mode == RN_RES_UP2) { r.C = res_C; r.H = (dH + 1) / 2; r.W = (dW + 1) / 2; }
+  else { r.C = r.H = r.W = 0; }
+}
+
+}  // namespace
+
+extern "C" int rn_conv_fwd(const void* x, const void* w_fwd, void* y, const void* res, int res_mode, int res_C, int dtype,
+                           const rn_conv_geom* g, rn_stream s) {
+  if (int e = check_geom(g, dtype, "rn_conv_fwd")) return e;
+  RN_CHECK_ARG(x && w_fwd && y, "rn_conv_fwd: null pointer");
+  IgemmArgs a{};
+  a.src = x; a.wt = w_fwd; a.dst = y;
+  fill_res(a.res, res, res_mode, res_C, g->N, g->P, g->Q, g->K);
+  a.N = g->N; a.Hs = g->H; a.Ws = g->W; a.Cs = g->C;
+  a.Pc = g->P; a.Qc = g->Q; a.M = g->N * g->P * g->Q;
+  a.Hd = g->P; a.Wd = g->Q; a.Kd = g->K;
+  a.ss = g->stride; a.ds = 1; a.oh = a.ow = 0;
+  a.nt = g->R * g->S; a.wrs = g->R * g->S;
+  for (int r = 0; r < g->R; ++r)
+    for (int t = 0; t < g->S; ++t) {
+      int i = r * g->S + t;
+      a.dh[i] = r - g->pad; a.dw[i] = t - g->pad; a.widx[i] = i;
+    }
+  const int ce = dtype == RN_F32 ? 4 : 8;
+  a.cpt = g->C / ce;
+  a.nk = cdiv((long)a.nt * a.cpt, CPR);
+  a.accum = 0;
+  return dtype == RN_F32 ? launch_igemm<float>(a, as_stream(s)) : launch_igemm<bf16_t>(a, as_stream(s));
+}
+
+extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* res, int res_mode, int res_C, int flags,
+                             int dtype, const rn_conv_geom* g, rn_stream s) {
+  if (int e = check_geom(g, dtype, "rn_conv_dgrad")) return e;
+  RN_CHECK_ARG(dy && w_dgrad && dx, "rn_conv_dgrad: null pointer");
+  const int st = g->stride;
+  const int ce = dtype == RN_F32 ? 4 : 8;
+  // one launch per parity class (a, b) of the input grid: h = st*p' + a, w = st*q' + b
+  for (int pa = 0; pa < st; ++pa)
+    for (int pb = 0; pb < st; ++pb) {
+      IgemmArgs a{};
+      a.src = dy; a.wt = w_dgrad; a.dst = dx;
+      fill_res(a.res, res, res_mode, res_C, g->N, g->H, g->W, g->C);
+      a.N = g->N; a.Hs = g->P; a.Ws = g->Q; a.Cs = g->K;
+      a.Pc = (g->H - pa + st - 1) / st; a.Qc = (g->W - pb + st - 1) / st;
+      if (a.Pc <= 0 || a.Qc <= 0) continue;
+      a.M = g->N * a.Pc * a.Qc;
+      a.Hd = g->H; a.Wd = g->W; a.Kd = g->C;
+      a.ss = 1; a.ds = st; a.oh = pa; a.ow = pb;
+      a.wrs = g->R * g->S;
+      int nt = 0;
+      for (int r = 0; r < g->R; ++r) {
+        if ((pa + g->pad - r) % st != 0) continue;           // (pa + pad - r) may be negative: C '%' keeps the sign, 0 stays 0
+        for (int t = 0; t < g->S; ++t) {
+          if ((pb + g->pad - t) % st != 0) continue;
+          // floor division for possibly negative numerators that are exact multiples of st
+          a.dh[nt] = (pa + g->pad - r) / st; a.dw[nt] = (pb + g->pad - t) / st; a.widx[nt] = r * g->S + t;
+          ++nt;
+        }
+      }
+      a.nt = nt;
+      a.cpt = g->K / ce;
+      a.nk = cdiv((long)nt * a.cpt, CPR);
+      a.accum = (flags & RN_F_ACCUM) ? 1 : 0;
+      if (nt == 0 && a.accum && a.res.mode == RN_RES_NONE) continue;   // nothing to add to this class
+      int e = dtype == RN_F32 ? launch_igemm<float>(a, as_stream(s)) : launch_igemm<bf16_t>(a, as_stream(s));
+      if (e) return e;
+    }
+  return 0;
+}

@@ -1,0 +1,295 @@
+// Weight gradient of the block convolutions (autograd of residual_block.py:34-57,129-159) on MFMA, gfx950.
+//
+//   dw[k][t][c] = sum_{m=(n,p,q)} dy[m][k] * x[n, p*stride+dh[t], q*stride+dw[t], c]          (fp32, KRSC)
+//
+// GEMM view per tap t: rows = K output channels (from dy), columns = C input channels (from x), reduction = the
+// N*P*Q output pixels.  Both operands are pixel-major in HBM (NHWC), i.e. the reduction index is the SLOW index of
+// both tiles, so the MFMA fragments are transposed reads of a [pixel][channel] LDS image:
+//   bf16: ds_read_b64_tr_b16 (gfx950 hardware transpose) feeding v_mfma_f32_16x16x32_bf16,
+//   f32 : ds_read_b32 feeding v_mfma_f32_16x16x4_f32 (one value per lane, rows of a tile are consecutive floats).
+// Work split: (K tile x C tile x tap) x pixel-splits; each block reduces its pixel range into an fp32 slab, a
+// second kernel sums the slabs in a fixed order (bitwise reproducible; no float atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int MAX_TAPS = 9;
+template <typename T> struct Bp { static constexpr int v = sizeof(T) == 4 ? 16 : 32; };  // pixels per K-step tile
+
+struct WgradArgs {
+  const void* x;
+  const void* dy;
+  float* out;        // slab base: [splits][K][RS][C] (or dw itself when splits == 1 and no accumulate)
+  int N, H, W, C, P, Q, K;
+  int stride, RS, nt;
+  int M;             // N*P*Q
+  int splits, rows_per_split;
+  int kt, ct;        // tiles along K and C
+  int dh[MAX_TAPS], dw[MAX_TAPS];
+};
+
+template <typename T, int TI, int TJ> struct WTile;  // per-wave MFMA work on one 32-pixel tile
+
+// bf16: A fragment of a 16-channel group = 8 pixels per lane via two transposed 4x16 block reads
+template <int TI, int TJ> struct WTile<bf16_t, TI, TJ> {
+  __device__ static inline bf16x8 frag(const char* tile, int rowb, int ch0, int lane) {
+    const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const char* a0 = tile + (size_t)(8 * g + q) * rowb + (ch0 + 4 * p) * 2;
+    typedef __attribute__((address_space(3))) bf16x4* lp;
+    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(a0));
+    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(a0 + 4 * rowb));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+  __device__ static inline void run(const char* ta, int rowa, int cha, const char* tb, int rowbb, int chb, int lane, f32x4 (&acc)[TI][TJ]) {
+    bf16x8 fa[TI], fb[TJ];
+#pragma unroll
+    for (int i = 0; i < TI; ++i) fa[i] = frag(ta, rowa, cha + 16 * i, lane);
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) fb[j] = frag(tb, rowbb, chb + 16 * j, lane);
+#pragma unroll
+    for (int i = 0; i < TI; ++i)
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+  }
+};
+
+template <int TI, int TJ> struct WTile<float, TI, TJ> {
+  __device__ static inline void run(const char* ta, int rowa, int cha, const char* tb, int rowbb, int chb, int lane, f32x4 (&acc)[TI][TJ]) {
+    const int kk = lane >> 4, i16 = lane & 15;
+#pragma unroll
+    for (int s = 0; s < Bp<float>::v / 4; ++s) {
+      float fa[TI], fb[TJ];
+      const int pix = 4 * s + kk;
+#pragma unroll
+      for (int i = 0; i < TI; ++i) fa[i] = *reinterpret_cast<const float*>(ta + (size_t)pix * rowa + (cha + 16 * i + i16) * 4);
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) fb[j] = *reinterpret_cast<const float*>(tb + (size_t)pix * rowbb + (chb + 16 * j + i16) * 4);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+  }
+};
+
+constexpr int padded_row(int bytes) { return bytes % 128 == 64 ? bytes : bytes + ((64 - bytes % 128) + 128) % 128; }
+
+// block tile (2*TI*16) x (2*TJ*16): 4 waves as 2x2, each TI x TJ MFMA tiles of 16x16
+template <typename T, int TI, int TJ>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+  constexpr int CE = Elem<T>::CE;
+  constexpr int BK_ = 2 * TI * 16, BC_ = 2 * TJ * 16;
+  constexpr int ROWA = padded_row(BK_ * (int)sizeof(T)), ROWB = padded_row(BC_ * (int)sizeof(T));
+  constexpr int CHA = BK_ / CE, CHB = BC_ / CE;          // 16-byte chunks per pixel row
+  constexpr int BP = Bp<T>::v, TPR = 256 / BP;          // pixels per tile, threads staging one pixel row
+  constexpr int NJA = (CHA + TPR - 1) / TPR, NJB = (CHB + TPR - 1) / TPR;
+  __shared__ __attribute__((aligned(16))) char lds[2][BP * (ROWA + ROWB)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int b = blockIdx.x;
+  const int split = b % a.splits; b /= a.splits;
+  const int t = b % a.nt; b /= a.nt;
+  const int ctile = b % a.ct, ktile = b / a.ct;
+  const int k0 = ktile * BK_, c0 = ctile * BC_;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
+  const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
+
+  const int m_begin = split * a.rows_per_split;
+  const int m_end = min(a.M, m_begin + a.rows_per_split);
+  const int niter = m_end > m_begin ? (m_end - m_begin + BP - 1) / BP : 0;
+
+  // staging role: pixel row tid/TPR of the tile, chunks tid%TPR + TPR*j
+  const int prow = tid / TPR, cl = tid % TPR;
+  const int pq = a.P * a.Q;
+  const int dht = a.dh[t], dwt = a.dw[t];
+
+  uint4 ra[NJA], rb[NJB];
+  auto load_tile = [&](int it) {
+    const int m = m_begin + it * BP + prow;
+    const bool mv = m < m_end;
+    bool xv = false;
+    size_t xoff = 0;
+    if (mv) {
+      int n = m / pq, rem = m - n * pq;
+      int p = rem / a.Q, q = rem - p * a.Q;
+      int h = p * a.stride + dht, w = q * a.stride + dwt;
+      xv = (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+      xoff = (((size_t)n * a.H + h) * a.W + w) * a.C;
+    }
+#pragma unroll
+    for (int j = 0; j < NJA; ++j) {
+      const int ch = cl + TPR * j;
+      ra[j] = make_uint4(0, 0, 0, 0);
+      if (mv && ch < CHA && k0 + ch * CE < a.K) ra[j] = *reinterpret_cast<const uint4*>(DY + (size_t)m * a.K + k0 + ch * CE);
+    }
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) {
+      const int ch = cl + TPR * j;
+      rb[j] = make_uint4(0, 0, 0, 0);
+      if (xv && ch < CHB && c0 + ch * CE < a.C) rb[j] = *reinterpret_cast<const uint4*>(X + xoff + c0 + ch * CE);
+    }
+  };
+  auto store_tile = [&](int buf) {
+    char* ta = lds[buf];
+    char* tb = lds[buf] + BP * ROWA;
+#pragma unroll
+    for (int j = 0; j < NJA; ++j) {
+      const int ch = cl + TPR * j;
+      if (ch < CHA) *reinterpret_cast<uint4*>(ta + prow * ROWA + ch * 16) = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NJB; ++j) {
+      const int ch = cl + TPR * j;
+      if (ch < CHB) *reinterpret_cast<uint4*>(tb + prow * ROWB + ch * 16) = rb[j];
+    }
+  };
+
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int j = 0; j < TJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int wi = wave >> 1, wj = wave & 1;
+  const int cha = wi * TI * 16, chb = wj * TJ * 16;   // channel offsets of this wave inside the block tile
+
+  if (niter > 0) {
+    load_tile(0);
+    store_tile(0);
+  }
+  __syncthreads();
+  for (int it = 0; it < niter; ++it) {
+    const int buf = it & 1;
+    if (it + 1 < niter) load_tile(it + 1);
+    WTile<T, TI, TJ>::run(lds[buf], ROWA, cha, lds[buf] + BP * ROWA, ROWB, chb, lane, acc);
+    if (it + 1 < niter) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // C/D layout of 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+  float* __restrict__ out = a.out + (size_t)split * a.K * a.RS * a.C;
+#pragma unroll
+  for (int i = 0; i < TI; ++i)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int k = k0 + cha + 16 * i + (lane >> 4) * 4 + r;
+      if (k >= a.K) continue;
+#pragma unroll
+      for (int j = 0; j < TJ; ++j) {
+        const int c = c0 + chb + 16 * j + (lane & 15);
+        if (c < a.C) out[((size_t)k * a.RS + t) * a.C + c] = acc[i][j][r];
+      }
+    }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n, int splits, int accum) {
+  long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long n4 = n >> 2;
+  for (; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 s = reinterpret_cast<const float4*>(ws)[i];
+    for (int k = 1; k < splits; ++k) {
+      float4 v = reinterpret_cast<const float4*>(ws + (size_t)k * n)[i];
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    if (accum) {
+      float4 o = reinterpret_cast<float4*>(dw)[i];
+      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
+    }
+    reinterpret_cast<float4*>(dw)[i] = s;
+  }
+}
+
+struct WCfg { int bk, bc; };
+
+inline int pick_tile(int n) {       // block tile edge from {160,128,64,32}: fewest tiles, then least padding
+  const int opts[4] = {160, 128, 64, 32};
+  int best = 32, best_tiles = 1 << 30, best_pad = 1 << 30;
+  for (int o : opts) {
+    int tiles = (n + o - 1) / o, pad = tiles * o - n;
+    long cost = (long)tiles * o;
+    if (cost < (long)best_tiles * best || (cost == (long)best_tiles * best && tiles < best_tiles)) { best = o; best_tiles = tiles; best_pad = pad; }
+  }
+  (void)best_pad;
+  return best;
+}
+
+int wgrad_splits(const rn_conv_geom* g, int bk, int bc) {
+  const long M = (long)g->N * g->P * g->Q;
+  const int tiles = cdiv(g->K, bk) * cdiv(g->C, bc) * g->R * g->S;
+  int splits = cdiv(768, tiles);
+  const int max_by_rows = (int)((M + 255) / 256);      // at least 8 K-steps per block
+  if (splits > max_by_rows) splits = max_by_rows;
+  if (splits < 1) splits = 1;
+  if (splits > 256) splits = 256;
+  return splits;
+}
+
+template <typename T, int TI, int TJ>
+int launch_w(const WgradArgs& a, hipStream_t s) {
+  int grid = a.kt * a.ct * a.nt * a.splits;
+  hipLaunchKernelGGL((wgrad_kernel<T, TI, TJ>), dim3(grid), dim3(256), 0, s, a);
+  RN_CHECK_LAUNCH("wgrad");
+  return 0;
+}
+
+template <typename T> int dispatch_w(const WgradArgs& a, int bk, int bc, hipStream_t s) {
+#define W_CASE(BK, BC) if (bk == BK && bc == BC) return launch_w<T, BK / 32, BC / 32>(a, s);
+  W_CASE(160, 160) W_CASE(160, 128) W_CASE(160, 64) W_CASE(160, 32)
+  W_CASE(128, 160) W_CASE(128, 128) W_CASE(128, 64) W_CASE(128, 32)
+  W_CASE(64, 160) W_CASE(64, 128) W_CASE(64, 64) W_CASE(64, 32)
+  W_CASE(32, 160) W_CASE(32, 128) W_CASE(32, 64) W_CASE(32, 32)
+#undef W_CASE
+  rn_set_error("wgrad: no tile %dx%d", bk, bc);
+  return 1;
+}
+
+}  // namespace
+
+extern "C" size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g) {
+  if (!g) return 0;
+  const int bk = pick_tile(g->K), bc = pick_tile(g->C);
+  const int splits = wgrad_splits(g, bk, bc);
+  return (size_t)splits * g->K * g->R * g->S * g->C * sizeof(float);
+}
+
+extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void* ws, size_t ws_bytes, int flags, int dtype,
+                             const rn_conv_geom* g, rn_stream s) {
+  RN_CHECK_ARG(g && x && dy && dw_krsc, "rn_conv_wgrad: null pointer");
+  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "rn_conv_wgrad: bad dtype");
+  const int ce = dtype == RN_F32 ? 4 : 8;
+  RN_CHECK_ARG(g->C % ce == 0 && g->K % ce == 0, "rn_conv_wgrad: C=%d, K=%d must be multiples of %d", g->C, g->K, ce);
+  RN_CHECK_ARG(g->R == g->S && g->R * g->S <= MAX_TAPS, "rn_conv_wgrad: kernel %dx%d unsupported", g->R, g->S);
+  RN_CHECK_ARG((long)g->N * g->P * g->Q < (1L << 31), "rn_conv_wgrad: too many pixels");
+  const int bk = pick_tile(g->K), bc = pick_tile(g->C);
+  WgradArgs a{};
+  a.x = x; a.dy = dy;
+  a.N = g->N; a.H = g->H; a.W = g->W; a.C = g->C; a.P = g->P; a.Q = g->Q; a.K = g->K;
+  a.stride = g->stride; a.RS = g->R * g->S; a.nt = a.RS;
+  for (int r = 0; r < g->R; ++r)
+    for (int t = 0; t < g->S; ++t) { a.dh[r * g->S + t] = r - g->pad; a.dw[r * g->S + t] = t - g->pad; }
+  a.M = g->N * g->P * g->Q;
+  a.splits = wgrad_splits(g, bk, bc);
+  a.rows_per_split = ((a.M + a.splits - 1) / a.splits + 31) / 32 * 32;
+  a.kt = cdiv(g->K, bk); a.ct = cdiv(g->C, bc);
+  const size_t n = (size_t)g->K * a.RS * g->C;
+  const bool direct = a.splits == 1 && !(flags & RN_F_ACCUM);
+  if (!direct) {
+    RN_CHECK_ARG(ws != nullptr && ws_bytes >= (size_t)a.splits * n * sizeof(float), "rn_conv_wgrad: workspace too small (%zu < %zu)",
+                 ws_bytes, (size_t)a.splits * n * sizeof(float));
+  }
+  a.out = direct ? dw_krsc : reinterpret_cast<float*>(ws);
+  int e = dtype == RN_F32 ? dispatch_w<float>(a, bk, bc, as_stream(s)) : dispatch_w<bf16_t>(a, bk, bc, as_stream(s));
+  if (e) return e;
+  if (!direct) {
+    int blocks = (int)((n / 4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), dw_krsc, (long)n,
+                       a.splits, (flags & RN_F_ACCUM) ? 1 : 0);
+    RN_CHECK_LAUNCH("wgrad_reduce");
+  }
+  return 0;
+}

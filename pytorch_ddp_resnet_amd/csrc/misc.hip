@@ -1,0 +1,337 @@
+// Small kernels around the conv/BN core: weight repack, MaxPool2d (resnet.py:83-87), global AvgPool2d + Flatten +
+// Linear (resnet.py:77-81,117-120), softmax cross-entropy + top-k error (metrics.py:10-29) and a fused flat SGD step
+// (torch.optim.SGD rule; optim_util.py:11-18, config.yaml:22-28).  gfx950.
+#include "common.h"
+#include <float.h>
+
+namespace {
+
+constexpr int NT = 256;
+
+// ---- weights: fp32 KRSC master -> [K][RS][C] and [C][RS][K] in the compute dtype ---------------------------
+template <typename T>
+__global__ void pack_w_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int K, int RS, int C) {
+  const long n = (long)K * RS * C;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = w[i];
+    if (wf) wf[i] = Elem<T>::from_f(v);
+    if (wd) {
+      const int c = (int)(i % C);
+      const long kr = i / C;
+      const int rs = (int)(kr % RS), k = (int)(kr / RS);
+      wd[((size_t)c * RS + rs) * K + k] = Elem<T>::from_f(v);
+    }
+  }
+}
+
+// ---- MaxPool2d(k, s, p), NHWC, -inf padding; backward recomputes the argmax (first maximum in (r,s) scan order wins) ---
+template <typename T>
+__global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int P, int Q, int k,
+                                                         int stride, int pad) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE;
+  const long n = (long)N * P * Q * CC;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const int cg = (int)(i % CC);
+    long pix = i / CC;
+    const int q = (int)(pix % Q); pix /= Q;
+    const int p = (int)(pix % P);
+    const int nn = (int)(pix / P);
+    float m[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) m[e] = -FLT_MAX;
+    for (int r = 0; r < k; ++r) {
+      const int h = p * stride + r - pad;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int s = 0; s < k; ++s) {
+        const int w = q * stride + s - pad;
+        if ((unsigned)w >= (unsigned)W) continue;
+        Chunk<T> c = load_chunk<T>(x + (((size_t)nn * H + h) * W + w) * C + cg * CE);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) m[e] = fmaxf(m[e], Elem<T>::to_f(c.e[e]));
+      }
+    }
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) o.e[e] = Elem<T>::from_f(m[e]);
+    store_chunk<T>(y + i * CE, o);
+  }
+}
+
+// gather form: each input element sums dy of the windows whose argmax it is (no atomics, no zero-fill pass)
+template <typename T>
+__global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, int N, int H, int W, int C,
+                                                         int P, int Q, int k, int stride, int pad) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE;
+  const long n = (long)N * H * W * CC;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const int cg = (int)(i % CC);
+    long pix = i / CC;
+    const int w = (int)(pix % W); pix /= W;
+    const int h = (int)(pix % H);
+    const int nn = (int)(pix / H);
+    Chunk<T> cx = load_chunk<T>(x + i * CE);
+    float g[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) g[e] = 0.f;
+    // windows (p, q) that contain (h, w): p*stride - pad <= h < p*stride - pad + k
+    const int p_lo = max(0, (h + pad - k + stride) / stride), p_hi = min(P - 1, (h + pad) / stride);
+    const int q_lo = max(0, (w + pad - k + stride) / stride), q_hi = min(Q - 1, (w + pad) / stride);
+    for (int p = p_lo; p <= p_hi; ++p)
+      for (int q = q_lo; q <= q_hi; ++q) {
+        // is (h, w) the first maximum of window (p, q)?
+        bool win[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) win[e] = true;
+        for (int r = 0; r < k; ++r) {
+          const int hh = p * stride + r - pad;
+          if ((unsigned)hh >= (unsigned)H) continue;
+          for (int s = 0; s < k; ++s) {
+            const int ww = q * stride + s - pad;
+            if ((unsigned)ww >= (unsigned)W || (hh == h && ww == w)) continue;
+            const bool before = hh < h || (hh == h && ww < w);
+            Chunk<T> c = load_chunk<T>(x + (((size_t)nn * H + hh) * W + ww) * C + cg * CE);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+              const float o = Elem<T>::to_f(c.e[e]), me = Elem<T>::to_f(cx.e[e]);
+              if (before ? o >= me : o > me) win[e] = false;
+            }
+          }
+        }
+        Chunk<T> d = load_chunk<T>(dy + (((size_t)nn * P + p) * Q + q) * C + cg * CE);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) if (win[e]) g[e] += Elem<T>::to_f(d.e[e]);
+      }
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) o.e[e] = Elem<T>::from_f(g[e]);
+    store_chunk<T>(dx + i * CE, o);
+  }
+}
+
+// ---- global average pool: feat[n][c] = mean_{hw} x[n][hw][c] ------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(NT) void gap_kernel(const T* __restrict__ x, float* __restrict__ feat, int HW, int C) {
+  constexpr int CE = Elem<T>::CE;
+  __shared__ float red[NT][CE + 1];
+  const int CC = C / CE;
+  const int n = blockIdx.x;
+  const int cols = CC >= NT ? NT : CC, lanes = CC >= NT ? 1 : NT / CC;
+  for (int cbase = 0; cbase < CC; cbase += cols) {
+    const int cg = cbase + threadIdx.x % cols, rl = threadIdx.x / cols;
+    float s[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) s[e] = 0.f;
+    if (rl < lanes && cg < CC)
+      for (int p = rl; p < HW; p += lanes) {
+        Chunk<T> c = load_chunk<T>(x + ((size_t)n * HW + p) * C + cg * CE);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) s[e] += Elem<T>::to_f(c.e[e]);
+      }
+#pragma unroll
+    for (int e = 0; e < CE; ++e) red[threadIdx.x][e] = s[e];
+    __syncthreads();
+    if (threadIdx.x < cols && cg < CC) {
+      float t[CE];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) t[e] = 0.f;
+      for (int l = 0; l < lanes; ++l)
+#pragma unroll
+        for (int e = 0; e < CE; ++e) t[e] += red[l * cols + threadIdx.x][e];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) feat[(size_t)n * C + cg * CE + e] = t[e] / (float)HW;
+    }
+    __syncthreads();
+  }
+}
+
+// one wave per (n, o): logits[n][o] = b[o] + <W[o,:], feat[n,:]>
+__global__ __launch_bounds__(NT) void fc_fwd_kernel(const float* __restrict__ feat, const float* __restrict__ w, const float* __restrict__ b,
+                                                    float* __restrict__ logits, int N, int C, int O) {
+  const long wid = ((long)blockIdx.x * NT + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
+  if (wid >= (long)N * O) return;
+  const int n = (int)(wid / O), o = (int)(wid - (long)n * O);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s = fmaf(feat[(size_t)n * C + c], w[(size_t)o * C + c], s);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  if (lane == 0) logits[(size_t)n * O + o] = s + b[o];
+}
+
+// dW[o][c] = sum_n dl[n][o] * feat[n][c]; db[o] = sum_n dl[n][o]   (thread per (o, c); c fastest -> coalesced)
+__global__ __launch_bounds__(NT) void fc_wgrad_kernel(const float* __restrict__ dl, const float* __restrict__ feat, float* __restrict__ dw,
+                                                      float* __restrict__ db, int N, int C, int O, int accum) {
+  const long i = (long)blockIdx.x * NT + threadIdx.x;
+  if (i >= (long)O * C) return;
+  const int o = (int)(i / C), c = (int)(i - (long)o * C);
+  float s = 0.f, sb = 0.f;
+  for (int n = 0; n < N; ++n) {
+    const float d = dl[(size_t)n * O + o];
+    s = fmaf(d, feat[(size_t)n * C + c], s);
+    sb += d;
+  }
+  dw[i] = accum ? dw[i] + s : s;
+  if (c == 0) db[o] = accum ? db[o] + sb : sb;
+}
+
+// dx[n][hw][c] = (sum_o dl[n][o] * W[o][c]) / HW, broadcast over hw
+template <typename T>
+__global__ __launch_bounds__(NT) void fc_dgrad_kernel(const float* __restrict__ dl, const float* __restrict__ w, T* __restrict__ dx, int HW, int C, int O) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE;
+  const int n = blockIdx.x;
+  for (int cg = threadIdx.x; cg < CC; cg += NT) {
+    float s[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) s[e] = 0.f;
+    for (int o = 0; o < O; ++o) {
+      const float d = dl[(size_t)n * O + o];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) s[e] = fmaf(d, w[(size_t)o * C + cg * CE + e], s[e]);
+    }
+    Chunk<T> c;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) c.e[e] = Elem<T>::from_f(s[e] / (float)HW);
+    for (int p = 0; p < HW; ++p) store_chunk<T>(dx + ((size_t)n * HW + p) * C + cg * CE, c);
+  }
+}
+
+// ---- softmax cross-entropy, top-1 / top-5 error counts, dlogits (single block: N is a batch, a few hundred rows) ----
+// rank rule for ties (torch.topk leaves it implementation-defined): an entry outranks the label iff it is strictly
+// greater, or equal with a lower index.
+__global__ __launch_bounds__(NT) void softmax_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, float* __restrict__ out3,
+                                                        float* __restrict__ dlogits, int N, int O, float scale) {
+  __shared__ float red[3][NT];
+  float nll = 0.f, e1 = 0.f, e5 = 0.f;
+  for (int n = threadIdx.x; n < N; n += NT) {
+    const float* row = logits + (size_t)n * O;
+    const int lab = (int)labels[n];
+    float mx = -FLT_MAX;
+    for (int o = 0; o < O; ++o) mx = fmaxf(mx, row[o]);
+    float se = 0.f;
+    for (int o = 0; o < O; ++o) se += expf(row[o] - mx);
+    const float lse = logf(se);
+    const float zl = row[lab];
+    nll += lse - (zl - mx);
+    int ahead = 0;
+    for (int o = 0; o < O; ++o) ahead += (row[o] > zl) || (row[o] == zl && o < lab);
+    e1 += ahead >= 1 ? 1.f : 0.f;
+    e5 += ahead >= (O < 5 ? O : 5) ? 1.f : 0.f;
+    if (dlogits) {
+      const float inv = 1.f / se;
+      for (int o = 0; o < O; ++o) dlogits[(size_t)n * O + o] = (expf(row[o] - mx) * inv - (o == lab ? 1.f : 0.f)) * scale;
+    }
+  }
+  red[0][threadIdx.x] = nll; red[1][threadIdx.x] = e1; red[2][threadIdx.x] = e5;
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    float s = 0.f;
+    for (int i = 0; i < NT; ++i) s += red[threadIdx.x][i];
+    out3[threadIdx.x] = s;
+  }
+}
+
+__global__ __launch_bounds__(NT) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n, float lr, float momentum,
+                                                 float dampening, float wd, int nesterov, int first, float gscale) {
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    float d = g[i] * gscale + wd * p[i];
+    if (momentum != 0.f) {
+      float b = first ? d : momentum * buf[i] + (1.f - dampening) * d;
+      buf[i] = b;
+      d = nesterov ? d + momentum * b : b;
+    }
+    p[i] -= lr * d;
+  }
+}
+
+inline int ew_grid(long n) {
+  long b = (n + NT - 1) / NT;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, int dtype, int K, int RS, int C, rn_stream s) {
+  RN_CHECK_ARG(w_krsc && (w_fwd || w_dgrad) && K > 0 && RS > 0 && C > 0, "rn_pack_weights: bad argument");
+  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "rn_pack_weights: bad dtype");
+  const long n = (long)K * RS * C;
+  if (dtype == RN_F32) hipLaunchKernelGGL((pack_w_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), w_krsc, (float*)w_fwd, (float*)w_dgrad, K, RS, C);
+  else hipLaunchKernelGGL((pack_w_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), w_krsc, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, K, RS, C);
+  RN_CHECK_LAUNCH("pack_weights");
+  return 0;
+}
+
+static int check_pool(int dtype, int N, int H, int W, int C, int k, int stride, int pad, const char* who) {
+  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "%s: bad dtype", who);
+  RN_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % (dtype == RN_F32 ? 4 : 8) == 0 && k > 0 && stride > 0 && pad >= 0 && 2 * pad <= k,
+               "%s: bad shape", who);
+  return 0;
+}
+
+extern "C" int rn_maxpool_fwd(const void* x, void* y, int dtype, int N, int H, int W, int C, int k, int stride, int pad, rn_stream s) {
+  if (int e = check_pool(dtype, N, H, W, C, k, stride, pad, "rn_maxpool_fwd")) return e;
+  RN_CHECK_ARG(x && y, "rn_maxpool_fwd: null pointer");
+  const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
+  const long n = (long)N * P * Q * (C / (dtype == RN_F32 ? 4 : 8));
+  if (dtype == RN_F32) hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const float*)x, (float*)y, N, H, W, C, P, Q, k, stride, pad);
+  else hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const bf16_t*)x, (bf16_t*)y, N, H, W, C, P, Q, k, stride, pad);
+  RN_CHECK_LAUNCH("maxpool_fwd");
+  return 0;
+}
+
+extern "C" int rn_maxpool_bwd(const void* dy, const void* x, void* dx, int dtype, int N, int H, int W, int C, int k, int stride, int pad, rn_stream s) {
+  if (int e = check_pool(dtype, N, H, W, C, k, stride, pad, "rn_maxpool_bwd")) return e;
+  RN_CHECK_ARG(dy && x && dx, "rn_maxpool_bwd: null pointer");
+  const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
+  const long n = (long)N * H * W * (C / (dtype == RN_F32 ? 4 : 8));
+  if (dtype == RN_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const float*)dy, (const float*)x, (float*)dx, N, H, W, C, P, Q, k, stride, pad);
+  else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, N, H, W, C, P, Q, k, stride, pad);
+  RN_CHECK_LAUNCH("maxpool_bwd");
+  return 0;
+}
+
+extern "C" int rn_pool_fc_fwd(const void* x, const float* w, const float* b, float* feat, float* logits, int dtype, int N, int HW, int C, int O, rn_stream s) {
+  RN_CHECK_ARG(x && w && b && feat && logits && N > 0 && HW > 0 && O > 0, "rn_pool_fc_fwd: bad argument");
+  RN_CHECK_ARG((dtype == RN_F32 || dtype == RN_BF16) && C % (dtype == RN_F32 ? 4 : 8) == 0, "rn_pool_fc_fwd: bad dtype / C=%d", C);
+  if (dtype == RN_F32) hipLaunchKernelGGL((gap_kernel<float>), dim3(N), dim3(NT), 0, as_stream(s), (const float*)x, feat, HW, C);
+  else hipLaunchKernelGGL((gap_kernel<bf16_t>), dim3(N), dim3(NT), 0, as_stream(s), (const bf16_t*)x, feat, HW, C);
+  RN_CHECK_LAUNCH("gap");
+  hipLaunchKernelGGL(fc_fwd_kernel, dim3(cdiv((long)N * O * 64, NT)), dim3(NT), 0, as_stream(s), feat, w, b, logits, N, C, O);
+  RN_CHECK_LAUNCH("fc_fwd");
+  return 0;
+}
+
+extern "C" int rn_pool_fc_bwd(const float* dlogits, const float* feat, const float* w, void* dx, float* dw, float* db, int dtype, int N, int HW, int C,
+                              int O, int flags, rn_stream s) {
+  RN_CHECK_ARG(dlogits && feat && w && dw && db && N > 0 && HW > 0 && O > 0, "rn_pool_fc_bwd: bad argument");
+  RN_CHECK_ARG((dtype == RN_F32 || dtype == RN_BF16) && C % (dtype == RN_F32 ? 4 : 8) == 0, "rn_pool_fc_bwd: bad dtype / C=%d", C);
+  hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv((long)O * C, NT)), dim3(NT), 0, as_stream(s), dlogits, feat, dw, db, N, C, O, (flags & RN_F_ACCUM) ? 1 : 0);
+  RN_CHECK_LAUNCH("fc_wgrad");
+  if (!(flags & RN_F_NO_DX)) {
+    RN_CHECK_ARG(dx != nullptr, "rn_pool_fc_bwd: dx is null");
+    if (dtype == RN_F32) hipLaunchKernelGGL((fc_dgrad_kernel<float>), dim3(N), dim3(NT), 0, as_stream(s), dlogits, w, (float*)dx, HW, C, O);
+    else hipLaunchKernelGGL((fc_dgrad_kernel<bf16_t>), dim3(N), dim3(NT), 0, as_stream(s), dlogits, w, (bf16_t*)dx, HW, C, O);
+    RN_CHECK_LAUNCH("fc_dgrad");
+  }
+  return 0;
+}
+
+extern "C" int rn_softmax_ce(const float* logits, const int64_t* labels, float* out3, float* dlogits, int N, int O, float scale, rn_stream s) {
+  RN_CHECK_ARG(logits && labels && out3 && N > 0 && O > 0, "rn_softmax_ce: bad argument");
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(NT), 0, as_stream(s), logits, (const long long*)labels, out3, dlogits, N, O, scale);
+  RN_CHECK_LAUNCH("softmax_ce");
+  return 0;
+}
+
+extern "C" int rn_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
+                           float weight_decay, int nesterov, int first_step, float grad_scale, rn_stream s) {
+  RN_CHECK_ARG(param && grad && n > 0 && (momentum == 0.f || momentum_buf), "rn_sgd_step: bad argument");
+  hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), param, grad, momentum_buf, (long)n, lr, momentum, dampening, weight_decay,
+                     nesterov, first_step, grad_scale);
+  RN_CHECK_LAUNCH("sgd");
+  return 0;
+}

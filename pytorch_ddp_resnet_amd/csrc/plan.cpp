@@ -1,0 +1,170 @@
+// Plan executor: runs the lowered op list of one ResNet forward / backward as a sequence of HIP launches on the
+// caller's stream, one host call per range.  Replaces the Python-side module dispatch of ResNet.forward
+// (/root/reference/resnet/architectures/resnet.py:165-166) and the autograd engine's backward walk
+// (/root/reference/resnet/algos/training.py:100,102).  No allocation, no synchronisation, no host<->device copies
+// happen here (hipGraph-capturable); the caller binds every buffer.
+#include <stdarg.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+extern "C" int rn_add_res(void* dst, const void* res, int dtype, int N, int H, int W, int C, int res_mode, int res_C, rn_stream s);
+
+static thread_local char g_err[512] = "";
+
+void rn_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* rn_last_error(void) { return g_err; }
+extern "C" int rn_version(void) { return 1; }
+
+struct rn_plan {
+  std::vector<rn_op> ops;
+  std::vector<void*> bufs;
+  std::vector<size_t> ws_bytes;   // bytes available behind a 'ws' slot (set through rn_plan_set_bytes)
+  int dtype;
+};
+
+extern "C" int rn_plan_create(const rn_op* ops, int n_ops, int n_bufs, int dtype, rn_plan** out) {
+  RN_CHECK_ARG(ops && out && n_ops > 0 && n_bufs > 0, "rn_plan_create: bad argument");
+  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "rn_plan_create: bad dtype %d", dtype);
+  for (int i = 0; i < n_ops; ++i) {
+    RN_CHECK_ARG(ops[i].kind >= RN_OP_STEM_FWD && ops[i].kind <= RN_OP_ADD_RES, "rn_plan_create: op %d has unknown kind %d", i, ops[i].kind);
+    for (int j = 0; j < RN_OP_NBUF; ++j)
+      RN_CHECK_ARG(ops[i].buf[j] >= -1 && ops[i].buf[j] < n_bufs, "rn_plan_create: op %d buffer index %d out of range", i, ops[i].buf[j]);
+  }
+  rn_plan* p = new rn_plan();
+  p->ops.assign(ops, ops + n_ops);
+  p->bufs.assign(n_bufs, nullptr);
+  p->ws_bytes.assign(n_bufs, 0);
+  p->dtype = dtype;
+  *out = p;
+  return 0;
+}
+
+extern "C" int rn_plan_bind(rn_plan* plan, const void* const* device_ptrs, int n_bufs) {
+  RN_CHECK_ARG(plan && device_ptrs && n_bufs == (int)plan->bufs.size(), "rn_plan_bind: bad argument");
+  for (int i = 0; i < n_bufs; ++i) plan->bufs[i] = const_cast<void*>(device_ptrs[i]);
+  return 0;
+}
+
+extern "C" int rn_plan_set_bytes(rn_plan* plan, int slot, size_t bytes) {
+  RN_CHECK_ARG(plan && slot >= 0 && slot < (int)plan->bufs.size(), "rn_plan_set_bytes: bad slot");
+  plan->ws_bytes[slot] = bytes;
+  return 0;
+}
+
+extern "C" int rn_plan_num_ops(const rn_plan* plan) { return plan ? (int)plan->ops.size() : 0; }
+extern "C" void rn_plan_destroy(rn_plan* plan) { delete plan; }
+
+static inline rn_conv_geom geom_of(const rn_op& o) {
+  rn_conv_geom g;
+  g.N = o.dim[0]; g.H = o.dim[1]; g.W = o.dim[2]; g.C = o.dim[3]; g.P = o.dim[4]; g.Q = o.dim[5]; g.K = o.dim[6];
+  g.R = o.dim[7]; g.S = o.dim[8]; g.stride = o.dim[9]; g.pad = o.dim[10];
+  return g;
+}
+
+static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
+  const rn_op& o = p->ops[idx];
+  const int dt = p->dtype;
+  auto B = [&](int i) -> void* { return o.buf[i] >= 0 ? p->bufs[o.buf[i]] : nullptr; };
+  auto need = [&](int n) -> bool {
+    for (int i = 0; i < n; ++i)
+      if (o.buf[i] >= 0 && p->bufs[o.buf[i]] == nullptr) return false;
+    return true;
+  };
+  if (!need(RN_OP_NBUF)) {
+    rn_set_error("rn_plan_run: op %d (kind %d) uses an unbound buffer", idx, o.kind);
+    return 1;
+  }
+  const int* d = o.dim;
+  switch (o.kind) {
+    case RN_OP_STEM_FWD: {
+      rn_conv_geom g = geom_of(o);
+      return rn_stem_conv_fwd((const float*)B(0), (const float*)B(1), (const float*)B(2), B(3), dt, &g, s);
+    }
+    case RN_OP_PACK_W:
+      return rn_pack_weights((const float*)B(0), B(1), B(2), dt, d[0], d[1], d[2], s);
+    case RN_OP_CONV_FWD: {
+      rn_conv_geom g = geom_of(o);
+      return rn_conv_fwd(B(0), B(1), B(2), B(3), d[11], d[12], dt, &g, s);
+    }
+    case RN_OP_BN_STATS:
+      return rn_bn_stats(B(0), (float*)B(1), d[2], dt, d[0], d[1], s);
+    case RN_OP_BN_FINALIZE:
+      return rn_bn_finalize((const float*)B(0), d[0], (double)d[1], (const float*)B(1), (const float*)B(2), (float*)B(3), (float*)B(4),
+                            (int64_t*)B(5), (float*)B(6), d[2], o.fp[0], o.fp[1], o.flags, s);
+    case RN_OP_BN_APPLY:
+      return rn_bn_apply(B(0), (const float*)B(1), B(2), B(3), dt, d[0], d[1], d[2], d[3], d[4], d[5], o.flags, o.fp[0], o.seed, step_seed, s);
+    case RN_OP_DROPOUT_FWD:
+      return rn_dropout_fwd(B(0), B(1), dt, ((int64_t)d[1] << 31) | (int64_t)d[0], o.fp[0], o.seed, step_seed, s);
+    case RN_OP_MAXPOOL_FWD:
+      return rn_maxpool_fwd(B(0), B(1), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], s);
+    case RN_OP_POOL_FC_FWD:
+      return rn_pool_fc_fwd(B(0), (const float*)B(1), (const float*)B(2), (float*)B(3), (float*)B(4), dt, d[0], d[1], d[2], d[3], s);
+    case RN_OP_POOL_FC_BWD:
+      return rn_pool_fc_bwd((const float*)B(0), (const float*)B(1), (const float*)B(2), B(3), (float*)B(4), (float*)B(5), dt, d[0], d[1], d[2], d[3],
+                            o.flags, s);
+    case RN_OP_MAXPOOL_BWD:
+      return rn_maxpool_bwd(B(0), B(1), B(2), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], s);
+    case RN_OP_BN_BWD_REDUCE:
+      return rn_bn_bwd_reduce(B(0), B(1), B(2), (const float*)B(3), (float*)B(4), d[2], dt, d[0], d[1], o.flags, o.fp[0], s);
+    case RN_OP_BN_BWD_FINALIZE:
+      return rn_bn_bwd_finalize((const float*)B(0), d[0], (float*)B(1), (float*)B(2), (float*)B(3), d[1], o.flags, s);
+    case RN_OP_BN_BWD_APPLY:
+      return rn_bn_bwd_apply(B(0), B(1), B(2), (const float*)B(3), (const float*)B(4), B(5), B(6), B(7), dt, d[0], d[1], d[2], d[3], d[4], d[5],
+                             o.flags, o.fp[0], (double)d[6], s);
+    case RN_OP_CONV_DGRAD: {
+      rn_conv_geom g = geom_of(o);
+      return rn_conv_dgrad(B(0), B(1), B(2), B(3), d[11], d[12], o.flags, dt, &g, s);
+    }
+    case RN_OP_CONV_WGRAD: {
+      rn_conv_geom g = geom_of(o);
+      return rn_conv_wgrad(B(0), B(1), (float*)B(2), B(3), o.buf[3] >= 0 ? p->ws_bytes[o.buf[3]] : 0, o.flags, dt, &g, s);
+    }
+    case RN_OP_STEM_WGRAD: {
+      rn_conv_geom g = geom_of(o);
+      if (o.buf[4] < 0 || p->ws_bytes[o.buf[4]] < rn_stem_wgrad_ws_bytes(&g)) {
+        rn_set_error("rn_plan_run: op %d: stem wgrad workspace too small", idx);
+        return 1;
+      }
+      return rn_stem_conv_wgrad((const float*)B(0), B(1), dt, (float*)B(2), (float*)B(3), B(4), (o.flags & RN_F_ACCUM) ? 1 : 0, &g, s);
+    }
+    case RN_OP_DROPOUT_BWD:
+      return rn_dropout_bwd(B(0), B(1), B(2), dt, ((int64_t)d[1] << 31) | (int64_t)d[0], o.fp[0], s);
+    case RN_OP_SOFTMAX_CE:
+      return rn_softmax_ce((const float*)B(0), (const int64_t*)B(1), (float*)B(2), (float*)B(3), d[0], d[1], o.fp[0], s);
+    case RN_OP_ZERO: {
+      size_t bytes = ((size_t)(uint32_t)d[1] << 31) | (size_t)(uint32_t)d[0];
+      hipError_t e = hipMemsetAsync(B(0), 0, bytes, as_stream(s));
+      if (e != hipSuccess) { rn_set_error("rn_plan_run: memset failed: %s", hipGetErrorString(e)); return 2; }
+      return 0;
+    }
+    case RN_OP_ADD_RES:
+      return rn_add_res(B(0), B(1), dt, d[0], d[1], d[2], d[3], d[4], d[5], s);
+    default:
+      rn_set_error("rn_plan_run: unknown op kind %d", o.kind);
+      return 1;
+  }
+}
+
+extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_seed, rn_stream stream) {
+  RN_CHECK_ARG(plan != nullptr, "rn_plan_run: null plan");
+  RN_CHECK_ARG(first >= 0 && last <= (int)plan->ops.size() && first <= last, "rn_plan_run: bad range [%d, %d)", first, last);
+  for (int i = first; i < last; ++i) {
+    int e = run_op(plan, i, step_seed, stream);
+    if (e) {
+      std::string msg = g_err;
+      rn_set_error("op %d (kind %d): %s", i, plan->ops[i].kind, msg.c_str());
+      return e;
+    }
+  }
+  return 0;
+}

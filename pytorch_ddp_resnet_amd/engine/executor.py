@@ -1,0 +1,148 @@
+"""
+Engine: owns the device buffers of one lowered plan and runs it through librn_hip.so.
+
+PyTorch is used here for device memory (torch.empty on the caching allocator), the current HIP stream and, in
+ddp.py, torch.distributed; all arithmetic of the hot path happens inside the library.
+"""
+import ctypes as C
+from typing import Callable, Dict, Optional
+
+import torch
+
+from .. import _lib
+from . import ir
+from .lowering import Plan
+
+_TORCH_DT = {'f32': torch.float32, 'i64': torch.int64, 'u8': torch.uint8}
+ALIGN = 64          # elements: every gradient starts on a 256-byte boundary inside the flat buffer
+
+
+class Engine:
+    def __init__(self, plan: Plan, device: torch.device, compute_dtype: torch.dtype):
+        if device.type != 'cuda':
+            raise _lib.RnError("the HIP engine needs an MI355X device ('cuda:N' under PyTorch-ROCm); there is no CPU path")
+        self.L = _lib.lib()
+        self.plan, self.device = plan, device
+        self.T = compute_dtype
+        self.rn_dtype = ir.RN_F32 if compute_dtype == torch.float32 else ir.RN_BF16
+        assert plan.meta['fp32'] == (compute_dtype == torch.float32)
+        self.generation = 0
+        # ---- flat gradient buffer, laid out in the order the backward produces the gradients ----
+        self.grad_offsets: Dict[str, int] = {}
+        shapes = {s.key: s for s in plan.slots if s.role == 'grad'}
+        off = 0
+        for key in plan.grad_order:
+            self.grad_offsets[key] = off
+            off += (shapes[key].numel + ALIGN - 1) // ALIGN * ALIGN
+        self.flat_grad = torch.zeros(max(off, 1), dtype=torch.float32, device=device)
+        # ---- workspace (shared by all wgrad launches: they are serialised on one stream) ----
+        ws_bytes = 0
+        for kind, g in plan.meta['ws_need']:
+            gs = _lib.geom_struct(g)
+            fn = self.L.rn_conv_wgrad_ws_bytes if kind == 'wgrad' else self.L.rn_stem_wgrad_ws_bytes
+            ws_bytes = max(ws_bytes, int(fn(C.byref(gs))))
+        self.ws_bytes = ws_bytes
+        # ---- buffers ----
+        self.tensors = [None] * len(plan.slots)
+        for i, s in enumerate(plan.slots):
+            if s.role in ('param', 'buffer', 'input', 'labels'):
+                continue
+            if s.role == 'grad':
+                o = self.grad_offsets[s.key]
+                self.tensors[i] = self.flat_grad[o:o + s.numel].view(s.shape if s.shape else ())
+            elif s.role == 'ws':
+                self.tensors[i] = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=device)
+            else:
+                dt = self.T if s.dtype == 'T' else _TORCH_DT[s.dtype]
+                self.tensors[i] = torch.zeros(s.shape if s.shape else (), dtype=dt, device=device)
+        # ---- native plan ----
+        ops = (_lib.RnOp * len(plan.ops))()
+        for j, op in enumerate(plan.ops):
+            buf, dim, fp = op.packed()
+            ops[j].kind, ops[j].flags, ops[j].seed = op.kind, op.flags, op.seed
+            for k in range(ir.OP_NBUF):
+                ops[j].buf[k] = buf[k]
+            for k in range(ir.OP_NDIM):
+                ops[j].dim[k] = dim[k]
+            for k in range(4):
+                ops[j].fp[k] = fp[k]
+        self._h = C.c_void_p()
+        _lib.check(self.L.rn_plan_create(ops, len(plan.ops), len(plan.slots), self.rn_dtype, C.byref(self._h)))
+        if 'ws' in plan.slot_of:
+            _lib.check(self.L.rn_plan_set_bytes(self._h, plan.slot_of['ws'], max(ws_bytes, 16)))
+        self._ptrs = (C.c_void_p * len(plan.slots))()
+        self._bound = None
+        self._hooks = {}
+        for h in plan.hooks:
+            self._hooks.setdefault(h.at, []).append(h)
+        self._hook_points = sorted(self._hooks)
+
+    def __del__(self):
+        try:
+            if getattr(self, '_h', None):
+                self.L.rn_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+    # ---- binding ------------------------------------------------------------------------------------------
+    def bind(self, named: Dict[str, torch.Tensor], x: Optional[torch.Tensor] = None, labels: Optional[torch.Tensor] = None):
+        """named: reference-keyed parameters and buffers (conv weights must be KRSC in memory)."""
+        sig = []
+        for i, s in enumerate(self.plan.slots):
+            if s.role in ('param', 'buffer'):
+                t = named[s.key]
+                if t.device != self.device or (s.dtype == 'f32' and t.dtype != torch.float32):
+                    raise _lib.RnError(f"{s.key}: expected a float32 tensor on {self.device}, got {t.dtype} on {t.device}")
+                if t.dim() == 4 and not t.permute(0, 2, 3, 1).is_contiguous():
+                    raise _lib.RnError(f"{s.key}: convolution weights must be channels_last (KRSC in memory)")
+                if t.dim() != 4 and not t.is_contiguous():
+                    raise _lib.RnError(f"{s.key}: must be contiguous")
+                self.tensors[i] = t
+            elif s.role == 'input' and x is not None:
+                if tuple(x.shape) != s.shape or x.dtype != torch.float32 or not x.is_contiguous() or x.device != self.device:
+                    raise _lib.RnError(f"input must be a contiguous float32 NCHW tensor of shape {s.shape} on {self.device}")
+                self.tensors[i] = x
+            elif s.role == 'labels' and labels is not None:
+                self.tensors[i] = labels
+            t = self.tensors[i]
+            sig.append(t.data_ptr() if t is not None else 0)
+        if sig != self._bound:
+            for i, p in enumerate(sig):
+                self._ptrs[i] = p
+            _lib.check(self.L.rn_plan_bind(self._h, self._ptrs, len(sig)))
+            self._bound = sig
+
+    # ---- execution ------------------------------------------------------------------------------------------
+    def run(self, first: int, last: int, step_seed: int, hook_fn: Optional[Callable] = None):
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        pos = first
+        for at in self._hook_points:
+            if at < first or at >= last:
+                continue
+            if hook_fn is None:
+                continue
+            if at > pos:
+                _lib.check(self.L.rn_plan_run(self._h, pos, at, step_seed, stream))
+                pos = at
+            for h in self._hooks[at]:
+                hook_fn(self, h)
+        if last > pos:
+            _lib.check(self.L.rn_plan_run(self._h, pos, last, step_seed, stream))
+
+    def forward(self, step_seed=0, hook_fn=None):
+        self.generation += 1
+        self.run(0, self.plan.n_fwd, step_seed, hook_fn)
+
+    def backward(self, step_seed=0, hook_fn=None):
+        self.run(self.plan.n_fwd, len(self.plan.ops), step_seed, hook_fn)
+
+    def t(self, name):
+        return self.tensors[self.plan.slot_of[name]]
+
+    def grad_view(self, key):
+        """the gradient of parameter `key`, shaped like the parameter (conv: [K,C,R,S] view of KRSC storage)."""
+        s = next(sl for sl in self.plan.slots if sl.role == 'grad' and sl.key == key)
+        o = self.grad_offsets[key]
+        g = self.flat_grad[o:o + s.numel].view(s.shape if s.shape else ())
+        return g.permute(0, 3, 1, 2) if g.dim() == 4 else g

@@ -1,0 +1,272 @@
+"""GPU parity of every HIP kernel against the oracle formulas, through the C ABI (one-op plans).
+fp32 path: tolerance 2e-5 relative to the tensor's max (exact-f32 MFMA, different summation order than the oracle's
+float64).  bf16 path: inputs are pre-rounded to bf16 on both sides, so the residual error is fp32 accumulation plus one
+bf16 rounding of the output (2^-9 relative): tolerance 6e-3."""
+import numpy as np
+import pytest
+import torch
+
+from filler import fill
+from pytorch_ddp_resnet_amd.engine import ir
+
+pytestmark = pytest.mark.gpu
+
+TOL = {True: 2e-5, False: 6e-3}
+DT = [True, False]      # fp32, bf16
+
+
+def H():
+    import gpu_harness
+    return gpu_harness
+
+
+CONV_GEOMS = [
+    # N, H, W, C, K, k, stride, pad
+    (2, 8, 8, 16, 32, 3, 1, 1),
+    (3, 8, 8, 160, 160, 3, 1, 1),        # BN=160 tile, M tail (192 rows)
+    (2, 9, 7, 24, 16, 3, 1, 1),          # odd sizes, K=16 masked columns, C not a multiple of the K tile
+    (2, 8, 8, 16, 32, 3, 2, 1),          # stride 2
+    (2, 8, 8, 64, 128, 1, 1, 0),         # 1x1
+    (2, 8, 8, 32, 64, 1, 2, 0),          # projection shortcut
+    (1, 16, 16, 96, 96, 3, 1, 1),        # BN=96 tile
+    (2, 7, 7, 128, 256, 3, 1, 1),        # ImageNet-like 7x7 map
+]
+
+
+@pytest.mark.parametrize('fp32', DT)
+@pytest.mark.parametrize('g', CONV_GEOMS)
+def test_conv_fwd_dgrad_wgrad(g, fp32):
+    h = H()
+    N, Hh, W, C, K, k, s, p = g
+    gm = h.geom(*g)
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, Hh, W, C)); w = b.slot('w', (K, k, k, C), 'f32')
+    wf = b.slot('wf', (K, k * k, C)); wd = b.slot('wd', (C, k * k, K))
+    y = b.slot('y', (N, gm['P'], gm['Q'], K)); dy = b.slot('dy', (N, gm['P'], gm['Q'], K)); dx = b.slot('dx', (N, Hh, W, C))
+    dw = b.slot('dw', (K, k, k, C), 'f32'); ws = b.slot('workspace', (0,), 'u8')
+    b.op(ir.OP_PACK_W, buf=dict(w=w, w_fwd=wf, w_dgrad=wd), dim=dict(K=K, RS=k * k, C=C))
+    b.op(ir.OP_CONV_FWD, buf=dict(x=x, w_fwd=wf, y=y, res=-1), dim=dict(gm, res_mode=0, res_C=0))
+    b.op(ir.OP_CONV_DGRAD, buf=dict(dy=dy, w_dgrad=wd, dx=dx, res=-1), dim=dict(gm, res_mode=0, res_C=0))
+    b.op(ir.OP_CONV_WGRAD, buf=dict(x=x, dy=dy, dw=dw, ws=ws), dim=dict(gm))
+    b.ws_need.append(('wgrad', gm))
+    plan = b.plan(fp32)
+    plan.slot_of['ws'] = ws
+    wv = fill((K, k, k, C), 1, (3.0 / (C * k * k)) ** 0.5)
+    if not fp32:
+        wv = h.bf16_round(wv)      # the master is fp32; round so both sides multiply the same values
+    hip, ref = h.run_both(plan, dict(x=fill((N, Hh, W, C), 2), w=wv, dy=fill((N, gm['P'], gm['Q'], K), 3)), fp32)
+    for name in ('y', 'dx', 'dw'):
+        assert h.max_rel(hip[name], ref[name]) < TOL[fp32], name
+
+
+@pytest.mark.parametrize('fp32', DT)
+@pytest.mark.parametrize('mode', [ir.RES_SAME, ir.RES_DOWN2PAD, ir.RES_UP2])
+def test_conv_epilogue_residual_and_accum(mode, fp32):
+    h = H()
+    N, Hh, C, K = 2, 8, 16, 32
+    gm = h.geom(N, Hh, Hh, C, K, 3, 1, 1)
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, Hh, Hh, C)); wf = b.slot('wf', (K, 9, C)); y = b.slot('y', (N, Hh, Hh, K))
+    rshape = {ir.RES_SAME: (N, Hh, Hh, K), ir.RES_DOWN2PAD: (N, 2 * Hh, 2 * Hh, K // 2), ir.RES_UP2: (N, Hh // 2, Hh // 2, 2 * K)}[mode]
+    r = b.slot('r', rshape)
+    b.op(ir.OP_CONV_FWD, buf=dict(x=x, w_fwd=wf, y=y, res=r), dim=dict(gm, res_mode=mode, res_C=rshape[3]))
+    # dgrad of a stride-2 conv, accumulating into a pre-filled dx, with the same residual mode on its own geometry
+    g2 = h.geom(N, 2 * Hh, 2 * Hh, K, C, 3, 2, 1)       # conv K->C, stride 2: dy is [N,Hh,Hh,C], dx is [N,2Hh,2Hh,K]
+    wd = b.slot('wd', (K, 9, C)); dx = b.slot('dx', (N, 2 * Hh, 2 * Hh, K))
+    r2shape = {ir.RES_SAME: (N, 2 * Hh, 2 * Hh, K), ir.RES_DOWN2PAD: (N, 4 * Hh, 4 * Hh, K // 2), ir.RES_UP2: (N, Hh, Hh, 2 * K)}[mode]
+    r2 = b.slot('r2', r2shape)
+    b.op(ir.OP_CONV_DGRAD, buf=dict(dy=x, w_dgrad=wd, dx=dx, res=r2), dim=dict(g2, res_mode=mode, res_C=r2shape[3]), flags=ir.F_ACCUM)
+    plan = b.plan(fp32)
+    hip, ref = h.run_both(plan, dict(x=fill((N, Hh, Hh, C), 4), wf=fill((K, 9, C), 5, 0.1), r=fill(rshape, 6), wd=fill((K, 9, C), 7, 0.1),
+                                     dx=fill((N, 2 * Hh, 2 * Hh, K), 8), r2=fill(r2shape, 9)), fp32)
+    assert h.max_rel(hip['y'], ref['y']) < TOL[fp32]
+    assert h.max_rel(hip['dx'], ref['dx']) < TOL[fp32]
+
+
+def test_wgrad_many_splits_bf16_exact_integers():
+    """integer-valued operands make every product and partial sum exact in fp32: the transposed-read fragment
+    layout (ds_read_b64_tr_b16 -> 16x16x32 MFMA) must reproduce the oracle bit for bit, asymmetric data."""
+    h = H()
+    g = (8, 16, 16, 32, 48, 3, 1, 1)
+    gm = h.geom(*g)
+    N, Hh, W, C, K, k, s, p = g
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, Hh, W, C)); dy = b.slot('dy', (N, Hh, W, K)); dw = b.slot('dw', (K, 3, 3, C), 'f32'); ws = b.slot('workspace', (0,), 'u8')
+    b.op(ir.OP_CONV_WGRAD, buf=dict(x=x, dy=dy, dw=dw, ws=ws), dim=dict(gm))
+    b.ws_need.append(('wgrad', gm))
+    plan = b.plan(False)
+    plan.slot_of['ws'] = ws
+    rng = np.random.RandomState(0)
+    xv = rng.randint(-3, 4, size=(N, Hh, W, C)).astype(np.float64)
+    dv = rng.randint(-2, 3, size=(N, Hh, W, K)).astype(np.float64)
+    hip, ref = h.run_both(plan, dict(x=xv, dy=dv), False)
+    assert np.array_equal(hip['dw'], ref['dw'])
+
+
+@pytest.mark.parametrize('fp32', DT)
+def test_igemm_exact_integers(fp32):
+    """A = identity-like weights with asymmetric data: catches a transposed C/D or operand map."""
+    h = H()
+    g = (2, 8, 8, 32, 32, 3, 1, 1)
+    gm = h.geom(*g)
+    N, Hh, W, C, K, k, s, p = g
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, Hh, W, C)); wf = b.slot('wf', (K, 9, C)); y = b.slot('y', (N, Hh, W, K))
+    b.op(ir.OP_CONV_FWD, buf=dict(x=x, w_fwd=wf, y=y, res=-1), dim=dict(gm, res_mode=0, res_C=0))
+    plan = b.plan(fp32)
+    rng = np.random.RandomState(1)
+    xv = rng.randint(-4, 5, size=(N, Hh, W, C)).astype(np.float64)
+    wv = rng.randint(-2, 3, size=(K, 9, C)).astype(np.float64)
+    hip, ref = h.run_both(plan, dict(x=xv, wf=wv), fp32)
+    if fp32:
+        assert np.array_equal(hip['y'], ref['y'])
+    else:
+        assert h.max_rel(hip['y'], ref['y']) < 4e-3     # |y| up to ~2^8: one bf16 rounding of the output
+
+
+@pytest.mark.parametrize('fp32', DT)
+@pytest.mark.parametrize('C,M_shape', [(16, (2, 8, 8)), (160, (3, 5, 7)), (64, (4, 16, 16))])
+def test_bn_forward_backward(C, M_shape, fp32):
+    h = H()
+    N, Hh, W = M_shape
+    M = N * Hh * W
+    nblk = 3
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, Hh, W, C)); part = b.slot('part', (nblk, 2, C), 'f32'); coef = b.slot('coef', (4, C), 'f32')
+    gamma = b.slot('gamma', (C,), 'f32'); beta = b.slot('beta', (C,), 'f32'); rm = b.slot('rm', (C,), 'f32'); rv = b.slot('rv', (C,), 'f32')
+    nbt = b.slot('nbt', (), 'i64'); out = b.slot('out', (N, Hh, W, C)); res = b.slot('res', (N, Hh, W, C))
+    dout = b.slot('dout', (N, Hh, W, C)); dpart = b.slot('dpart', (nblk, 2, C), 'f32'); dsum = b.slot('dsum', (2, C), 'f32')
+    dg = b.slot('dg', (C,), 'f32'); db = b.slot('db', (C,), 'f32'); dx = b.slot('dx', (N, Hh, W, C)); gout = b.slot('gout', (N, Hh, W, C))
+    add = b.slot('add', (N, Hh, W, C))
+    b.op(ir.OP_BN_STATS, buf=dict(x=x, partial=part), dim=dict(M=M, C=C, nblk=nblk))
+    b.op(ir.OP_BN_FINALIZE, buf=dict(partial=part, gamma=gamma, beta=beta, running_mean=rm, running_var=rv, nbt=nbt, coef=coef),
+         dim=dict(nblk=nblk, count=M, C=C), fp=dict(eps=1e-5, momentum=0.1), flags=ir.F_TRAIN)
+    b.op(ir.OP_BN_APPLY, buf=dict(x=x, coef=coef, res=res, out=out), dim=dict(N=N, H=Hh, W=W, C=C, res_mode=ir.RES_SAME, res_C=C),
+         fp=dict(p=0.3), flags=ir.F_RELU, seed=5)
+    fl = ir.F_RELU | ir.F_TRAIN
+    b.op(ir.OP_BN_BWD_REDUCE, buf=dict(dout=dout, x=x, mask=out, coef=coef, partial=dpart), dim=dict(M=M, C=C, nblk=nblk), fp=dict(gscale=1 / 0.7), flags=fl)
+    b.op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=dpart, dsum=dsum, dgamma=dg, dbeta=db), dim=dict(nblk=nblk, C=C))
+    b.op(ir.OP_BN_BWD_APPLY, buf=dict(dout=dout, x=x, mask=out, coef=coef, dsum=dsum, add=add, dx=dx, g_out=gout),
+         dim=dict(N=N, H=Hh, W=W, C=C, add_mode=ir.RES_SAME, add_C=C, count=M), fp=dict(gscale=1 / 0.7), flags=fl | ir.F_WRITE_G)
+    plan = b.plan(fp32)
+    hip, ref = h.run_both(plan, dict(x=fill((N, Hh, W, C), 11, 1.5, 0.4), gamma=fill((C,), 12, 0.25, 1.0), beta=fill((C,), 13, 0.2),
+                                     rm=fill((C,), 14, 0.1), rv=fill((C,), 15, 0.25, 1.0), res=fill((N, Hh, W, C), 16), dout=fill((N, Hh, W, C), 17),
+                                     add=fill((N, Hh, W, C), 18)), fp32, step_seed=987654321012)
+    tol = TOL[fp32]
+    for name in ('coef', 'rm', 'rv'):
+        assert h.max_rel(hip[name], ref[name]) < 2e-5, name
+    assert int(hip['nbt']) == 1
+    # the dropout keep pattern must be identical (counter-based hash), up to elements that sit at a rounding edge of relu
+    keep_h, keep_r = hip['out'] != 0, ref['out'] != 0
+    assert (keep_h != keep_r).mean() < 1e-3
+    same = keep_h == keep_r
+    assert np.abs(hip['out'] - ref['out'])[same].max() < tol * np.abs(ref['out']).max()
+    if same.all():
+        for name in ('dsum', 'dg', 'db', 'dx', 'gout'):
+            assert h.max_rel(hip[name], ref[name]) < max(tol, 1e-4), name
+
+
+@pytest.mark.parametrize('fp32', DT)
+def test_bn_eval_and_residual_modes(fp32):
+    h = H()
+    N, Hh, C = 2, 8, 32
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, Hh, Hh, C)); coef = b.slot('coef', (4, C), 'f32')
+    gamma = b.slot('gamma', (C,), 'f32'); beta = b.slot('beta', (C,), 'f32'); rm = b.slot('rm', (C,), 'f32'); rv = b.slot('rv', (C,), 'f32')
+    nbt = b.slot('nbt', (), 'i64')
+    r_dn = b.slot('r_dn', (N, 2 * Hh, 2 * Hh, C // 2)); r_up = b.slot('r_up', (N, Hh // 2, Hh // 2, 2 * C))
+    o1 = b.slot('o1', (N, Hh, Hh, C)); o2 = b.slot('o2', (N, Hh, Hh, C)); dst = b.slot('dst', (N, Hh, Hh, C))
+    b.op(ir.OP_BN_FINALIZE, buf=dict(partial=-1, gamma=gamma, beta=beta, running_mean=rm, running_var=rv, nbt=nbt, coef=coef),
+         dim=dict(nblk=0, count=1, C=C), fp=dict(eps=1e-5, momentum=0.1))
+    b.op(ir.OP_BN_APPLY, buf=dict(x=x, coef=coef, res=r_dn, out=o1), dim=dict(N=N, H=Hh, W=Hh, C=C, res_mode=ir.RES_DOWN2PAD, res_C=C // 2), flags=ir.F_RELU)
+    b.op(ir.OP_BN_APPLY, buf=dict(x=x, coef=coef, res=r_up, out=o2), dim=dict(N=N, H=Hh, W=Hh, C=C, res_mode=ir.RES_UP2, res_C=2 * C))
+    b.op(ir.OP_ADD_RES, buf=dict(dst=dst, res=r_up), dim=dict(N=N, H=Hh, W=Hh, C=C, res_mode=ir.RES_UP2, res_C=2 * C))
+    plan = b.plan(fp32)
+    hip, ref = h.run_both(plan, dict(x=fill((N, Hh, Hh, C), 21), gamma=fill((C,), 22, 0.25, 1.0), beta=fill((C,), 23, 0.2), rm=fill((C,), 24, 0.1),
+                                     rv=fill((C,), 25, 0.25, 1.0), r_dn=fill((N, 2 * Hh, 2 * Hh, C // 2), 26), r_up=fill((N, Hh // 2, Hh // 2, 2 * C), 27),
+                                     dst=fill((N, Hh, Hh, C), 28)), fp32)
+    assert int(hip['nbt']) == 0 and h.max_rel(hip['rm'], ref['rm']) == 0
+    for name in ('o1', 'o2', 'dst'):
+        assert h.max_rel(hip[name], ref[name]) < TOL[fp32], name
+
+
+@pytest.mark.parametrize('fp32', DT)
+@pytest.mark.parametrize('g', [(4, 8, 8, 3, 16, 3, 1, 1), (2, 16, 16, 3, 160, 3, 1, 1), (2, 16, 16, 3, 64, 7, 2, 3), (3, 9, 9, 3, 24, 3, 1, 1)])
+def test_stem_fwd_wgrad(g, fp32):
+    h = H()
+    N, Hh, W, C, K, k, s, p = g
+    gm = h.geom(*g)
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, C, Hh, W), 'f32'); w = b.slot('w', (K, k, k, C), 'f32'); bias = b.slot('bias', (K,), 'f32')
+    y = b.slot('y', (N, gm['P'], gm['Q'], K)); dy = b.slot('dy', (N, gm['P'], gm['Q'], K))
+    dw = b.slot('dw', (K, k, k, C), 'f32'); db = b.slot('db', (K,), 'f32'); ws = b.slot('workspace', (0,), 'u8')
+    b.op(ir.OP_STEM_FWD, buf=dict(x=x, w=w, bias=bias, y=y), dim=dict(gm))
+    b.op(ir.OP_STEM_WGRAD, buf=dict(x=x, dy=dy, dw=dw, db=db, ws=ws), dim=dict(gm))
+    b.ws_need.append(('stem', gm))
+    plan = b.plan(fp32)
+    plan.slot_of['ws'] = ws
+    hip, ref = h.run_both(plan, dict(x=fill((N, C, Hh, W), 31), w=fill((K, k, k, C), 32, 0.2), bias=fill((K,), 33, 0.1),
+                                     dy=fill((N, gm['P'], gm['Q'], K), 34)), fp32)
+    assert h.max_rel(hip['y'], ref['y']) < TOL[fp32]
+    assert h.max_rel(hip['dw'], ref['dw']) < 2e-5 and h.max_rel(hip['db'], ref['db']) < 2e-5
+
+
+@pytest.mark.parametrize('fp32', DT)
+def test_pools_fc_loss(fp32):
+    h = H()
+    N, Hh, C, O = 4, 8, 32, 10
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, Hh, Hh, C)); mp = b.slot('mp', (N, 4, 4, C)); dmp = b.slot('dmp', (N, 4, 4, C)); dxm = b.slot('dxm', (N, Hh, Hh, C))
+    w = b.slot('w', (O, C), 'f32'); bias = b.slot('bias', (O,), 'f32'); feat = b.slot('feat', (N, C), 'f32'); logits = b.slot('logits', (N, O), 'f32')
+    labels = b.slot('labels', (N,), 'i64'); out3 = b.slot('out3', (4,), 'f32'); dl = b.slot('dl', (N, O), 'f32')
+    dxf = b.slot('dxf', (N, 4, 4, C)); dwf = b.slot('dwf', (O, C), 'f32'); dbf = b.slot('dbf', (O,), 'f32')
+    dpool = dict(N=N, H=Hh, W=Hh, C=C, k=3, stride=2, pad=1)
+    b.op(ir.OP_MAXPOOL_FWD, buf=dict(x=x, y=mp), dim=dpool)
+    b.op(ir.OP_MAXPOOL_BWD, buf=dict(dy=dmp, x=x, dx=dxm), dim=dpool)
+    dfc = dict(N=N, HW=16, C=C, O=O)
+    b.op(ir.OP_POOL_FC_FWD, buf=dict(x=mp, w=w, b=bias, feat=feat, logits=logits), dim=dfc)
+    b.op(ir.OP_SOFTMAX_CE, buf=dict(logits=logits, labels=labels, out3=out3, dlogits=dl), dim=dict(N=N, O=O), fp=dict(scale=1.0 / N))
+    b.op(ir.OP_POOL_FC_BWD, buf=dict(dlogits=dl, feat=feat, w=w, dx=dxf, dw=dwf, db=dbf), dim=dfc)
+    plan = b.plan(fp32)
+    xv = fill((N, Hh, Hh, C), 41)
+    xv[0, 0:3, 0:3, :] = 0.5          # exact ties inside pooling windows: first maximum must win
+    hip, ref = h.run_both(plan, dict(x=xv, dmp=fill((N, 4, 4, C), 42), w=fill((O, C), 43, 0.3), bias=fill((O,), 44, 0.1),
+                                     labels=np.array([1, 3, 5, 9])), fp32)
+    tol = TOL[fp32]
+    assert h.max_rel(hip['mp'], ref['mp']) == 0
+    assert h.max_rel(hip['dxm'], ref['dxm']) < tol
+    for name in ('feat', 'logits', 'dl', 'dwf', 'dbf'):
+        assert h.max_rel(hip[name], ref[name]) < 1e-5, name
+    assert h.max_rel(hip['dxf'], ref['dxf']) < tol
+    assert h.max_rel(hip['out3'][:3], ref['out3'][:3]) < 1e-5
+
+
+def test_softmax_ce_matches_golden(golden):
+    """metrics.py:10-29 pinned by G6 (no-tie rows): loss, top-1/top-5, dlogits."""
+    h = H()
+    g = golden('g6_metrics')
+    N, O = g['logits'].shape
+    b = h.PlanBuilder()
+    logits = b.slot('logits', (N, O), 'f32'); labels = b.slot('labels', (N,), 'i64'); out3 = b.slot('out3', (4,), 'f32'); dl = b.slot('dl', (N, O), 'f32')
+    b.op(ir.OP_SOFTMAX_CE, buf=dict(logits=logits, labels=labels, out3=out3, dlogits=dl), dim=dict(N=N, O=O), fp=dict(scale=1.0 / N))
+    hip, _ = h.run_both(b.plan(True), dict(logits=g['logits'], labels=g['labels']), True)
+    assert abs(hip['out3'][0] / N - float(g['loss'])) < 1e-5
+    assert hip['out3'][1] / N == pytest.approx(float(g['top1_err'])) and hip['out3'][2] / N == pytest.approx(float(g['top5_err']))
+    assert h.max_rel(hip['dl'], g['dlogits']) < 1e-5
+
+
+def test_sgd_step_matches_torch():
+    import ctypes as C
+    from pytorch_ddp_resnet_amd import _lib
+    L = _lib.lib()
+    n = 10007
+    p = torch.from_numpy(fill((n,), 51)).cuda(); g = torch.from_numpy(fill((n,), 52)).cuda(); buf = torch.zeros(n, device='cuda')
+    pt = p.clone().requires_grad_(True)
+    opt = torch.optim.SGD([pt], lr=0.1, momentum=0.9, nesterov=True, weight_decay=5e-4)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    for step in range(3):
+        pt.grad = g.clone()
+        opt.step()
+        _lib.check(L.rn_sgd_step(p.data_ptr(), g.data_ptr(), buf.data_ptr(), n, 0.1, 0.9, 0.0, 5e-4, 1, int(step == 0), 1.0, st))
+    torch.cuda.synchronize()
+    assert (p - pt.detach()).abs().max().item() < 1e-6
