@@ -1,0 +1,195 @@
+"""
+bench.py -- images/sec of one training microbatch of the hot path (forward + loss + backward + gradient all-reduce;
+optimizer step excluded) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (default = the configuration BASELINE.json's metric is quoted on): WRN-28-10, CIFAR-10 shapes, batch 128 per
+GPU, dropout 0.3 as in /root/reference/models_dir/wrn-28-10-dropout_cifar10/config.yaml:15-18; synthetic N(0,1) NCHW
+fp32 batch resident in HBM (one fixed batch per rank, seed 1234+rank), random-init weights under manual_seed(0).
+Prints ONE JSON line (rank 0).  `roofline` is the MFMA roofline of the dominant kernel (the implicit-GEMM convolution
+launches: forward + dgrad + wgrad), measured with per-launch HIP events on the launch stream in an instrumented pass
+of the same steps; `cpu_baseline` times the torch-CPU port of the reference step (oracle/torch_model.py) on the host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: spec, preact, use_proj, dropout, classes, HxW, per-GPU batch, cpu-baseline batch
+    'rn20':      dict(spec='c3,16,3,1,1 n a r3 r3 r3 ap8,1,0 fc64,10', preact=False, use_proj=False, p=0.0, classes=10, hw=32, batch=128, cpu_batch=128),
+    'wrn-28-10': dict(spec='c3,160,3,1,1 r4 r4 r4 n a ap8,1,0 fc640,10', preact=True, use_proj=True, p=0.3, classes=10, hw=32, batch=128, cpu_batch=16),
+    'v2-164':    dict(spec='c3,64,3,1,1 b18 b18 b18 n a ap8,1,0 fc256,100', preact=True, use_proj=True, p=0.0, classes=100, hw=32, batch=128, cpu_batch=16),
+    'wrn-50-2a': dict(spec='c3,256,7,2,3 n a mp3,2,1 b3 b4 b6 b3 ap7,1,0 fc2048,1000', preact=False, use_proj=True, p=0.0, classes=1000, hw=224, batch=256, cpu_batch=4),
+    'wrn-50-2b': dict(spec='c3,512,7,2,3 n a mp3,2,1 b3 b4 b6 b3 ap7,1,0 fc4096,1000', preact=False, use_proj=True, p=0.0, classes=1000, hw=224, batch=256, cpu_batch=2),
+}
+
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}      # MI355X dense MFMA peaks (guides/MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def conv_flops(op):
+    d = op.dim
+    return 2.0 * d['N'] * d['P'] * d['Q'] * d['K'] * d['R'] * d['S'] * d['C']
+
+
+def cpu_baseline(cfg, steps=3):
+    """the reference's CPU training loop (torch-CPU port, fp32 NCHW, same region: fwd + loss/metrics + bwd) on a
+    bounded sample of the same workload: reduced batch, a few steps."""
+    from oracle import torch_model as tm
+    torch.manual_seed(0)
+    st = tm.make_trainable(tm.init_state(cfg['spec'], cfg['preact'], cfg['use_proj'], seed=0))
+    model = tm.TorchResNet(cfg['spec'], cfg['preact'], cfg['use_proj'], cfg['p'])
+    gen = torch.Generator().manual_seed(1234)
+    b = cfg['cpu_batch']
+    x = torch.randn(b, 3, cfg['hw'], cfg['hw'], generator=gen)
+    y = torch.randint(0, cfg['classes'], (b,), generator=gen)
+    tm.train_step(model, st, x, y)                     # warm-up
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tm.train_step(model, st, x, y)
+    dt = (time.perf_counter() - t0) / steps
+    return dict(value=b / dt, unit='images/sec', cores=torch.get_num_threads(), kind='port',
+                sample=f'{steps} steps of batch {b} (fwd+loss+bwd, fp32 NCHW torch-CPU port of the reference step), {dt * 1e3:.0f} ms/step',
+                cpu=_cpu_model(), torch=torch.__version__)
+
+
+def _cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--workload', default='wrn-28-10', choices=list(WORKLOADS))
+    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: the workload\'s)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--breakdown', action='store_true', help='print the per-op-kind time table to stderr')
+    ap.add_argument('--sync-bn', action='store_true')
+    args = ap.parse_args()
+
+    cfg = dict(WORKLOADS[args.workload])
+    if args.batch:
+        cfg['batch'] = args.batch
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
+    dev = torch.device('cuda', local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        torch.distributed.init_process_group('nccl', device_id=dev)        # RCCL over xGMI
+
+    from pytorch_ddp_resnet_amd import ResNet
+    from pytorch_ddp_resnet_amd.engine import ir
+    from pytorch_ddp_resnet_amd.ddp import GradReducer
+
+    torch.manual_seed(0)                                                       # identical replicas on every rank
+    model = ResNet(cfg['spec'], cfg['preact'], cfg['use_proj'], cfg['p'], compute_dtype=args.dtype, sync_bn=args.sync_bn).to(dev).train()
+    gen = torch.Generator().manual_seed(1234 + rank)
+    x = torch.randn(cfg['batch'], 3, cfg['hw'], cfg['hw'], generator=gen).to(dev)
+    y = torch.randint(0, cfg['classes'], (cfg['batch'],), generator=gen).to(dev)
+    reducer = GradReducer(model, world) if world > 1 else None
+
+    params = list(model.parameters())
+
+    def step():
+        for p_ in params:
+            p_.grad = None                                   # optimizer.zero_grad() of training.py:113 (set_to_none)
+        logits = model(x)
+        loss = torch.nn.functional.cross_entropy(logits, y)
+        loss.backward()
+        if reducer is not None:
+            reducer.finish()
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    ms = dt / args.steps * 1e3
+    value = world * cfg['batch'] * args.steps / dt
+
+    # ---- instrumented pass: per-launch HIP events on the launch stream (same steps, rank 0) ----
+    roof = None
+    if rank == 0:
+        eng = next(e for k, e in model._engines.items() if k[1] and k[2])
+        nprof = max(3, min(10, args.steps))
+        agg, conv_t, conv_f, nconv = {}, 0.0, 0.0, 0
+        for _ in range(nprof):
+            eng.profile(True)
+            step()
+            torch.cuda.synchronize()
+            for op, t_ms in eng.profile_read():
+                name = ir.OP_NAMES[op.kind]
+                agg[name] = agg.get(name, 0.0) + t_ms / nprof
+                if op.kind in (ir.OP_CONV_FWD, ir.OP_CONV_DGRAD, ir.OP_CONV_WGRAD):
+                    conv_t += t_ms
+                    conv_f += conv_flops(op)
+                    nconv += 1
+        eng.profile(False)
+        achieved = conv_f / (conv_t * 1e-3) / 1e12 if conv_t > 0 else 0.0
+        peak = PEAK_TFLOPS[args.dtype]
+        roof = dict(bound='mfma', achieved=round(achieved, 1), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4), traffic=None,
+                    kernel='igemm_kernel + wgrad_kernel (implicit-GEMM conv fwd/dgrad/wgrad launches)',
+                    launches_per_step=nconv // nprof, avg_launch_ms=round(conv_t / max(nconv, 1), 4),
+                    algorithmic_gflop_per_launch=round(conv_f / max(nconv, 1) / 1e9, 2),
+                    conv_ms_per_step=round(conv_t / nprof, 3), all_ops_ms_per_step=round(sum(agg.values()), 3))
+        if args.breakdown:
+            for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
+                print(f'  {k:22s} {v:9.3f} ms/step', file=sys.stderr)
+    if world > 1:
+        torch.distributed.barrier()
+
+    if rank == 0:
+        out = {
+            'metric': 'images/sec fwd+bwd (whole node)', 'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f"{args.workload} CIFAR-10 32x32" if cfg['hw'] == 32 else f"{args.workload} 224x224", 'architecture_spec': cfg['spec'],
+                       'preact': cfg['preact'], 'use_proj': cfg['use_proj'], 'dropout_prob': cfg['p'], 'batch_per_gpu': cfg['batch'],
+                       'global_batch': cfg['batch'] * world, 'parallelism': f'dp{world}', 'timed_region': 'fwd + CE loss + bwd + grad all-reduce (no optimizer step)',
+                       'sync_bn': bool(args.sync_bn)},
+            'roofline': roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

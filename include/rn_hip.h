@@ -100,6 +100,9 @@ int rn_plan_set_bytes(rn_plan* plan, int slot, size_t bytes);
 /* runs ops [first, last) in order on `stream`; step_seed feeds the dropout hash (same value forward and backward) */
 int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_seed, rn_stream stream);
 int rn_plan_num_ops(const rn_plan* plan);
+/* per-op hipEvent pairs on the launch stream; rn_plan_profile_read blocks and returns ms per op (0 = not run) */
+int rn_plan_profile(rn_plan* plan, int enable);
+int rn_plan_profile_read(rn_plan* plan, float* ms, int n);
 void rn_plan_destroy(rn_plan* plan);
 
 /* ---- geometry of a (transposed) convolution as an implicit GEMM ---- */

@@ -41,6 +41,8 @@ def lib():
     L.rn_plan_set_bytes.argtypes = [vp, i32, sz]
     L.rn_plan_run.argtypes = [vp, i32, i32, u64, vp]
     L.rn_plan_num_ops.argtypes = [vp]
+    L.rn_plan_profile.argtypes = [vp, i32]
+    L.rn_plan_profile_read.argtypes = [vp, C.POINTER(C.c_float), i32]
     L.rn_plan_destroy.argtypes = [vp]
     L.rn_plan_destroy.restype = None
     L.rn_conv_wgrad_ws_bytes.argtypes = [C.POINTER(RnConvGeom)]

@@ -39,6 +39,7 @@ __global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, 
 #pragma unroll
         for (int e = 0; e < CE; ++e) { mean[e] = coef[2 * C + cg * CE + e]; invstd[e] = coef[3 * C + cg * CE + e]; }
       }
+#pragma unroll 4
       for (int r = r_begin + rl; r < r_end; r += lanes) {
         const size_t off = (size_t)r * C + (size_t)cg * CE;
         Chunk<T> cx = load_chunk<T>(x + off);
@@ -80,16 +81,31 @@ __global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, 
   }
 }
 
-__global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, double count, const float* __restrict__ gamma,
+// reduces [nblk][2][C] partials in double: 16 channels x 16 slab-lanes per workgroup
+constexpr int FC = 16, FL = 16;
+__device__ inline void reduce_partials(const float* __restrict__ partial, int nblk, int C, int c, int bl, double& s, double& ss, double (*red)[FL][FC]) {
+  s = 0.0; ss = 0.0;
+  if (c < C)
+    for (int b = bl; b < nblk; b += FL) { s += (double)partial[((size_t)b * 2) * C + c]; ss += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+  const int cl = threadIdx.x % FC;
+  red[0][bl][cl] = s; red[1][bl][cl] = ss;
+  __syncthreads();
+  if (bl == 0) {
+    for (int l = 1; l < FL; ++l) { s += red[0][l][cl]; ss += red[1][l][cl]; }
+  }
+}
+
+__global__ __launch_bounds__(FC * FL) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                    long long* __restrict__ nbt, float* __restrict__ coef, int C, float eps, float momentum, int train) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c == 0 && train && nbt) nbt[0] += 1;
-  if (c >= C) return;
-  double mean, var;
+  __shared__ double red[2][FL][FC];
+  const int c = blockIdx.x * FC + threadIdx.x % FC, bl = threadIdx.x / FC;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && train && nbt) nbt[0] += 1;
+  double mean = 0.0, var = 0.0;
   if (train) {
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) { s += (double)partial[((size_t)b * 2) * C + c]; ss += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+    double s, ss;
+    reduce_partials(partial, nblk, C, c, bl, s, ss, red);
+    if (bl != 0 || c >= C) return;
     mean = s / count;
     var = ss / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -97,6 +113,7 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, 
     rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
     rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unbiased);
   } else {
+    if (bl != 0 || c >= C) return;
     mean = (double)rmean[c];
     var = (double)rvar[c];
   }
@@ -108,94 +125,142 @@ __global__ void bn_finalize_kernel(const float* __restrict__ partial, int nblk, 
   coef[3 * C + c] = (float)invstd;
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dsum, float* __restrict__ dgamma,
+__global__ __launch_bounds__(FC * FL) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dsum, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, int C, int accum) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int b = 0; b < nblk; ++b) { s += (double)partial[((size_t)b * 2) * C + c]; ss += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+  __shared__ double red[2][FL][FC];
+  const int c = blockIdx.x * FC + threadIdx.x % FC, bl = threadIdx.x / FC;
+  double s, ss;
+  reduce_partials(partial, nblk, C, c, bl, s, ss, red);
+  if (bl != 0 || c >= C) return;
   dsum[c] = (float)s;
   dsum[C + c] = (float)ss;
   if (accum) { dbeta[c] += (float)s; dgamma[c] += (float)ss; }
   else { dbeta[c] = (float)s; dgamma[c] = (float)ss; }
 }
 
-// ---- elementwise passes: one 16-byte chunk per thread-iteration --------------------------------------------
-template <typename T>
-__global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef, ResDesc res, T* __restrict__ out,
-                                                      int H, int W, int C, long nchunks, int relu, float inv_keep, uint32_t key, uint32_t thr) {
-  constexpr int CE = Elem<T>::CE;
-  const int CC = C / CE;
-  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < nchunks; i += (long)gridDim.x * NT) {
-    const long pix = i / CC;
-    const int c0 = (int)(i - pix * CC) * CE;
-    Chunk<T> cx = load_chunk<T>(x + i * CE);
-    float v[CE];
-#pragma unroll
-    for (int e = 0; e < CE; ++e) v[e] = Elem<T>::to_f(cx.e[e]) * coef[c0 + e] + coef[C + c0 + e];
-    if (res.mode != RN_RES_NONE) {
-      const int hw = H * W;
-      const int n = (int)(pix / hw), rem = (int)(pix - (long)n * hw);
-      const int h = rem / W, w = rem - h * W;
-      res_add_chunk<T>(res, n, h, w, c0, v);
-    }
-    if (relu) {
-#pragma unroll
-      for (int e = 0; e < CE; ++e) v[e] = fmaxf(v[e], 0.f);
-    }
-    if (thr) {
-#pragma unroll
-      for (int e = 0; e < CE; ++e) v[e] = rn_keep(key, (uint32_t)(i * CE + e), thr) ? v[e] * inv_keep : 0.f;
-    }
-    Chunk<T> co;
-#pragma unroll
-    for (int e = 0; e < CE; ++e) co.e[e] = Elem<T>::from_f(v[e]);
-    store_chunk<T>(out + i * CE, co);
-  }
+// ---- elementwise passes.  A thread owns ONE 16-byte channel chunk (its per-channel coefficients live in registers for
+// the whole launch) and streams the rows of its workgroup's slab; consecutive lanes sit on consecutive chunks of a row.
+struct Slab {
+  int cols, lanes, cg, rl, r_begin, r_end;
+  bool active;
+};
+__device__ inline Slab make_slab(int CC, int M, int rows_per_blk, int cbase) {
+  Slab s;
+  s.cols = CC >= NT ? NT : CC;
+  s.lanes = CC >= NT ? 1 : NT / CC;
+  s.cg = cbase + (int)(threadIdx.x % s.cols);
+  s.rl = threadIdx.x / s.cols;
+  s.r_begin = blockIdx.x * rows_per_blk;
+  s.r_end = min(M, s.r_begin + rows_per_blk);
+  s.active = s.rl < s.lanes && s.cg < CC;
+  return s;
 }
 
 template <typename T>
+__global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, const float* __restrict__ coef, ResDesc res, T* __restrict__ out,
+                                                      int M, int H, int W, int C, int rows_per_blk, int relu, float inv_keep, uint32_t key, uint32_t thr) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE;
+  for (int cbase = 0; cbase < CC; cbase += NT) {
+    const Slab s = make_slab(CC, M, rows_per_blk, cbase);
+    if (!s.active) continue;
+    const int c0 = s.cg * CE;
+    float sc[CE], sh[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { sc[e] = coef[c0 + e]; sh[e] = coef[C + c0 + e]; }
+#pragma unroll 2
+    for (int r = s.r_begin + s.rl; r < s.r_end; r += s.lanes) {
+      const size_t off = (size_t)r * C + c0;
+      Chunk<T> cx = load_chunk<T>(x + off);
+      float v[CE];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) v[e] = fmaf(Elem<T>::to_f(cx.e[e]), sc[e], sh[e]);
+      if (res.mode == RN_RES_SAME) {
+        Chunk<T> cr = load_chunk<T>(reinterpret_cast<const T*>(res.ptr) + off);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cr.e[e]);
+      } else if (res.mode != RN_RES_NONE) {
+        const int hw = H * W;
+        const int n = r / hw, rem = r - n * hw;
+        const int h = rem / W, w = rem - h * W;
+        res_add_chunk<T>(res, n, h, w, c0, v);
+      }
+      if (relu) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) v[e] = fmaxf(v[e], 0.f);
+      }
+      if (thr) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) v[e] = rn_keep(key, (uint32_t)(off + e), thr) ? v[e] * inv_keep : 0.f;
+      }
+      Chunk<T> co;
+#pragma unroll
+      for (int e = 0; e < CE; ++e) co.e[e] = Elem<T>::from_f(v[e]);
+      store_chunk<T>(out + off, co);
+    }
+  }
+}
+
+// dx = a*g + b*x + c per channel:  a = scale, b = -scale*invstd*m1, c = scale*(invstd*m1*mean - m0), m = dsum/count
+template <typename T>
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ mask,
                                                           const float* __restrict__ coef, const float* __restrict__ dsum, ResDesc add,
-                                                          T* __restrict__ dx, T* __restrict__ g_out, int H, int W, int C, long nchunks,
+                                                          T* __restrict__ dx, T* __restrict__ g_out, int M, int H, int W, int C, int rows_per_blk,
                                                           int use_mask, int train, float gscale, float inv_count) {
   constexpr int CE = Elem<T>::CE;
   const int CC = C / CE;
-  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < nchunks; i += (long)gridDim.x * NT) {
-    const long pix = i / CC;
-    const int c0 = (int)(i - pix * CC) * CE;
-    Chunk<T> cd = load_chunk<T>(dout + i * CE);
-    Chunk<T> cx = load_chunk<T>(x + i * CE);
-    Chunk<T> cm;
-    if (use_mask) cm = load_chunk<T>(mask + i * CE);
-    float v[CE], g[CE];
+  for (int cbase = 0; cbase < CC; cbase += NT) {
+    const Slab s = make_slab(CC, M, rows_per_blk, cbase);
+    if (!s.active) continue;
+    const int c0 = s.cg * CE;
+    float ka[CE], kb[CE], kc[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) {
-      float gg = Elem<T>::to_f(cd.e[e]) * gscale;
-      if (use_mask && !(Elem<T>::to_f(cm.e[e]) > 0.f)) gg = 0.f;
-      g[e] = gg;
       const float scale = coef[c0 + e];
+      ka[e] = scale * gscale;
       if (train) {
-        const float xh = (Elem<T>::to_f(cx.e[e]) - coef[2 * C + c0 + e]) * coef[3 * C + c0 + e];
-        v[e] = scale * (gg - dsum[c0 + e] * inv_count - xh * (dsum[C + c0 + e] * inv_count));
+        const float mean = coef[2 * C + c0 + e], invstd = coef[3 * C + c0 + e];
+        const float m0 = dsum[c0 + e] * inv_count, m1 = dsum[C + c0 + e] * inv_count;
+        kb[e] = -scale * invstd * m1;
+        kc[e] = scale * (invstd * m1 * mean - m0);
       } else {
-        v[e] = scale * gg;
+        kb[e] = 0.f; kc[e] = 0.f;
       }
     }
-    if (add.mode != RN_RES_NONE) {
-      const int hw = H * W;
-      const int n = (int)(pix / hw), rem = (int)(pix - (long)n * hw);
-      const int h = rem / W, w = rem - h * W;
-      res_add_chunk<T>(add, n, h, w, c0, v);
-    }
-    Chunk<T> co;
+#pragma unroll 2
+    for (int r = s.r_begin + s.rl; r < s.r_end; r += s.lanes) {
+      const size_t off = (size_t)r * C + c0;
+      Chunk<T> cd = load_chunk<T>(dout + off);
+      Chunk<T> cx = load_chunk<T>(x + off);
+      Chunk<T> cm;
+      if (use_mask) cm = load_chunk<T>(mask + off);
+      float v[CE], g[CE];
 #pragma unroll
-    for (int e = 0; e < CE; ++e) co.e[e] = Elem<T>::from_f(v[e]);
-    store_chunk<T>(dx + i * CE, co);
-    if (g_out) {
+      for (int e = 0; e < CE; ++e) {
+        float gg = Elem<T>::to_f(cd.e[e]);
+        if (use_mask && !(Elem<T>::to_f(cm.e[e]) > 0.f)) gg = 0.f;
+        g[e] = gg * gscale;
+        v[e] = fmaf(ka[e], gg, fmaf(kb[e], Elem<T>::to_f(cx.e[e]), kc[e]));
+      }
+      if (add.mode == RN_RES_SAME) {
+        Chunk<T> cr = load_chunk<T>(reinterpret_cast<const T*>(add.ptr) + off);
 #pragma unroll
-      for (int e = 0; e < CE; ++e) co.e[e] = Elem<T>::from_f(g[e]);
-      store_chunk<T>(g_out + i * CE, co);
+        for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cr.e[e]);
+      } else if (add.mode != RN_RES_NONE) {
+        const int hw = H * W;
+        const int n = r / hw, rem = r - n * hw;
+        const int h = rem / W, w = rem - h * W;
+        res_add_chunk<T>(add, n, h, w, c0, v);
+      }
+      Chunk<T> co;
+#pragma unroll
+      for (int e = 0; e < CE; ++e) co.e[e] = Elem<T>::from_f(v[e]);
+      store_chunk<T>(dx + off, co);
+      if (g_out) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) co.e[e] = Elem<T>::from_f(g[e]);
+        store_chunk<T>(g_out + off, co);
+      }
     }
   }
 }
@@ -246,6 +311,18 @@ __global__ __launch_bounds__(NT) void add_res_kernel(T* __restrict__ dst, ResDes
   }
 }
 
+// rows of a slab pass per workgroup: every thread should see >= 4 rows so its coefficient loads amortise
+inline int slab_rows(long M, int C, int ce) {
+  const int CC = C / ce;
+  const int lanes = CC >= NT ? 1 : NT / CC;
+  long blocks = (M + (long)lanes * 4 - 1) / ((long)lanes * 4);
+  if (blocks > 4096) blocks = 4096;
+  if (blocks < 1) blocks = 1;
+  long rows = (M + blocks - 1) / blocks;
+  rows = (rows + lanes - 1) / lanes * lanes;
+  return (int)rows;
+}
+
 inline int ew_grid(long nchunks) {
   long b = (nchunks + NT - 1) / NT;
   if (b > 4096) b = 4096;
@@ -287,7 +364,7 @@ extern "C" int rn_bn_finalize(const float* partial, int nblk, double count, cons
   const int train = (flags & RN_F_TRAIN) ? 1 : 0;
   RN_CHECK_ARG(gamma && beta && running_mean && running_var && coef && C > 0, "rn_bn_finalize: null pointer");
   RN_CHECK_ARG(!train || (partial && nblk > 0 && count > 0), "rn_bn_finalize: train mode needs partial sums");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, as_stream(s), partial, nblk, count, gamma, beta, running_mean, running_var,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FC)), dim3(FC * FL), 0, as_stream(s), partial, nblk, count, gamma, beta, running_mean, running_var,
                      (long long*)nbt, coef, C, eps, momentum, train);
   RN_CHECK_LAUNCH("bn_finalize");
   return 0;
@@ -307,10 +384,14 @@ extern "C" int rn_bn_apply(const void* x, const float* coef, const void* res, vo
   const uint32_t key = rn_drop_key(site, step_seed);
   const float inv_keep = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
   const int relu = (flags & RN_F_RELU) ? 1 : 0;
+  RN_CHECK_ARG(M < (1L << 31), "rn_bn_apply: too many pixels");
+  (void)nchunks;
+  const int rows = slab_rows(M, C, ce);
+  const int grid = cdiv(M, rows);
   if (dtype == RN_F32)
-    hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const float*)x, coef, r, (float*)out, H, W, C, nchunks, relu, inv_keep, key, thr);
+    hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(NT), 0, as_stream(s), (const float*)x, coef, r, (float*)out, (int)M, H, W, C, rows, relu, inv_keep, key, thr);
   else
-    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const bf16_t*)x, coef, r, (bf16_t*)out, H, W, C, nchunks, relu, inv_keep, key, thr);
+    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(NT), 0, as_stream(s), (const bf16_t*)x, coef, r, (bf16_t*)out, (int)M, H, W, C, rows, relu, inv_keep, key, thr);
   RN_CHECK_LAUNCH("bn_apply");
   return 0;
 }
@@ -331,7 +412,7 @@ extern "C" int rn_bn_bwd_reduce(const void* dout, const void* x, const void* mas
 
 extern "C" int rn_bn_bwd_finalize(const float* partial, int nblk, float* dsum, float* dgamma, float* dbeta, int C, int flags, rn_stream s) {
   RN_CHECK_ARG(partial && dsum && dgamma && dbeta && nblk > 0 && C > 0, "rn_bn_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, 128)), dim3(128), 0, as_stream(s), partial, nblk, dsum, dgamma, dbeta, C, (flags & RN_F_ACCUM) ? 1 : 0);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FC)), dim3(FC * FL), 0, as_stream(s), partial, nblk, dsum, dgamma, dbeta, C, (flags & RN_F_ACCUM) ? 1 : 0);
   RN_CHECK_LAUNCH("bn_bwd_finalize");
   return 0;
 }
@@ -350,10 +431,14 @@ extern "C" int rn_bn_bwd_apply(const void* dout, const void* x, const void* mask
   const long nchunks = M * (C / ce);
   void* g = (flags & RN_F_WRITE_G) ? g_out : nullptr;
   const float inv_count = (float)(1.0 / count);
+  RN_CHECK_ARG(M < (1L << 31), "rn_bn_bwd_apply: too many pixels");
+  (void)nchunks;
+  const int rows = slab_rows(M, C, ce);
+  const int grid = cdiv(M, rows);
   if (dtype == RN_F32)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const float*)dout, (const float*)x, (const float*)mask_src, coef, dsum, r, (float*)dx, (float*)g, H, W, C, nchunks, use_mask, train, gscale, inv_count);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid), dim3(NT), 0, as_stream(s), (const float*)dout, (const float*)x, (const float*)mask_src, coef, dsum, r, (float*)dx, (float*)g, (int)M, H, W, C, rows, use_mask, train, gscale, inv_count);
   else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const bf16_t*)dout, (const bf16_t*)x, (const bf16_t*)mask_src, coef, dsum, r, (bf16_t*)dx, (bf16_t*)g, H, W, C, nchunks, use_mask, train, gscale, inv_count);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(grid), dim3(NT), 0, as_stream(s), (const bf16_t*)dout, (const bf16_t*)x, (const bf16_t*)mask_src, coef, dsum, r, (bf16_t*)dx, (bf16_t*)g, (int)M, H, W, C, rows, use_mask, train, gscale, inv_count);
   RN_CHECK_LAUNCH("bn_bwd_apply");
   return 0;
 }

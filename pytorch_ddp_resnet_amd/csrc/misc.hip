@@ -10,17 +10,31 @@ constexpr int NT = 256;
 
 // ---- weights: fp32 KRSC master -> [K][RS][C] and [C][RS][K] in the compute dtype ---------------------------
 template <typename T>
-__global__ void pack_w_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int K, int RS, int C) {
-  const long n = (long)K * RS * C;
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-    const float v = w[i];
-    if (wf) wf[i] = Elem<T>::from_f(v);
-    if (wd) {
-      const int c = (int)(i % C);
-      const long kr = i / C;
-      const int rs = (int)(kr % RS), k = (int)(kr / RS);
-      wd[((size_t)c * RS + rs) * K + k] = Elem<T>::from_f(v);
-    }
+__global__ void pack_w_fwd_kernel(const float* __restrict__ w, T* __restrict__ wf, long n) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) wf[i] = Elem<T>::from_f(w[i]);
+}
+
+// w[k][rs][c] -> wd[c][rs][k]: one 32x32 (k, c) tile per workgroup and tap, transposed through LDS so both the read
+// (along c) and the write (along k) are coalesced
+template <typename T>
+__global__ __launch_bounds__(256) void pack_w_dgrad_kernel(const float* __restrict__ w, T* __restrict__ wd, int K, int RS, int C) {
+  __shared__ float tile[32][33];
+  const int kt = (K + 31) / 32, ct = (C + 31) / 32;
+  int b = blockIdx.x;
+  const int rs = b % RS; b /= RS;
+  const int c0 = (b % ct) * 32, k0 = (b / ct) * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  (void)kt;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int k = k0 + ty + 8 * j, c = c0 + tx;
+    tile[ty + 8 * j][tx] = (k < K && c < C) ? w[((size_t)k * RS + rs) * C + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int c = c0 + ty + 8 * j, k = k0 + tx;
+    if (k < K && c < C) wd[((size_t)c * RS + rs) * K + k] = Elem<T>::from_f(tile[tx][ty + 8 * j]);
   }
 }
 
@@ -259,8 +273,16 @@ extern "C" int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, 
   RN_CHECK_ARG(w_krsc && (w_fwd || w_dgrad) && K > 0 && RS > 0 && C > 0, "rn_pack_weights: bad argument");
   RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "rn_pack_weights: bad dtype");
   const long n = (long)K * RS * C;
-  if (dtype == RN_F32) hipLaunchKernelGGL((pack_w_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), w_krsc, (float*)w_fwd, (float*)w_dgrad, K, RS, C);
-  else hipLaunchKernelGGL((pack_w_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), w_krsc, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, K, RS, C);
+  if (w_fwd) {
+    if (dtype == RN_F32) hipLaunchKernelGGL((pack_w_fwd_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), w_krsc, (float*)w_fwd, n);
+    else hipLaunchKernelGGL((pack_w_fwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), w_krsc, (bf16_t*)w_fwd, n);
+    RN_CHECK_LAUNCH("pack_weights_fwd");
+  }
+  if (w_dgrad) {
+    const int grid = cdiv(K, 32) * cdiv(C, 32) * RS;
+    if (dtype == RN_F32) hipLaunchKernelGGL((pack_w_dgrad_kernel<float>), dim3(grid), dim3(256), 0, as_stream(s), w_krsc, (float*)w_dgrad, K, RS, C);
+    else hipLaunchKernelGGL((pack_w_dgrad_kernel<bf16_t>), dim3(grid), dim3(256), 0, as_stream(s), w_krsc, (bf16_t*)w_dgrad, K, RS, C);
+  }
   RN_CHECK_LAUNCH("pack_weights");
   return 0;
 }

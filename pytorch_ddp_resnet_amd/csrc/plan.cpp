@@ -30,6 +30,10 @@ struct rn_plan {
   std::vector<void*> bufs;
   std::vector<size_t> ws_bytes;   // bytes available behind a 'ws' slot (set through rn_plan_set_bytes)
   int dtype;
+  bool profile = false;            // per-op hipEvent pairs on the launch stream (bench.py roofline leg)
+  std::vector<hipEvent_t> ev;      // 2 per op
+  std::vector<char> ev_set;
+  ~rn_plan() { for (auto e : ev) hipEventDestroy(e); }
 };
 
 extern "C" int rn_plan_create(const rn_op* ops, int n_ops, int n_bufs, int dtype, rn_plan** out) {
@@ -58,6 +62,33 @@ extern "C" int rn_plan_bind(rn_plan* plan, const void* const* device_ptrs, int n
 extern "C" int rn_plan_set_bytes(rn_plan* plan, int slot, size_t bytes) {
   RN_CHECK_ARG(plan && slot >= 0 && slot < (int)plan->bufs.size(), "rn_plan_set_bytes: bad slot");
   plan->ws_bytes[slot] = bytes;
+  return 0;
+}
+
+extern "C" int rn_plan_profile(rn_plan* plan, int enable) {
+  RN_CHECK_ARG(plan != nullptr, "rn_plan_profile: null plan");
+  if (enable && plan->ev.empty()) {
+    plan->ev.resize(2 * plan->ops.size());
+    for (auto& e : plan->ev)
+      if (hipEventCreate(&e) != hipSuccess) { rn_set_error("rn_plan_profile: hipEventCreate failed"); return 2; }
+    plan->ev_set.assign(plan->ops.size(), 0);
+  }
+  plan->profile = enable != 0;
+  if (enable) plan->ev_set.assign(plan->ops.size(), 0);
+  return 0;
+}
+
+// elapsed milliseconds of every op launched since profiling was (re-)enabled; 0 for ops that did not run. Blocks.
+extern "C" int rn_plan_profile_read(rn_plan* plan, float* ms, int n) {
+  RN_CHECK_ARG(plan && ms && n == (int)plan->ops.size() && !plan->ev.empty(), "rn_plan_profile_read: bad argument");
+  for (int i = 0; i < n; ++i) {
+    ms[i] = 0.f;
+    if (!plan->ev_set[i]) continue;
+    if (hipEventSynchronize(plan->ev[2 * i + 1]) != hipSuccess || hipEventElapsedTime(&ms[i], plan->ev[2 * i], plan->ev[2 * i + 1]) != hipSuccess) {
+      rn_set_error("rn_plan_profile_read: event query failed at op %d", i);
+      return 2;
+    }
+  }
   return 0;
 }
 
@@ -159,7 +190,9 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
   RN_CHECK_ARG(plan != nullptr, "rn_plan_run: null plan");
   RN_CHECK_ARG(first >= 0 && last <= (int)plan->ops.size() && first <= last, "rn_plan_run: bad range [%d, %d)", first, last);
   for (int i = first; i < last; ++i) {
+    if (plan->profile) hipEventRecord(plan->ev[2 * i], as_stream(stream));
     int e = run_op(plan, i, step_seed, stream);
+    if (plan->profile) { hipEventRecord(plan->ev[2 * i + 1], as_stream(stream)); plan->ev_set[i] = 1; }
     if (e) {
       std::string msg = g_err;
       rn_set_error("op %d (kind %d): %s", i, plan->ops[i].kind, msg.c_str());

@@ -66,73 +66,74 @@ __global__ __launch_bounds__(NT) void stem_fwd_kernel(const StemArgs a) {
   }
 }
 
-// wgrad: thread = (4 output channels) x (pixel lane); per tap-row group accumulates dy*x in registers over its pixels,
-// block-reduces through LDS and writes one partial slab per block.
-constexpr int WCH = 4;          // channels per thread
-constexpr int MAXG = 24;        // taps per register group (S*C <= 24: 3x3x3 -> 9, 7x7x3 -> 21)
+// wgrad + dbias as a skinny GEMM  [K x M] . [M x (RSC+1)]  (last column = ones -> bias gradient) on the vector ALU.
+// A workgroup walks pixel tiles of 64: the dy tile [64][KT] and the gathered image patches [64][RSC+1] are staged in
+// LDS; thread (k, tap group) accumulates its taps over the tile with broadcast LDS reads of the patch row.  One partial
+// [K][RSC+1] slab per workgroup, summed in a fixed order by stem_wgrad_reduce_kernel.
+constexpr int WPIX = 64;        // pixels per tile
+constexpr int MAXTG = 16;       // taps per thread (register accumulators)
 
 template <typename T>
 __global__ __launch_bounds__(NT) void stem_wgrad_kernel(const StemArgs a) {
-  __shared__ float red[NT][WCH + 1];
-  const int RSC = a.R * a.S * a.C, SC = a.S * a.C;
+  extern __shared__ float smem[];
+  const int RSC = a.R * a.S * a.C, NCOL = RSC + 1;
+  const int NCP = (NCOL + 3) / 4 * 4;                    // padded patch row (float4 reads)
+  float* patch = smem;                                   // [WPIX][NCP]
+  float* dyt = smem + WPIX * NCP;                        // [WPIX][KT]
   const int k0 = blockIdx.y * a.KT;
   const int kt = min(a.KT, a.K - k0);
-  const int ccb = a.KT / WCH;
-  const int ppb = NT / ccb;
-  const int kc = threadIdx.x % ccb, pl = threadIdx.x / ccb;
-  const bool active = pl < ppb && kc * WCH < kt;
+  const int tg_count = NT / a.KT;                        // tap groups
+  const int tpg = (NCOL + tg_count - 1) / tg_count;      // taps per group (<= MAXTG, checked on the host)
+  const int kk = threadIdx.x % a.KT, tg = threadIdx.x / a.KT;
+  const int t0 = tg * tpg;
+  const bool active = tg < tg_count && kk < kt;
   const int pq = a.P * a.Q;
   const T* __restrict__ dy = reinterpret_cast<const T*>(a.y);
-  float* __restrict__ out = a.out + (size_t)blockIdx.x * a.K * (RSC + 1);
-
-  for (int r = 0; r <= a.R; ++r) {            // r == R: the bias gradient pass
-    float acc[MAXG][WCH];
+  float acc[MAXTG];
 #pragma unroll
-    for (int g = 0; g < MAXG; ++g)
-#pragma unroll
-      for (int e = 0; e < WCH; ++e) acc[g][e] = 0.f;
+  for (int i = 0; i < MAXTG; ++i) acc[i] = 0.f;
+  const int ntiles = (a.M + WPIX - 1) / WPIX;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int m0 = tile * WPIX;
+    __syncthreads();
+    for (int i = threadIdx.x; i < WPIX * NCP; i += NT) {
+      const int pl = i / NCP, col = i - pl * NCP;
+      const int m = m0 + pl;
+      float v = 0.f;
+      if (m < a.M && col < NCOL) {
+        if (col == RSC) v = 1.f;
+        else {
+          const int n = m / pq, rem = m - n * pq;
+          const int p = rem / a.Q, q = rem - p * a.Q;
+          const int r = col / (a.S * a.C), sc = col - r * (a.S * a.C);
+          const int s_ = sc / a.C, c = sc - s_ * a.C;
+          const int h = p * a.stride + r - a.pad, w = q * a.stride + s_ - a.pad;
+          if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) v = a.x[(((size_t)n * a.C + c) * a.H + h) * a.W + w];
+        }
+      }
+      patch[i] = v;
+    }
+    for (int i = threadIdx.x; i < WPIX * a.KT; i += NT) {
+      const int pl = i / a.KT, kc = i - pl * a.KT;
+      const int m = m0 + pl;
+      dyt[i] = (m < a.M && kc < kt) ? Elem<T>::to_f(dy[(size_t)m * a.K + k0 + kc]) : 0.f;
+    }
+    __syncthreads();
     if (active) {
-      for (int m = blockIdx.x * ppb + pl; m < a.M; m += gridDim.x * ppb) {
-        const int n = m / pq, rem = m - n * pq;
-        const int p = rem / a.Q, q = rem - p * a.Q;
-        float d[WCH];
+      for (int pl = 0; pl < WPIX; ++pl) {
+        const float d = dyt[pl * a.KT + kk];
+        const float* pr = patch + pl * NCP + t0;
 #pragma unroll
-        for (int e = 0; e < WCH; ++e) d[e] = Elem<T>::to_f(dy[(size_t)m * a.K + k0 + kc * WCH + e]);
-        if (r == a.R) {
-#pragma unroll
-          for (int e = 0; e < WCH; ++e) acc[0][e] += d[e];
-          continue;
-        }
-        const int h = p * a.stride + r - a.pad;
-        if ((unsigned)h >= (unsigned)a.H) continue;
-#pragma unroll
-        for (int g = 0; g < MAXG; ++g) {
-          if (g < SC) {
-            const int s = g / a.C, c = g - s * a.C;
-            const int w = q * a.stride + s - a.pad;
-            const float v = (unsigned)w < (unsigned)a.W ? a.x[(((size_t)n * a.C + c) * a.H + h) * a.W + w] : 0.f;
-#pragma unroll
-            for (int e = 0; e < WCH; ++e) acc[g][e] = fmaf(v, d[e], acc[g][e]);
-          }
-        }
+        for (int i = 0; i < MAXTG; ++i)
+          if (i < tpg) acc[i] = fmaf(d, pr[i], acc[i]);
       }
     }
-    const int ng = r == a.R ? 1 : SC;
-    for (int g = 0; g < ng; ++g) {
+  }
+  if (active) {
+    float* __restrict__ out = a.out + (size_t)blockIdx.x * a.K * NCOL + (size_t)(k0 + kk) * NCOL;
 #pragma unroll
-      for (int e = 0; e < WCH; ++e) red[threadIdx.x][e] = acc[g][e];
-      __syncthreads();
-      if (threadIdx.x < ccb && threadIdx.x * WCH < kt) {
-        float t[WCH] = {0.f, 0.f, 0.f, 0.f};
-        for (int l = 0; l < ppb; ++l)
-#pragma unroll
-          for (int e = 0; e < WCH; ++e) t[e] += red[l * ccb + threadIdx.x][e];
-        const int col = r == a.R ? RSC : r * SC + g;
-#pragma unroll
-        for (int e = 0; e < WCH; ++e) out[(size_t)(k0 + threadIdx.x * WCH + e) * (RSC + 1) + col] = t[e];
-      }
-      __syncthreads();
-    }
+    for (int i = 0; i < MAXTG; ++i)
+      if (i < tpg && t0 + i < NCOL) out[t0 + i] = acc[i];
   }
 }
 
@@ -161,16 +162,24 @@ inline int stem_kt(const rn_conv_geom* g, int ce) {
 
 inline int stem_wgrad_blocks(const rn_conv_geom* g) {
   long M = (long)g->N * g->P * g->Q;
-  long b = M / 64;
-  if (b > 512) b = 512;
+  long b = (M + WPIX - 1) / WPIX;
+  if (b > 256) b = 256;
   if (b < 1) b = 1;
   return (int)b;
+}
+
+// channels per workgroup so that (256 / KT) tap groups cover RSC+1 columns with <= MAXTG taps each
+inline int stem_wgrad_kt(const rn_conv_geom* g) {
+  const int ncol = g->R * g->S * g->C + 1;
+  int kt = 128;
+  while (kt > 8 && ((ncol + (NT / kt) - 1) / (NT / kt) > MAXTG || kt > g->K)) kt /= 2;
+  return kt;
 }
 
 int check_stem(const rn_conv_geom* g, int dtype, const char* who) {
   RN_CHECK_ARG(g != nullptr, "%s: null geometry", who);
   RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "%s: bad dtype", who);
-  RN_CHECK_ARG(g->C > 0 && g->C <= 4 && g->S * g->C <= MAXG, "%s: stem path needs C_in <= 4 and S*C <= %d (got C=%d S=%d)", who, MAXG, g->C, g->S);
+  RN_CHECK_ARG(g->C > 0 && g->C <= 4 && g->S * g->C <= 24, "%s: stem path needs C_in <= 4 and S*C <= %d (got C=%d S=%d)", who, 24, g->C, g->S);
   RN_CHECK_ARG(g->K % 8 == 0, "%s: K=%d must be a multiple of 8", who, g->K);
   RN_CHECK_ARG(g->P == (g->H + 2 * g->pad - g->R) / g->stride + 1 && g->Q == (g->W + 2 * g->pad - g->S) / g->stride + 1, "%s: inconsistent output size", who);
   RN_CHECK_ARG((long)g->N * g->P * g->Q < (1L << 31), "%s: too many pixels", who);
@@ -215,11 +224,14 @@ extern "C" int rn_stem_conv_wgrad(const float* x_nchw, const void* dy, int dtype
   StemArgs a{};
   fill(a, g);
   a.x = x_nchw; a.y = const_cast<void*>(dy); a.out = reinterpret_cast<float*>(ws);
-  a.KT = g->K < 128 ? (g->K + 3) / 4 * 4 : 128;
+  a.KT = stem_wgrad_kt(g);
+  const int ncol = g->R * g->S * g->C + 1;
+  RN_CHECK_ARG((ncol + (NT / a.KT) - 1) / (NT / a.KT) <= MAXTG, "rn_stem_conv_wgrad: %d patch columns do not fit the tap groups", ncol);
   const int nblk = stem_wgrad_blocks(g);
   dim3 grid(nblk, cdiv(g->K, a.KT));
-  if (dtype == RN_F32) hipLaunchKernelGGL((stem_wgrad_kernel<float>), grid, dim3(NT), 0, as_stream(s), a);
-  else hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t>), grid, dim3(NT), 0, as_stream(s), a);
+  const size_t smem = (size_t)WPIX * (((ncol + 3) / 4 * 4) + a.KT) * sizeof(float);
+  if (dtype == RN_F32) hipLaunchKernelGGL((stem_wgrad_kernel<float>), grid, dim3(NT), smem, as_stream(s), a);
+  else hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t>), grid, dim3(NT), smem, as_stream(s), a);
   RN_CHECK_LAUNCH("stem_wgrad");
   const int n = g->K * (g->R * g->S * g->C + 1);
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), nblk, dw_krsc, dbias,

@@ -137,6 +137,16 @@ class Engine:
     def backward(self, step_seed=0, hook_fn=None):
         self.run(self.plan.n_fwd, len(self.plan.ops), step_seed, hook_fn)
 
+    def profile(self, enable: bool):
+        _lib.check(self.L.rn_plan_profile(self._h, int(enable)))
+
+    def profile_read(self):
+        """-> list of (op, milliseconds) for the ops launched since profile(True)."""
+        n = len(self.plan.ops)
+        ms = (C.c_float * n)()
+        _lib.check(self.L.rn_plan_profile_read(self._h, ms, n))
+        return [(self.plan.ops[i], float(ms[i])) for i in range(n)]
+
     def t(self, name):
         return self.tensors[self.plan.slot_of[name]]
 

