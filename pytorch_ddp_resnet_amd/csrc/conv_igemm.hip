@@ -15,10 +15,16 @@
 // f32 FMA chain), bf16 v_mfma_f32_32x32x16_bf16, both fed by one 16-byte ds_read_b128 per operand per k-step.
 #include "common.h"
 
+int rn_conv3x3_patch(const void* src, const void* wt, void* dst, const ResDesc& res, int accum, int dtype, int N, int H, int W, int C, int K,
+                     bool flip, rn_stream s);
+
+int g_rn_variant = 0;   // tuning switch (tools/conv_bench.py): bit0 = use the LDS-patch 3x3 kernel, bit1 = plain fragment schedule
+extern "C" void rn_set_variant(int v) { g_rn_variant = v; }
+
 namespace {
 
 constexpr int MAX_TAPS = 9;
-constexpr int CPR = 4;  // 16-byte chunks per LDS row
+constexpr int CPR = 8;  // 16-byte chunks per LDS row (128 bytes of K per row)
 
 struct IgemmArgs {
   const void* src;
@@ -49,14 +55,28 @@ template <> struct Mfma<bf16_t> {
   }
 };
 
-__device__ inline int swz(int row, int chunk) { return row * CPR + (chunk ^ ((row >> 2) & 3)); }
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
-template <typename T, int BM, int BN, int WM, int WN>
+// 128-byte K rows (8 chunks of 16 B): chunk' = chunk ^ ((row>>1)&7) makes the ds_read_b128 of 16 consecutive rows at a
+// fixed chunk hit 16 distinct 16-byte slots of the 256-byte bank row, and keeps the 8-lane ds_write_b128 groups whole
+__device__ inline int swz(int row, int chunk) { return row * CPR + (chunk ^ ((row >> 1) & 7)); }
+
+__device__ inline uint4 bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);     // out-of-range offset -> zeros, no branch
+  return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
+constexpr unsigned OOB = 0xFFFFFFF0u;
+
+template <typename T, int BM, int BN, int WM, int WN, int VAR>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   constexpr int CE = Elem<T>::CE;
+  constexpr int ES = (int)sizeof(T);
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int AR = BM / 64, BR = (BN + 63) / 64;
-  static_assert(WM * WN == 4 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && BM % 64 == 0, "tile");
+  constexpr int RPP = 256 / CPR;                       // rows staged per pass (32)
+  constexpr int AR = BM / RPP, BR = (BN + RPP - 1) / RPP;
+  constexpr int KS = CPR / 2;                          // MFMA k-steps per tile (2 chunks each)
+  static_assert(WM * WN == 4 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && BM % RPP == 0, "tile");
   __shared__ uint4 lds[2][(BM + BN) * CPR];
   __shared__ int tap_src[MAX_TAPS + 1], tap_w[MAX_TAPS + 1];
 
@@ -64,30 +84,39 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   const int nmt = (a.M + BM - 1) / BM;
   const int mt = blockIdx.x % nmt, ntile = blockIdx.x / nmt;
   const int m0 = mt * BM, n0 = ntile * BN;
-  const T* __restrict__ src = reinterpret_cast<const T*>(a.src);
-  const T* __restrict__ wt = reinterpret_cast<const T*>(a.wt);
+  const int pq = a.Pc * a.Qc;
+
+  // buffer descriptors: the activation descriptor is rebased on the first image of this tile so that per-lane byte
+  // offsets fit 32 bits for any tensor size; out-of-range offsets (padding taps, K tail) return zeros in hardware
+  const int n_first = m0 / pq;
+  const size_t img_bytes = (size_t)a.Hs * a.Ws * a.Cs * ES;
+  const size_t a_total = (size_t)a.N * img_bytes, a_base = (size_t)n_first * img_bytes;
+  const size_t a_left = a_total - a_base;
+  const __amdgpu_buffer_rsrc_t ra_desc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<char*>(reinterpret_cast<const char*>(a.src)) + a_base, (short)0, (int)(a_left > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (unsigned)a_left), 0x00020000);
+  const size_t w_total = (size_t)a.Kd * a.wrs * a.Cs * ES;
+  const __amdgpu_buffer_rsrc_t rb_desc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(a.wt), (short)0, (int)(w_total > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (unsigned)w_total), 0x00020000);
 
   if (tid <= MAX_TAPS) {
     int t = tid < a.nt ? tid : 0;
-    tap_src[tid] = tid < a.nt ? (a.dh[t] * a.Ws + a.dw[t]) * a.Cs : 0;
-    tap_w[tid] = tid < a.nt ? a.widx[t] * a.Cs : 0;
+    tap_src[tid] = tid < a.nt ? (a.dh[t] * a.Ws + a.dw[t]) * a.Cs * ES : 0;
+    tap_w[tid] = tid < a.nt ? a.widx[t] * a.Cs * ES : 0;
   }
 
-  // ---- per-thread staging roles: chunk column c of rows r0 + 64*i ----
-  const int c = tid & 3, r0 = tid >> 2;
-  long abase[AR];
-  unsigned amask[AR];
+  // ---- per-thread staging roles: chunk column c of rows r0 + RPP*i ----
+  const int c = tid % CPR, r0 = tid / CPR;
+  unsigned abase[AR], amask[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
-    int m = m0 + r0 + 64 * i;
+    int m = m0 + r0 + RPP * i;
     amask[i] = 0;
     abase[i] = 0;
     if (m < a.M) {
-      int pq = a.Pc * a.Qc;
       int n = m / pq, rem = m - n * pq;
       int p = rem / a.Qc, q = rem - p * a.Qc;
       int hb = p * a.ss, wb = q * a.ss;
-      abase[i] = (((long)n * a.Hs + hb) * a.Ws + wb) * a.Cs;
+      abase[i] = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES);   // may wrap for border taps: masked
       unsigned mk = 0;
       for (int t = 0; t < a.nt; ++t) {
         int h = hb + a.dh[t], w = wb + a.dw[t];
@@ -96,14 +125,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
       amask[i] = mk;
     }
   }
-  long bbase[BR];
-  bool bok[BR];
+  unsigned bbase[BR];
 #pragma unroll
   for (int i = 0; i < BR; ++i) {
-    int rn = r0 + 64 * i;
+    int rn = r0 + RPP * i;
     int k = n0 + rn;
-    bok[i] = (rn < BN) && (k < a.Kd);
-    bbase[i] = (long)k * a.wrs * a.Cs;
+    bbase[i] = (rn < BN && k < a.Kd) ? (unsigned)((size_t)k * a.wrs * a.Cs * ES) : OOB;     // weights < 4 GB (checked on the host)
   }
   __syncthreads();
 
@@ -114,26 +141,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   auto load_tile = [&]() {
     const bool kv = tap < a.nt;
     const int tp = kv ? tap : 0;
-    const int so = tap_src[tp] + cc * CE, wo = tap_w[tp] + cc * CE;
+    const unsigned so = (unsigned)(tap_src[tp] + cc * 16), wo = (unsigned)(tap_w[tp] + cc * 16);
 #pragma unroll
-    for (int i = 0; i < AR; ++i) {
-      ra[i] = make_uint4(0, 0, 0, 0);
-      if (kv && ((amask[i] >> tp) & 1)) ra[i] = *reinterpret_cast<const uint4*>(src + abase[i] + so);
-    }
+    for (int i = 0; i < AR; ++i) ra[i] = bload(ra_desc, (kv && ((amask[i] >> tp) & 1)) ? abase[i] + so : OOB);
 #pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      rb[i] = make_uint4(0, 0, 0, 0);
-      if (kv && bok[i]) rb[i] = *reinterpret_cast<const uint4*>(wt + bbase[i] + wo);
-    }
+    for (int i = 0; i < BR; ++i) rb[i] = bload(rb_desc, (kv && bbase[i] != OOB) ? bbase[i] + wo : OOB);
     cc += CPR;
     while (cc >= a.cpt) { cc -= a.cpt; ++tap; }
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < AR; ++i) lds[buf][swz(r0 + 64 * i, c)] = ra[i];
+    for (int i = 0; i < AR; ++i) lds[buf][swz(r0 + RPP * i, c)] = ra[i];
 #pragma unroll
     for (int i = 0; i < BR; ++i) {
-      int rn = r0 + 64 * i;
+      int rn = r0 + RPP * i;
       if (rn < BN) lds[buf][BM * CPR + swz(rn, c)] = rb[i];
     }
   };
@@ -159,18 +180,44 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   for (int it = 0; it < a.nk; ++it) {
     const int buf = it & 1;
     if (it + 1 < a.nk) load_tile();
+    if constexpr (VAR & 1) {
+      // fragment double buffering: the ds_reads of k-step ks+1 are in flight under the MFMAs of k-step ks
+      uint4 fa[2][TM], fb[2][TN];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      const int ch = 2 * ks + lh;
-      uint4 fa[TM], fb[TN];
+      for (int i = 0; i < TM; ++i) fa[0][i] = lds[buf][swz(arow0 + 32 * i, lh)];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = lds[buf][swz(arow0 + 32 * i, ch)];
+      for (int j = 0; j < TN; ++j) fb[0][j] = lds[buf][BM * CPR + swz(brow0 + 32 * j, lh)];
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = lds[buf][BM * CPR + swz(brow0 + 32 * j, ch)];
+      for (int ks = 0; ks < KS; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < KS) {
+          const int ch = 2 * (ks + 1) + lh;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i) fa[nxt][i] = lds[buf][swz(arow0 + 32 * i, ch)];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+          for (int j = 0; j < TN; ++j) fb[nxt][j] = lds[buf][BM * CPR + swz(brow0 + 32 * j, ch)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur][i], fb[cur][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int ch = 2 * ks + lh;
+        uint4 fa[TM], fb[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[i] = lds[buf][swz(arow0 + 32 * i, ch)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[j] = lds[buf][BM * CPR + swz(brow0 + 32 * j, ch)];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[i], fb[j], acc[i][j]);
+      }
     }
     if (it + 1 < a.nk) store_tile(buf ^ 1);
     __syncthreads();
@@ -191,7 +238,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
       if (dense) {
         pix = (size_t)m;
       } else {
-        int pq = a.Pc * a.Qc;
         n = m / pq;
         int rem = m - n * pq;
         int p = rem / a.Qc, q = rem - p * a.Qc;
@@ -219,7 +265,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   int nmt = cdiv(a.M, BM), nnt = cdiv(a.Kd, BN);
-  hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN>), dim3(nmt * nnt), dim3(256), 0, s, a);
+  if (g_rn_variant & 2) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, 0>), dim3(nmt * nnt), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, 1>), dim3(nmt * nnt), dim3(256), 0, s, a);
   RN_CHECK_LAUNCH("igemm");
   return 0;
 }
@@ -246,6 +293,8 @@ int check_geom(const rn_conv_geom* g, int dtype, const char* who) {
   RN_CHECK_ARG(g->P == (g->H + 2 * g->pad - g->R) / g->stride + 1 && g->Q == (g->W + 2 * g->pad - g->S) / g->stride + 1,
                "%s: inconsistent output size", who);
   RN_CHECK_ARG((long)g->N * g->H * g->W < (1L << 31) && (long)g->N * g->P * g->Q < (1L << 31), "%s: too many pixels", who);
+  RN_CHECK_ARG((size_t)g->K * g->R * g->S * g->C * 4 < 0xFFFFFFE0ull, "%s: weights exceed the 4 GiB buffer-descriptor range", who);
+  RN_CHECK_ARG(((size_t)g->H * g->W * g->C + (size_t)g->P * g->Q * g->K) * 4 * 130 < 0xFFFFFFE0ull, "%s: images too large for 32-bit tile offsets", who);
   return 0;
 }
 
@@ -267,6 +316,10 @@ extern "C" int rn_conv_fwd(const void* x, const void* w_fwd, void* y, const void
   IgemmArgs a{};
   a.src = x; a.wt = w_fwd; a.dst = y;
   fill_res(a.res, res, res_mode, res_C, g->N, g->P, g->Q, g->K);
+  if ((g_rn_variant & 1) && g->R == 3 && g->S == 3 && g->stride == 1 && g->pad == 1) {      // LDS-resident patch kernel (opt-in) for CIFAR-sized maps
+    const int e = rn_conv3x3_patch(x, w_fwd, y, a.res, 0, dtype, g->N, g->H, g->W, g->C, g->K, false, s);
+    if (e >= 0) return e;
+  }
   a.N = g->N; a.Hs = g->H; a.Ws = g->W; a.Cs = g->C;
   a.Pc = g->P; a.Qc = g->Q; a.M = g->N * g->P * g->Q;
   a.Hd = g->P; a.Wd = g->Q; a.Kd = g->K;
@@ -290,6 +343,12 @@ extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, cons
   RN_CHECK_ARG(dy && w_dgrad && dx, "rn_conv_dgrad: null pointer");
   const int st = g->stride;
   const int ce = dtype == RN_F32 ? 4 : 8;
+  if ((g_rn_variant & 1) && g->R == 3 && g->S == 3 && st == 1 && g->pad == 1) {
+    ResDesc rd;
+    fill_res(rd, res, res_mode, res_C, g->N, g->H, g->W, g->C);
+    const int e = rn_conv3x3_patch(dy, w_dgrad, dx, rd, (flags & RN_F_ACCUM) ? 1 : 0, dtype, g->N, g->H, g->W, g->K, g->C, true, s);
+    if (e >= 0) return e;
+  }
   // one launch per parity class (a, b) of the input grid: h = st*p' + a, w = st*q' + b
   for (int pa = 0; pa < st; ++pa)
     for (int pb = 0; pb < st; ++pb) {

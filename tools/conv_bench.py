@@ -1,0 +1,62 @@
+"""Micro-benchmark of the convolution launchers on the WRN-28-10 shapes (A/B inside one process).
+usage: python tools/conv_bench.py [fwd|dgrad|wgrad] [iters]   env RN_CONV_VARIANT selects kernel variants."""
+import ctypes as C
+import os
+import sys
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pytorch_ddp_resnet_amd import _lib
+
+L = _lib.lib()
+vp = C.c_void_p
+L.rn_conv_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(_lib.RnConvGeom), vp]
+L.rn_conv_dgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_lib.RnConvGeom), vp]
+L.rn_conv_wgrad.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(_lib.RnConvGeom), vp]
+L.rn_set_variant.argtypes = [C.c_int]
+
+SHAPES = [(128, 32, 32, 160, 160), (128, 16, 16, 320, 320), (128, 8, 8, 640, 640)]
+
+
+def run(which, iters, variants, dtype=torch.bfloat16):
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    for (N, H, W, Cc, K) in SHAPES:
+        g = _lib.RnConvGeom(N, H, W, Cc, H, W, K, 3, 3, 1, 1)
+        x = torch.randn(N, H, W, Cc, device='cuda').to(dtype)
+        w = (torch.randn(K, 9, Cc, device='cuda') * 0.05).to(dtype)
+        wd = (torch.randn(Cc, 9, K, device='cuda') * 0.05).to(dtype)
+        y = torch.empty(N, H, W, K, device='cuda', dtype=dtype)
+        dy = torch.randn(N, H, W, K, device='cuda').to(dtype)
+        dx = torch.empty(N, H, W, Cc, device='cuda', dtype=dtype)
+        dw = torch.empty(K, 9, Cc, device='cuda')
+        wsb = int(L.rn_conv_wgrad_ws_bytes(C.byref(g)))
+        ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device='cuda')
+        rn = 1 if dtype == torch.bfloat16 else 0
+        flops = 2.0 * N * H * W * K * 9 * Cc
+        for v in variants:
+            L.rn_set_variant(v)
+
+            def call():
+                if which == 'fwd':
+                    _lib.check(L.rn_conv_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, 0, 0, rn, C.byref(g), st))
+                elif which == 'dgrad':
+                    _lib.check(L.rn_conv_dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, 0, 0, 0, rn, C.byref(g), st))
+                else:
+                    _lib.check(L.rn_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsb, 0, rn, C.byref(g), st))
+            for _ in range(3):
+                call()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(iters):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            us = e0.elapsed_time(e1) / iters * 1e3
+            print(f'{which} {N}x{H}x{W} C{Cc}->K{K} variant {v}: {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
+
+
+if __name__ == '__main__':
+    which = sys.argv[1] if len(sys.argv) > 1 else 'fwd'
+    iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    variants = [int(v) for v in os.environ.get('RN_CONV_VARIANT', '0,1').split(',')]
+    run(which, iters, variants)
