@@ -14,7 +14,7 @@
 namespace {
 
 constexpr int MAX_TAPS = 9;
-template <typename T> struct Bp { static constexpr int v = sizeof(T) == 4 ? 16 : 32; };  // pixels per K-step tile
+template <typename T> struct Bp { static constexpr int v = sizeof(T) == 4 ? 16 : 64; };  // pixels per LDS tile (bf16: two 32-pixel MFMA k-steps)
 
 struct WgradArgs {
   const void* x;
@@ -44,15 +44,28 @@ template <int TI, int TJ> struct WTile<bf16_t, TI, TJ> {
     return r;
   }
   __device__ static inline void run(const char* ta, int rowa, int cha, const char* tb, int rowbb, int chb, int lane, f32x4 (&acc)[TI][TJ]) {
-    bf16x8 fa[TI], fb[TJ];
+    bf16x8 fa[2][TI], fb[2][TJ];
 #pragma unroll
-    for (int i = 0; i < TI; ++i) fa[i] = frag(ta, rowa, cha + 16 * i, lane);
+    for (int i = 0; i < TI; ++i) fa[0][i] = frag(ta, rowa, cha + 16 * i, lane);
 #pragma unroll
-    for (int j = 0; j < TJ; ++j) fb[j] = frag(tb, rowbb, chb + 16 * j, lane);
+    for (int j = 0; j < TJ; ++j) fb[0][j] = frag(tb, rowbb, chb + 16 * j, lane);
+    constexpr int NS = Bp<bf16_t>::v / 32;
 #pragma unroll
-    for (int i = 0; i < TI; ++i)
+    for (int s = 0; s < NS; ++s) {
+      const int cur = s & 1, nxt = cur ^ 1;
+      if (s + 1 < NS) {
 #pragma unroll
-      for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TI; ++i) fa[nxt][i] = frag(ta + (size_t)(s + 1) * 32 * rowa, rowa, cha + 16 * i, lane);
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) fb[nxt][j] = frag(tb + (size_t)(s + 1) * 32 * rowbb, rowbb, chb + 16 * j, lane);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TI; ++i)
+#pragma unroll
+        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   }
 };
 
@@ -106,31 +119,43 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   const int pq = a.P * a.Q;
   const int dht = a.dh[t], dwt = a.dw[t];
 
+  // buffer descriptors rebased on this block's first image: 32-bit byte offsets, out-of-range -> zeros in hardware
+  constexpr int ES = (int)sizeof(T);
+  const int n_first = m_begin / pq;
+  const size_t ximg = (size_t)a.H * a.W * a.C * ES, yimg = (size_t)pq * a.K * ES;
+  const size_t xleft = ((size_t)a.N - n_first) * ximg, yleft = ((size_t)a.N - n_first) * yimg;
+  const __amdgpu_buffer_rsrc_t xdesc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(X)) + (size_t)n_first * ximg, (short)0,
+                                                                        (int)(xleft > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (unsigned)xleft), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ydesc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(DY)) + (size_t)n_first * yimg, (short)0,
+                                                                        (int)(yleft > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (unsigned)yleft), 0x00020000);
+  constexpr unsigned OOB = 0xFFFFFFF0u;
+  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+  auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+  };
+  unsigned cha_off[NJA], chb_off[NJB];
+#pragma unroll
+  for (int j = 0; j < NJA; ++j) { const int ch = cl + TPR * j; cha_off[j] = (ch < CHA && k0 + ch * CE < a.K) ? (unsigned)((k0 + ch * CE) * ES) : OOB; }
+#pragma unroll
+  for (int j = 0; j < NJB; ++j) { const int ch = cl + TPR * j; chb_off[j] = (ch < CHB && c0 + ch * CE < a.C) ? (unsigned)((c0 + ch * CE) * ES) : OOB; }
+
   uint4 ra[NJA], rb[NJB];
   auto load_tile = [&](int it) {
     const int m = m_begin + it * BP + prow;
     const bool mv = m < m_end;
-    bool xv = false;
-    size_t xoff = 0;
+    unsigned xoff = OOB, yoff = OOB;
     if (mv) {
       int n = m / pq, rem = m - n * pq;
       int p = rem / a.Q, q = rem - p * a.Q;
       int h = p * a.stride + dht, w = q * a.stride + dwt;
-      xv = (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
-      xoff = (((size_t)n * a.H + h) * a.W + w) * a.C;
+      yoff = (unsigned)(((size_t)(m - n_first * pq)) * a.K * ES);
+      if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) xoff = (unsigned)((((size_t)(n - n_first) * a.H + h) * a.W + w) * a.C * ES);
     }
 #pragma unroll
-    for (int j = 0; j < NJA; ++j) {
-      const int ch = cl + TPR * j;
-      ra[j] = make_uint4(0, 0, 0, 0);
-      if (mv && ch < CHA && k0 + ch * CE < a.K) ra[j] = *reinterpret_cast<const uint4*>(DY + (size_t)m * a.K + k0 + ch * CE);
-    }
+    for (int j = 0; j < NJA; ++j) ra[j] = bload(ydesc, (yoff != OOB && cha_off[j] != OOB) ? yoff + cha_off[j] : OOB);
 #pragma unroll
-    for (int j = 0; j < NJB; ++j) {
-      const int ch = cl + TPR * j;
-      rb[j] = make_uint4(0, 0, 0, 0);
-      if (xv && ch < CHB && c0 + ch * CE < a.C) rb[j] = *reinterpret_cast<const uint4*>(X + xoff + c0 + ch * CE);
-    }
+    for (int j = 0; j < NJB; ++j) rb[j] = bload(xdesc, (xoff != OOB && chb_off[j] != OOB) ? xoff + chb_off[j] : OOB);
   };
   auto store_tile = [&](int buf) {
     char* ta = lds[buf];
@@ -219,7 +244,7 @@ inline int pick_tile(int n) {       // block tile edge from {160,128,64,32}: few
 int wgrad_splits(const rn_conv_geom* g, int bk, int bc) {
   const long M = (long)g->N * g->P * g->Q;
   const int tiles = cdiv(g->K, bk) * cdiv(g->C, bc) * g->R * g->S;
-  int splits = cdiv(768, tiles);
+  int splits = 512 / tiles;                              // one resident round: 2 workgroups per CU x 256 CUs
   const int max_by_rows = (int)((M + 255) / 256);      // at least 8 K-steps per block
   if (splits > max_by_rows) splits = max_by_rows;
   if (splits < 1) splits = 1;
