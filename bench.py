@@ -109,6 +109,7 @@ def main():
     x = torch.randn(cfg['batch'], 3, cfg['hw'], cfg['hw'], generator=gen).to(dev)
     y = torch.randint(0, cfg['classes'], (cfg['batch'],), generator=gen).to(dev)
     reducer = GradReducer(model, world) if world > 1 else None
+    model.alias_grads = True            # gradients are consumed (dropped) every step: no defensive copy of the flat buffer
 
     params = list(model.parameters())
 

@@ -91,6 +91,8 @@ typedef struct rn_plan rn_plan;
 
 const char* rn_last_error(void);
 int rn_version(void);
+/* tuning switch for tools/conv_bench.py (bit0: LDS-patch 3x3 kernel, bit1: plain fragment schedule); 0 = shipped configuration */
+void rn_set_variant(int v);
 
 /* ---- plan executor: the per-batch forward / backward of ResNet.forward as ONE host call each ---- */
 int rn_plan_create(const rn_op* ops, int n_ops, int n_bufs, int dtype, rn_plan** out);

@@ -1,0 +1,32 @@
+"""
+Loss and metrics of one microbatch.  Mirrors /root/reference/resnet/algos/metrics.py:10-41: mean cross-entropy,
+top-1 / top-5 error, and the world-averaged logging values -- with the three scalar all-reduces + three ``.item()``
+host syncs per microbatch (metrics.py:32-36) collapsed into ONE 3-float all-reduce and one host read.
+"""
+from collections import Counter
+
+import torch
+import torch.distributed as dist
+
+
+def cross_entropy_loss(logits, labels):
+    return torch.nn.functional.cross_entropy(logits, labels)
+
+
+def top_k_err(logits, labels, k):
+    topk = torch.topk(logits, k=k, dim=-1).indices
+    return 1.0 - torch.eq(topk, labels.unsqueeze(-1)).float().sum(dim=-1).mean(dim=0)
+
+
+def compute_losses_and_metrics(logits, labels):
+    return {"loss": cross_entropy_loss(logits, labels), "top1_err": top_k_err(logits, labels, 1), "top5_err": top_k_err(logits, labels, 5)}
+
+
+def global_means(metrics, world_size):
+    """for logging only (as the reference): mean over ranks of each metric -> Counter of floats."""
+    keys = list(metrics)
+    packed = torch.stack([metrics[k].detach().float() for k in keys])
+    if world_size > 1 and dist.is_initialized():
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    vals = (packed / world_size).tolist()
+    return Counter(dict(zip(keys, vals)))

@@ -1,0 +1,73 @@
+"""
+The training step around the hot path.  ``train_step`` is this build's counterpart of the reference's step body
+(/root/reference/resnet/algos/training.py:92-113): forward -> loss/metrics -> backward (+ gradient mean across ranks)
+-> optimizer step once ``num_microbatches`` microbatches have been accumulated (gradients are SUMMED over
+microbatches, the loss is not rescaled -- training.py:92-113).  ``training_loop`` keeps the reference's
+control flow (epochs over the loader, scheduler step unit, per-epoch evaluation) without its TensorBoard / checkpoint
+plumbing, which is out of the accelerated path's scope.
+"""
+from collections import Counter
+from typing import Optional
+
+import torch
+
+from .metrics import compute_losses_and_metrics, global_means
+
+
+def train_step(classifier, x, y, optimizer=None, reducer=None, world_size=1, microbatch_id=1, num_microbatches=1, accum=None):
+    """one microbatch.  returns the world-averaged metrics (Counter of floats).  ``reducer``: ddp.GradReducer or None;
+    ``accum``: dict used to sum gradients across microbatches when num_microbatches > 1."""
+    logits = classifier(x)
+    metrics = compute_losses_and_metrics(logits=logits, labels=y)
+    metrics['loss'].backward()
+    if reducer is not None:
+        reducer.finish()
+    if num_microbatches > 1 and accum is not None:
+        for k, p in classifier.named_parameters():
+            if p.grad is None:
+                continue
+            if k in accum:
+                accum[k] += p.grad
+            else:
+                accum[k] = p.grad.clone()
+            p.grad = None
+    out = global_means(metrics, world_size)
+    if optimizer is not None and microbatch_id % num_microbatches == 0:
+        if num_microbatches > 1 and accum is not None:
+            for k, p in classifier.named_parameters():
+                p.grad = accum.pop(k, None)
+        optimizer.step()
+        optimizer.zero_grad(set_to_none=True)
+    return out
+
+
+def training_loop(rank, world_size, device, dl_train, dl_test, classifier, optimizer, scheduler=None, scheduler_step_unit='none',
+                  num_microbatches=1, global_step=0, max_steps=1, reducer=None, sampler_train=None, log=print, **kwargs):
+    from .evaluation import evaluation_loop
+    epoch = 0
+    while global_step < max_steps:
+        if sampler_train is not None:
+            sampler_train.set_epoch(epoch)
+        classifier.train()
+        acc, running = {}, Counter()
+        for microbatch_id, (x, y) in enumerate(dl_train, 1):
+            x, y = x.to(device), y.to(device)
+            running += train_step(classifier, x, y, optimizer, reducer, world_size, microbatch_id, num_microbatches, acc)
+            if microbatch_id % num_microbatches == 0:
+                means = {k: v / num_microbatches for k, v in running.items()}
+                if scheduler is not None and scheduler_step_unit == 'batch':
+                    scheduler.step()
+                if rank == 0:
+                    log(f"global step: {global_step}... loss: {means.get('loss')}")
+                running = Counter()
+                global_step += 1
+                if global_step >= max_steps:
+                    break
+        if dl_test is not None:
+            val = evaluation_loop(world_size, device, dl_test, classifier)
+            if scheduler is not None and scheduler_step_unit == 'epoch':
+                scheduler.step()
+            if rank == 0:
+                log(f"epoch: {epoch}... validation loss: {val.get('loss')}")
+        epoch += 1
+    return global_step

@@ -42,7 +42,14 @@ class _EngineFn(torch.autograd.Function):
             raise RuntimeError("forward ran without gradient support")
         eng.t('dlogits').copy_(dlogits)
         eng.backward(step_seed=ctx.seed, hook_fn=ctx.model._hook_fn)
-        return (None, None, None, None) + tuple(eng.grad_view(k) for k in ctx.keys)
+        # autograd's AccumulateGrad keeps (steals) the tensors returned here as p.grad.  Handing out views of the engine's
+        # flat buffer is zero-copy but means the NEXT backward overwrites p.grad in place -- only safe when the caller
+        # consumes the gradients every step (ddp.GradReducer / bench.py set alias_grads).  Default: one flat copy.
+        if ctx.model.alias_grads and any(p.grad is not None for p in ctx.model.parameters()):
+            raise RuntimeError("alias_grads: parameter .grad must be None before backward (optimizer.zero_grad(set_to_none=True)); "
+                               "an existing .grad would alias the buffer the engine has just overwritten")
+        flat = eng.flat_grad if ctx.model.alias_grads else eng.flat_grad.clone()
+        return (None, None, None, None) + tuple(eng.grad_view(k, flat) for k in ctx.keys)
 
 
 class ResNet(nn.Module):
@@ -62,6 +69,7 @@ class ResNet(nn.Module):
         self._step = 0
         self._seed_base = int(torch.empty((), dtype=torch.int64).random_().item()) & 0x7FFFFFFFFFFF
         self._hook_fn = None
+        self.alias_grads = False        # True: p.grad aliases the engine's flat gradient buffer (no copy; see _EngineFn.backward)
 
     # ---- construction (module order == reference order) ---------------------------------------------------------
     def _parse_spec(self, spec: str) -> nn.Sequential:

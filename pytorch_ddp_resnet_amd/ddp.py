@@ -45,6 +45,7 @@ class GradReducer:
         self._work = []
         self._comm_stream = None
         model._hook_fn = self._on_hook
+        model.alias_grads = True          # finish() re-points p.grad at the reduced flat buffer every step
 
     # ---- hook entry point: called by Engine.run between op ranges -------------------------------------------
     def _on_hook(self, eng, hook):

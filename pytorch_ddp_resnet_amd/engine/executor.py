@@ -17,6 +17,17 @@ _TORCH_DT = {'f32': torch.float32, 'i64': torch.int64, 'u8': torch.uint8}
 ALIGN = 64          # elements: every gradient starts on a 256-byte boundary inside the flat buffer
 
 
+def layout_grads(plan: Plan):
+    """offsets (in elements) of every parameter gradient inside the flat buffer, in gradient-production order, each
+    starting on a 256-byte boundary.  -> (offsets dict, total elements)"""
+    shapes = {s.key: s for s in plan.slots if s.role == 'grad'}
+    offsets, off = {}, 0
+    for key in plan.grad_order:
+        offsets[key] = off
+        off += (shapes[key].numel + ALIGN - 1) // ALIGN * ALIGN
+    return offsets, max(off, 1)
+
+
 class Engine:
     def __init__(self, plan: Plan, device: torch.device, compute_dtype: torch.dtype):
         if device.type != 'cuda':
@@ -28,13 +39,9 @@ class Engine:
         assert plan.meta['fp32'] == (compute_dtype == torch.float32)
         self.generation = 0
         # ---- flat gradient buffer, laid out in the order the backward produces the gradients ----
-        self.grad_offsets: Dict[str, int] = {}
-        shapes = {s.key: s for s in plan.slots if s.role == 'grad'}
-        off = 0
-        for key in plan.grad_order:
-            self.grad_offsets[key] = off
-            off += (shapes[key].numel + ALIGN - 1) // ALIGN * ALIGN
-        self.flat_grad = torch.zeros(max(off, 1), dtype=torch.float32, device=device)
+        self.grad_offsets, total = layout_grads(plan)
+        self._grad_slots = {s.key: s for s in plan.slots if s.role == 'grad'}
+        self.flat_grad = torch.zeros(total, dtype=torch.float32, device=device)
         # ---- workspace (shared by all wgrad launches: they are serialised on one stream) ----
         ws_bytes = 0
         for kind, g in plan.meta['ws_need']:
@@ -150,9 +157,10 @@ class Engine:
     def t(self, name):
         return self.tensors[self.plan.slot_of[name]]
 
-    def grad_view(self, key):
-        """the gradient of parameter `key`, shaped like the parameter (conv: [K,C,R,S] view of KRSC storage)."""
-        s = next(sl for sl in self.plan.slots if sl.role == 'grad' and sl.key == key)
+    def grad_view(self, key, flat=None):
+        """the gradient of parameter `key`, shaped like the parameter (conv: [K,C,R,S] view of KRSC storage), as a view
+        of `flat` (default: the engine's own flat gradient buffer)."""
+        s = self._grad_slots[key]
         o = self.grad_offsets[key]
-        g = self.flat_grad[o:o + s.numel].view(s.shape if s.shape else ())
+        g = (self.flat_grad if flat is None else flat)[o:o + s.numel].view(s.shape if s.shape else ())
         return g.permute(0, 3, 1, 2) if g.dim() == 4 else g

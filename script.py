@@ -1,0 +1,104 @@
+"""
+Entrypoint: ``python -m script --mode {train,eval} --models_dir models_dir --run_name <run> --data_dir <dir>``.
+
+Mirrors /root/reference/script.py: same four CLI flags (:20-29), same config surface (``models_dir/<run>/config.yaml``
+merged over ``{mode, data_dir, checkpoint_dir, log_dir}``, :32-46), one process per rank via ``mp.spawn`` (:129-136),
+``init_process_group(backend, world_size, rank)`` with ``master_addr/master_port`` from the config (:50-56).  What
+changes: on an MI355X node the backend is RCCL over xGMI whatever the YAML says (``nccl`` IS RCCL under PyTorch-ROCm;
+``gloo`` is kept for CPU-only plumbing runs, which cannot execute the HIP path), each rank binds to its own GPU, and
+DistributedDataParallel (:64-71) is replaced by ``ddp.GradReducer`` (bucketed all-reduce overlapped with the engine's
+backward) + a rank-0 parameter broadcast.  Dataset loading (torchvision, transforms) is outside the accelerated path:
+``--data_dir synthetic`` (or a missing torchvision) feeds the fixed-shape synthetic batches the benchmark uses.
+"""
+import argparse
+import os
+
+import torch
+
+from pytorch_ddp_resnet_amd import ResNet
+from pytorch_ddp_resnet_amd.algos.evaluation import evaluation_loop
+from pytorch_ddp_resnet_amd.algos.training import training_loop
+from pytorch_ddp_resnet_amd.ddp import GradReducer, broadcast_parameters
+from pytorch_ddp_resnet_amd.utils.config_util import ConfigParser
+from pytorch_ddp_resnet_amd.utils.optim_util import get_optimizer, get_scheduler
+
+_SHAPES = {'CIFAR10': (32, 10), 'CIFAR100': (32, 100), 'ImageNet': (224, 1000)}
+
+
+def create_argparser():
+    parser = argparse.ArgumentParser(description="MI355X-native ResNet trainer (drop-in for lucaslingle/pytorch_ddp_resnet's script.py)")
+    parser.add_argument("--mode", choices=['train', 'eval'], default='train')
+    parser.add_argument("--models_dir", type=str, default='models_dir')
+    parser.add_argument("--run_name", type=str, default='wrn-28-10-dropout_cifar10')
+    parser.add_argument("--data_dir", type=str, default='synthetic')
+    return parser
+
+
+def get_config(args):
+    base = os.path.join(args.models_dir, args.run_name)
+    config = ConfigParser(defaults={'mode': args.mode, 'data_dir': args.data_dir, 'checkpoint_dir': os.path.join(base, 'checkpoints'),
+                                    'log_dir': os.path.join(base, 'tensorboard_logs')})
+    config.read(os.path.join(base, 'config.yaml'), verbose=True)
+    return config
+
+
+class SyntheticLoader:
+    """fixed-shape N(0,1) NCHW fp32 batches resident on the device: `steps` microbatches per epoch."""
+
+    def __init__(self, batch, hw, classes, steps, device, seed):
+        g = torch.Generator().manual_seed(seed)
+        self.x = torch.randn(batch, 3, hw, hw, generator=g).to(device)
+        self.y = torch.randint(0, classes, (batch,), generator=g).to(device)
+        self.steps = steps
+
+    def __iter__(self):
+        for _ in range(self.steps):
+            yield self.x, self.y
+
+
+def setup(rank, config):
+    os.environ['MASTER_ADDR'] = config.get('master_addr')
+    os.environ['MASTER_PORT'] = str(config.get('master_port'))
+    on_gpu = torch.cuda.is_available()
+    backend = 'nccl' if on_gpu else config.get('backend')
+    world = config.get('world_size')
+    if on_gpu:
+        torch.cuda.set_device(rank)
+    torch.distributed.init_process_group(backend=backend, world_size=world, rank=rank)
+    device = torch.device('cuda', rank) if on_gpu else torch.device('cpu')
+    if config.get('data_dir') != 'synthetic':
+        raise NotImplementedError("dataset loading is outside the accelerated path (SURVEY 2, row 11): run with --data_dir synthetic")
+    hw, classes = _SHAPES[config.get('dataset_cls_name')]
+    local_batch = config.get('batch_size') // (config.get('num_microbatches') * world)          # data_util.py:216 (batch_size is global)
+    steps = config.get('num_microbatches') * 4
+    dl_train = SyntheticLoader(local_batch, hw, classes, steps, device, 1234 + rank)
+    dl_test = SyntheticLoader(local_batch, hw, classes, 2, device, 4321 + rank)
+    classifier = ResNet(architecture_spec=config.get('architecture_spec'), preact=config.get('preact'), use_proj=config.get('use_proj'),
+                        dropout_prob=config.get('dropout_prob'), sync_bn=bool(dict(config).get('sync_bn', False))).to(device)
+    if world > 1:
+        broadcast_parameters(classifier)                       # ranks draw different initial weights (no seeding): rank 0 defines the model
+    reducer = GradReducer(classifier, world) if world > 1 else None
+    optimizer = get_optimizer(config.get('optimizer_cls_name'), classifier, config.get('optimizer_args'))
+    scheduler = get_scheduler(config.get('scheduler_cls_name'), optimizer, config.get('scheduler_args'))
+    return dict(device=device, dl_train=dl_train, dl_test=dl_test, classifier=classifier, optimizer=optimizer, scheduler=scheduler,
+                reducer=reducer, global_step=0)
+
+
+def train(rank, config):
+    system = setup(rank, config)
+    training_loop(rank, **{k: v for k, v in config.items() if k not in system}, **system)
+    torch.distributed.destroy_process_group()
+
+
+def evaluate(rank, config):
+    system = setup(rank, config)
+    metrics = evaluation_loop(config.get('world_size'), system['device'], system['dl_test'], system['classifier'])
+    if rank == 0:
+        print(f"Test metrics: {metrics}")
+    torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    args = create_argparser().parse_args()
+    config = get_config(args)
+    torch.multiprocessing.spawn(train if config.get('mode') == 'train' else evaluate, args=(config,), nprocs=config.get('world_size'), join=True)

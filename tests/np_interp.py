@@ -103,7 +103,7 @@ class NumpyPlan:
         d, k = op.dim, op.kind
 
         def put(n, v):
-            self.bufs[op.buf[n]] = np.asarray(v, dtype=self.bufs[op.buf[n]].dtype).reshape(self.bufs[op.buf[n]].shape)
+            self.bufs[op.buf[n]] = np.array(v, dtype=self.bufs[op.buf[n]].dtype).reshape(self.bufs[op.buf[n]].shape)   # copy: slots never alias
 
         def w_kcrs(w, K, R, S, C):
             return np.transpose(w.reshape(K, R, S, C), (0, 3, 1, 2))

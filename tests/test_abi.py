@@ -1,0 +1,64 @@
+"""The C-ABI library loads on a machine without a GPU and exports every symbol include/rn_hip.h declares; the Python
+mirror of the header constants (engine/ir.py) agrees with the header.  No compute calls."""
+import os
+import re
+
+import pytest
+
+from pytorch_ddp_resnet_amd import _lib
+from pytorch_ddp_resnet_amd.engine import ir
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = open(os.path.join(ROOT, 'include', 'rn_hip.h')).read()
+
+
+def header_enum(name):
+    m = re.search(r'\b%s\s*=\s*([^,/\n}]+)' % name, HEADER)
+    assert m, name
+    return eval(m.group(1).strip())
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('librn_hip.so not built (run __graft_entry__.build())')
+    L = _lib.lib()
+    names = set(re.findall(r'\b(rn_[a-z0-9_]+)\s*\(', HEADER))
+    assert len(names) >= 30
+    for n in sorted(names):
+        assert hasattr(L, n), f'{n} declared in rn_hip.h but not exported'
+    assert L.rn_version() >= 1
+    assert isinstance(L.rn_last_error(), bytes)
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    monkeypatch.setattr(_lib, '_lib', None)
+    monkeypatch.setattr(_lib, 'LIB_PATH', '/nonexistent/librn_hip.so')
+    with pytest.raises(_lib.RnError, match='no fallback'):
+        _lib.lib()
+
+
+def test_constants_match_header():
+    for k, v in vars(ir).items():
+        if k.startswith('OP_') and isinstance(v, int) and k not in ('OP_NBUF', 'OP_NDIM'):
+            assert header_enum('RN_' + k) == v, k
+    for k in ('RES_NONE', 'RES_SAME', 'RES_DOWN2PAD', 'RES_UP2'):
+        assert header_enum('RN_' + k) == getattr(ir, k)
+    for k in ('F_RELU', 'F_TRAIN', 'F_ACCUM', 'F_WRITE_G', 'F_NEED_DGRAD_PACK', 'F_SKIP_FWD_PACK', 'F_NO_DX'):
+        assert header_enum('RN_' + k) == getattr(ir, k)
+    assert header_enum('RN_F32') == ir.RN_F32 and header_enum('RN_BF16') == ir.RN_BF16
+    assert int(re.search(r'#define RN_OP_NBUF (\d+)', HEADER).group(1)) == ir.OP_NBUF
+    assert int(re.search(r'#define RN_OP_NDIM (\d+)', HEADER).group(1)) == ir.OP_NDIM
+
+
+def test_op_struct_layout():
+    import ctypes as C
+    assert C.sizeof(_lib.RnOp) == 4 * (2 + ir.OP_NBUF + ir.OP_NDIM + 4 + 2)
+    assert C.sizeof(_lib.RnConvGeom) == 44
+
+
+def test_cpu_forward_refuses():
+    import torch
+    from pytorch_ddp_resnet_amd import ResNet
+    m = ResNet('c3,16,3,1,1 n a r1 ap32,1,0 fc16,10', False, False, 0.0)
+    with pytest.raises(RuntimeError, match='no CPU'):
+        m(torch.zeros(2, 3, 32, 32))
