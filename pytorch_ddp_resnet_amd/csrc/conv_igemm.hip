@@ -275,7 +275,10 @@ template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   const int K = a.Kd;
   // column tile: the widest of {160,128,96,64,32} that wastes no 32-column MFMA tile
-  if (K % 160 == 0) return launch_cfg<T, 128, 160, 4, 1>(a, s);
+  if (K % 160 == 0) {
+    if ((g_rn_variant & 4) && a.M >= 256 * 256) return launch_cfg<T, 256, 160, 4, 1>(a, s);     // experiment: 64x160 wave tiles
+    return launch_cfg<T, 128, 160, 4, 1>(a, s);
+  }
   if (K % 128 == 0) return launch_cfg<T, 128, 128, 2, 2>(a, s);
   if (K % 96 == 0) return launch_cfg<T, 128, 96, 4, 1>(a, s);
   if (K > 32) return launch_cfg<T, 128, 64, 2, 2>(a, s);
