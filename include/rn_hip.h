@@ -91,7 +91,7 @@ typedef struct rn_plan rn_plan;
 
 const char* rn_last_error(void);
 int rn_version(void);
-/* tuning switch for tools/conv_bench.py (bit0: LDS-patch 3x3 kernel, bit1: plain fragment schedule); 0 = shipped configuration */
+/* kernel-variant switch for A/B measurements (tools/conv_bench.py; bits documented in csrc/conv_igemm.hip); 0 = shipped */
 void rn_set_variant(int v);
 
 /* ---- plan executor: the per-batch forward / backward of ResNet.forward as ONE host call each ---- */

@@ -51,6 +51,9 @@ def lib():
     L.rn_stem_wgrad_ws_bytes.restype = sz
     L.rn_softmax_ce.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
     L.rn_sgd_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, f32, vp]
+    L.rn_set_variant.argtypes = [i32]
+    if os.environ.get('RN_VARIANT'):          # kernel-variant switch for A/B runs (tools/conv_bench.py); unset = shipped configuration
+        L.rn_set_variant(int(os.environ['RN_VARIANT']))
     _lib = L
     return L
 

@@ -18,7 +18,8 @@
 int rn_conv3x3_patch(const void* src, const void* wt, void* dst, const ResDesc& res, int accum, int dtype, int N, int H, int W, int C, int K,
                      bool flip, rn_stream s);
 
-int g_rn_variant = 0;   // tuning switch (tools/conv_bench.py): bit0 = use the LDS-patch 3x3 kernel, bit1 = plain fragment schedule
+int g_rn_variant = 0;   // tuning switch (tools/conv_bench.py): bit0 LDS-patch 3x3 kernel, bit1 register staging w/o fragment
+                        // double-buffering, bit2 256-row tile, bit3 register-staged kernel, bit4 4-stage 64-byte-row DMA ring
 extern "C" void rn_set_variant(int v) { g_rn_variant = v; }
 
 namespace {
@@ -262,11 +263,262 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-DMA variant: the A (activation) and B (weight) tiles go global -> LDS directly with `buffer_load_dwordx4 ... lds`
+// (no staging VGPRs, no ds_write: the VGPR->LDS store path was the busiest LDS client of the register-staged kernel).
+// Facts it relies on (tools/probes/lds_dma_oob.hip, measured on gfx950): the LDS destination of a wave instruction is
+// base + lane*16 (lane-linear, 1 KiB per instruction); an out-of-range buffer offset writes ZEROS (padding taps, K tail);
+// masked lanes write nothing.  The XOR swizzle therefore moves to the SOURCE side: lane l of an instruction covering rows
+// [R0, R0+64/CPRT) owns physical slot p = l % CPRT of row R0 + l / CPRT and fetches logical chunk p ^ swz(row).
+// ---------------------------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int CPRT> __device__ inline int swz_t(int row, int chunk) {
+  return CPRT == 8 ? row * 8 + (chunk ^ ((row >> 1) & 7)) : row * 4 + (chunk ^ ((row >> 2) & 3));
+}
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor (stride 0, bounds-checked on num_records bytes), built from wave-uniform values only
+__device__ inline v4i32 make_desc(const void* base, size_t bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  v4i32 d;
+  d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b & 0xFFFFFFFFull));
+  d[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((b >> 32) & 0xFFFFull));
+  d[2] = __builtin_amdgcn_readfirstlane((int)(bytes > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (unsigned)bytes));
+  d[3] = 0x00020000;
+  return d;
+}
+
+// one LDS-DMA wave instruction, invisible to hipcc's waitcnt pass (it would otherwise drain vmcnt(0) before every
+// ds_read of the same array): LDS[m0 + lane*16 .. +16) = desc[voff .. voff+16), zeros when voff is out of range.
+// M0 is saved/restored inside the statement; completion is tracked by the caller's counted s_waitcnt vmcnt.
+__device__ inline void dma16(v4i32 desc, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(voff), "s"(desc), "s"(lds_addr)
+               : "memory");
+}
+
+template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// NSTG LDS stages form a ring: at iteration `it` the DMA of tile it+NSTG-1 is issued while tile `it` is multiplied, so a
+// tile has NSTG-2 full iterations to land (global latency under full-chip load is several thousand cycles: one
+// iteration of cover is not enough).  Waits are COUNTED (`s_waitcnt vmcnt(k * PER)`, PER = DMA instructions a wave issues
+// per tile, identical for all waves: the B tile is padded with out-of-range dummies) and the barrier is the raw
+// `s_barrier`: `__syncthreads()` would make hipcc drain every DMA in flight.  All LDS lives in ONE __shared__ array (a
+// second __shared__ object makes hipcc wait vmcnt(0) before every ds_read; cdna_hip_programming.md section 5).
+template <typename T, int BM, int BN, int WM, int WN, int CPRT, int NSTG>
+__global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int RPI = 64 / CPRT;                       // rows per DMA instruction (1 KiB)
+  constexpr int AIT = BM / RPI, BIT = BN / RPI;        // DMA instructions per tile
+  constexpr int AI = AIT / 4, BI = (BIT + 3) / 4;      // per wave (B padded to a multiple of 4 instructions)
+  constexpr int PER = AI + BI;
+  constexpr int KS = CPRT / 2;
+  constexpr int NST = CPRT == 8 ? 2 : 1;               // distinct logical chunk columns a lane serves
+  constexpr int STAGE = (BM + 4 * BI * RPI) * CPRT;    // uint4 per stage (B region padded)
+  static_assert(WM * WN == 4 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && AIT % 4 == 0 && BN % RPI == 0 && NSTG >= 2 && NSTG <= 4, "tile");
+  __shared__ uint4 smem[NSTG * STAGE + 8];
+  int* taps = reinterpret_cast<int*>(&smem[NSTG * STAGE]);     // [0..9] source byte offset of tap, [16..25] weight byte offset
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: feeds M0 / SGPR operands
+  const int nmt = (a.M + BM - 1) / BM;
+  const int mt = blockIdx.x % nmt, ntile = blockIdx.x / nmt;
+  const int m0 = mt * BM, n0 = ntile * BN;
+  const int pq = a.Pc * a.Qc;
+
+  const int n_first = m0 / pq;
+  const size_t img_bytes = (size_t)a.Hs * a.Ws * a.Cs * ES;
+  const size_t a_left = (size_t)(a.N - n_first) * img_bytes;
+  const v4i32 ra_desc = make_desc(reinterpret_cast<const char*>(a.src) + (size_t)n_first * img_bytes, a_left);
+  const size_t w_total = (size_t)a.Kd * a.wrs * a.Cs * ES;
+  const v4i32 rb_desc = make_desc(a.wt, w_total);
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);           // LDS byte address of the ring
+
+  if (tid <= MAX_TAPS) {
+    int t = tid < a.nt ? tid : 0;
+    taps[tid] = tid < a.nt ? (a.dh[t] * a.Ws + a.dw[t]) * a.Cs * ES : 0;
+    taps[16 + tid] = tid < a.nt ? a.widx[t] * a.Cs * ES : 0;
+  }
+
+  // ---- per-lane DMA roles ----
+  const int lrow = lane / CPRT, p = lane % CPRT;
+  unsigned abase[AI], amask[AI];
+#pragma unroll
+  for (int i = 0; i < AI; ++i) {
+    const int m = m0 + RPI * (wave * AI + i) + lrow;
+    amask[i] = 0; abase[i] = 0;
+    if (m < a.M) {
+      int n = m / pq, rem = m - n * pq;
+      int pp = rem / a.Qc, q = rem - pp * a.Qc;
+      int hb = pp * a.ss, wb = q * a.ss;
+      abase[i] = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES);
+      unsigned mk = 0;
+      for (int t = 0; t < a.nt; ++t) {
+        int h = hb + a.dh[t], w = wb + a.dw[t];
+        if ((unsigned)h < (unsigned)a.Hs && (unsigned)w < (unsigned)a.Ws) mk |= 1u << t;
+      }
+      amask[i] = mk;
+    }
+  }
+  unsigned bbase[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int rn = RPI * (wave * BI + i) + lrow;
+    const int k = n0 + rn;
+    bbase[i] = (rn < BN && k < a.Kd) ? (unsigned)((size_t)k * a.wrs * a.Cs * ES) : OOB;     // padded rows: zeros, never read
+  }
+  int tapk[NST], cck[NST];
+#pragma unroll
+  for (int k = 0; k < NST; ++k) {
+    const int sw = CPRT == 8 ? (((lane >> 4) + 4 * k) & 7) : ((lane >> 4) & 3);
+    cck[k] = p ^ sw;
+    tapk[k] = 0;
+    while (cck[k] >= a.cpt) { cck[k] -= a.cpt; ++tapk[k]; }
+  }
+  __syncthreads();          // tap tables visible (no DMA in flight yet)
+
+  auto dma_tile = [&](int stg) {
+    unsigned so[NST], wo[NST];
+    bool kv[NST];
+    int tp[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      kv[k] = tapk[k] < a.nt;
+      tp[k] = kv[k] ? tapk[k] : 0;
+      so[k] = (unsigned)(taps[tp[k]] + cck[k] * 16);
+      wo[k] = (unsigned)(taps[16 + tp[k]] + cck[k] * 16);
+    }
+    const unsigned base = lds0 + (unsigned)(stg * STAGE * 16);
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int j = wave * AI + i;
+      const int k = NST == 2 ? (j & 1) : 0;
+      const unsigned off = (kv[k] && ((amask[i] >> tp[k]) & 1)) ? abase[i] + so[k] : OOB;
+      dma16(ra_desc, off, base + j * 1024);
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int j = wave * BI + i;
+      const int k = NST == 2 ? (j & 1) : 0;
+      const unsigned off = (kv[k] && bbase[i] != OOB) ? bbase[i] + wo[k] : OOB;
+      dma16(rb_desc, off, base + BM * CPRT * 16 + j * 1024);
+    }
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      cck[k] += CPRT;
+      while (cck[k] >= a.cpt) { cck[k] -= a.cpt; ++tapk[k]; }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int arow0 = wm * (BM / WM) + lr, brow0 = wn * (BN / WN) + lr;
+
+  // prologue: tiles 0 .. NSTG-2 in flight, tile 0 landed
+#pragma unroll
+  for (int t = 0; t < NSTG - 1; ++t)
+    if (t < a.nk) dma_tile(t);
+  {
+    const int inflight = min(a.nk, NSTG - 1) - 1;      // groups allowed to stay outstanding behind tile 0
+    if (inflight >= 2) wait_vmcnt<2 * PER>(); else if (inflight == 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+  }
+  __builtin_amdgcn_s_barrier();
+  int stg = 0;
+  for (int it = 0; it < a.nk; ++it) {
+    const uint4* cur_s = &smem[stg * STAGE];
+    int nstg = stg + (NSTG - 1); if (nstg >= NSTG) nstg -= NSTG;
+    if (it + NSTG - 1 < a.nk) dma_tile(nstg);          // ring slot read last in iteration it-1: free since the barrier
+    uint4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = cur_s[swz_t<CPRT>(arow0 + 32 * i, lh)];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = cur_s[BM * CPRT + swz_t<CPRT>(brow0 + 32 * j, lh)];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < KS) {
+        const int ch = 2 * (ks + 1) + lh;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa[nxt][i] = cur_s[swz_t<CPRT>(arow0 + 32 * i, ch)];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[nxt][j] = cur_s[BM * CPRT + swz_t<CPRT>(brow0 + 32 * j, ch)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur][i], fb[cur][j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // tile it+1 must have landed (for every wave) before the next iteration reads it; later tiles stay in flight
+    const int later = min(a.nk - 2 - it, NSTG - 2);    // DMA groups issued after tile it+1 that exist
+    if (later >= 2) wait_vmcnt<2 * PER>(); else if (later == 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    if (++stg == NSTG) stg = 0;
+  }
+
+  T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
+  const bool dense = (a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME);
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + row;
+      if (m >= a.M) continue;
+      size_t pix;
+      int n = 0, hd = 0, wd = 0;
+      if (dense) {
+        pix = (size_t)m;
+      } else {
+        n = m / pq;
+        int rem = m - n * pq;
+        int pp = rem / a.Qc, q = rem - pp * a.Qc;
+        hd = pp * a.ds + a.oh;
+        wd = q * a.ds + a.ow;
+        pix = ((size_t)n * a.Hd + hd) * a.Wd + wd;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int k = n0 + wn * (BN / WN) + 32 * j + lr;
+        if (k >= a.Kd) continue;
+        float v = acc[i][j][r];
+        const size_t off = pix * a.Kd + k;
+        if (a.res.mode != RN_RES_NONE) {
+          if (dense) v += Elem<T>::to_f(reinterpret_cast<const T*>(a.res.ptr)[off]);
+          else v += res_load1<T>(a.res, n, hd, wd, k);
+        }
+        if (a.accum) v += Elem<T>::to_f(dst[off]);
+        dst[off] = Elem<T>::from_f(v);
+      }
+    }
+  }
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   int nmt = cdiv(a.M, BM), nnt = cdiv(a.Kd, BN);
-  if (g_rn_variant & 2) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, 0>), dim3(nmt * nnt), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, 1>), dim3(nmt * nnt), dim3(256), 0, s, a);
+  if (!(g_rn_variant & (2 | 8 | 16))) {          // shipped configuration: LDS-DMA staging, 128-byte K rows, 2 LDS stages
+    hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, 8, 2>), dim3(nmt * nnt), dim3(256), 0, s, a);
+  } else if (g_rn_variant & 16) {
+    IgemmArgs b = a;
+    b.nk = cdiv((long)a.nt * a.cpt, 4);
+    hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, 4, 4>), dim3(nmt * nnt), dim3(256), 0, s, b);
+  } else if (g_rn_variant & 2) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, 0>), dim3(nmt * nnt), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, 1>), dim3(nmt * nnt), dim3(256), 0, s, a);      // bit3: register-staged kernel
   RN_CHECK_LAUNCH("igemm");
   return 0;
 }
