@@ -114,6 +114,23 @@ typedef struct rn_conv_geom {
   int32_t R, S, stride, pad;
 } rn_conv_geom;
 
+/* optional fused epilogue of rn_conv_fwd / rn_conv_dgrad (NULL = plain store).  The convolution reduces, per tile of
+ * RN_CONV_STATS_ROWS output pixels, two per-channel sums of what it stores, so the adjacent BatchNorm needs no pass of
+ * its own over the tensor:
+ *   forward (bn_x == NULL): partial[row][0][k] = sum y, partial[row][1][k] = sum y^2        -> rn_bn_finalize
+ *   dgrad   (bn_x != NULL): g = dx * gscale * [bn_mask > 0];  partial[row] = (sum g, sum g*xhat), xhat from bn_x, bn_coef
+ *                                                                                             -> rn_bn_bwd_finalize
+ * partial has rn_conv_stats_rows(g, is_dgrad) rows of [2][channels]. */
+#define RN_CONV_STATS_ROWS 128
+typedef struct rn_conv_epilogue {
+  float* partial;
+  const void* bn_x;
+  const void* bn_mask;     /* NULL: no ReLU/dropout mask */
+  const float* bn_coef;    /* [4][C] of that BatchNorm */
+  float gscale;            /* 1/(1-p) of the dropout behind that BatchNorm, else 1 */
+} rn_conv_epilogue;
+int rn_conv_stats_rows(const rn_conv_geom* g, int is_dgrad);
+
 /* ---- single kernels (also the executor's building blocks; tests call these through one-op plans or directly) ---- */
 
 /* y[n,p,q,k] = bias[k] + sum x[n,c,p*s+r-pad,q*s+t-pad] * w[k,r,t,c];  x NCHW fp32, w KRSC fp32, y NHWC dtype */
@@ -129,10 +146,10 @@ int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, int dtype, 
 
 /* y = conv(x, w_fwd) [+ res];  MFMA implicit GEMM, M = N*P*Q, N = K, K = R*S*C.  C % 8 == 0, K % 16 == 0 */
 int rn_conv_fwd(const void* x, const void* w_fwd, void* y, const void* res, int res_mode, int res_C, int dtype,
-                const rn_conv_geom* g, rn_stream s);
+                const rn_conv_geom* g, const rn_conv_epilogue* ep, rn_stream s);
 /* dx = conv_transpose(dy, w) [+ res] ; flags: RN_F_ACCUM */
 int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* res, int res_mode, int res_C,
-                  int flags, int dtype, const rn_conv_geom* g, rn_stream s);
+                  int flags, int dtype, const rn_conv_geom* g, const rn_conv_epilogue* ep, rn_stream s);
 /* dw[k,r,s,c] (fp32 KRSC) = sum_{n,p,q} dy * x ; split over pixels into ws, then reduced. flags: RN_F_ACCUM */
 int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void* ws, size_t ws_bytes, int flags, int dtype,
                   const rn_conv_geom* g, rn_stream s);

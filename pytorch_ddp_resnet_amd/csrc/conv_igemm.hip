@@ -22,6 +22,8 @@ int g_rn_variant = 0;   // tuning switch (tools/conv_bench.py): bit0 LDS-patch 3
                         // double-buffering, bit2 256-row tile, bit3 register-staged kernel, bit4 4-stage 64-byte-row DMA ring
 extern "C" void rn_set_variant(int v) { g_rn_variant = v; }
 
+#define RN_CONV_CHECK_EP RN_CHECK_ARG(!ep || (ep->partial && !ep->bn_x), "rn_conv_fwd: the forward epilogue takes `partial` only");
+
 namespace {
 
 constexpr int MAX_TAPS = 9;
@@ -39,6 +41,13 @@ struct IgemmArgs {
   int nt, wrs, cpt, nk;
   int accum;
   int dh[MAX_TAPS], dw[MAX_TAPS], widx[MAX_TAPS];
+  // fused epilogues (rn_conv_epilogue): per-M-tile partial sums written to stats[(tile_base + m-tile)][2][Kd]
+  float* stats;            // forward: (sum y, sum y^2) of the stored output
+  const void* bn_x;        // dgrad: (sum g, sum g*xhat), g = dx * gscale * [mask > 0], xhat = (bn_x - mean) * invstd
+  const void* bn_mask;
+  const float* bn_coef;
+  float gscale;
+  int tile_base;
 };
 
 template <typename T> struct Mfma;
@@ -55,6 +64,101 @@ template <> struct Mfma<bf16_t> {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
   }
 };
+
+
+// ---- epilogue shared by the register-staged and the LDS-DMA kernel ------------------------------------------------------
+// C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Besides the store (+ residual,
+// + accumulate) it can reduce per-channel statistics of what it stores -- the BatchNorm batch statistics of the next
+// layer (forward) or the two BatchNorm-backward sums of the previous one (dgrad) -- so those layers need no pass of
+// their own over the tensor: lane sums over its 16 rows, the two half-waves are folded with a cross-lane add, the
+// WM waves of a column strip through LDS (`red`, the staging memory, free after the K loop), one row per M tile out.
+template <typename T, int BM, int BN, int WM, int WN, int TM, int TN>
+__device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int wave, int lane, float* red) {
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int pq = a.Pc * a.Qc;
+  T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
+  const bool dense = (a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME);
+  const bool want_stats = a.stats != nullptr;
+  const bool bn_bwd = want_stats && a.bn_x != nullptr;
+  float s0[TN], s1[TN], mean[TN], invstd[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    s0[j] = s1[j] = 0.f; mean[j] = 0.f; invstd[j] = 1.f;
+    const int k = n0 + wn * (BN / WN) + 32 * j + lr;
+    if (bn_bwd && k < a.Kd) { mean[j] = a.bn_coef[2 * a.Kd + k]; invstd[j] = a.bn_coef[3 * a.Kd + k]; }
+  }
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + row;
+      if (m >= a.M) continue;
+      size_t pix;
+      int n = 0, hd = 0, wd = 0;
+      if (dense) {
+        pix = (size_t)m;
+      } else {
+        n = m / pq;
+        int rem = m - n * pq;
+        int pp = rem / a.Qc, q = rem - pp * a.Qc;
+        hd = pp * a.ds + a.oh;
+        wd = q * a.ds + a.ow;
+        pix = ((size_t)n * a.Hd + hd) * a.Wd + wd;
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int k = n0 + wn * (BN / WN) + 32 * j + lr;
+        if (k >= a.Kd) continue;
+        float v = acc[i][j][r];
+        const size_t off = pix * a.Kd + k;
+        if (a.res.mode != RN_RES_NONE) {
+          if (dense) v += Elem<T>::to_f(reinterpret_cast<const T*>(a.res.ptr)[off]);
+          else v += res_load1<T>(a.res, n, hd, wd, k);
+        }
+        if (a.accum) v += Elem<T>::to_f(dst[off]);
+        const T stored = Elem<T>::from_f(v);
+        dst[off] = stored;
+        if (want_stats) {
+          const float vs = Elem<T>::to_f(stored);            // statistics of the value the next kernel will read
+          if (!bn_bwd) { s0[j] += vs; s1[j] += vs * vs; }
+          else {
+            float g = vs * a.gscale;
+            if (a.bn_mask && !(Elem<T>::to_f(reinterpret_cast<const T*>(a.bn_mask)[off]) > 0.f)) g = 0.f;
+            const float xh = (Elem<T>::to_f(reinterpret_cast<const T*>(a.bn_x)[off]) - mean[j]) * invstd[j];
+            s0[j] += g; s1[j] += g * xh;
+          }
+        }
+      }
+    }
+  }
+  if (!want_stats) return;
+  // fold the two half-waves (rows 4*lh + ...), then the WM waves of this column strip
+#pragma unroll
+  for (int j = 0; j < TN; ++j) { s0[j] += __shfl_xor(s0[j], 32, 64); s1[j] += __shfl_xor(s1[j], 32, 64); }
+  __syncthreads();                                            // every wave is done reading the staging LDS
+  if (lh == 0) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int col = wn * (BN / WN) + 32 * j + lr;
+      red[(wm * 2 + 0) * BN + col] = s0[j];
+      red[(wm * 2 + 1) * BN + col] = s1[j];
+    }
+  }
+  __syncthreads();
+  const int tid = wave * 64 + lane;
+  for (int col = tid; col < BN; col += 256) {
+    const int k = n0 + col;
+    if (k >= a.Kd) continue;
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < WM; ++w) { t0 += red[(w * 2 + 0) * BN + col]; t1 += red[(w * 2 + 1) * BN + col]; }
+    float* out = a.stats + ((size_t)(a.tile_base + m0 / BM) * 2) * a.Kd;
+    out[k] = t0;
+    out[a.Kd + k] = t1;
+  }
+}
 
 typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
 
@@ -224,43 +328,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5) ----
-  T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
-  const bool dense = (a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int m = m0 + row;
-      if (m >= a.M) continue;
-      size_t pix;
-      int n = 0, hd = 0, wd = 0;
-      if (dense) {
-        pix = (size_t)m;
-      } else {
-        n = m / pq;
-        int rem = m - n * pq;
-        int p = rem / a.Qc, q = rem - p * a.Qc;
-        hd = p * a.ds + a.oh;
-        wd = q * a.ds + a.ow;
-        pix = ((size_t)n * a.Hd + hd) * a.Wd + wd;
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int k = n0 + wn * (BN / WN) + 32 * j + lr;
-        if (k >= a.Kd) continue;
-        float v = acc[i][j][r];
-        const size_t off = pix * a.Kd + k;
-        if (a.res.mode != RN_RES_NONE) {
-          if (dense) v += Elem<T>::to_f(reinterpret_cast<const T*>(a.res.ptr)[off]);
-          else v += res_load1<T>(a.res, n, hd, wd, k);
-        }
-        if (a.accum) v += Elem<T>::to_f(dst[off]);
-        dst[off] = Elem<T>::from_f(v);
-      }
-    }
-  }
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN>(a, acc, m0, n0, tid >> 6, tid & 63, reinterpret_cast<float*>(&lds[0][0]));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -470,42 +538,7 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
     if (++stg == NSTG) stg = 0;
   }
 
-  T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
-  const bool dense = (a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME);
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int m = m0 + row;
-      if (m >= a.M) continue;
-      size_t pix;
-      int n = 0, hd = 0, wd = 0;
-      if (dense) {
-        pix = (size_t)m;
-      } else {
-        n = m / pq;
-        int rem = m - n * pq;
-        int pp = rem / a.Qc, q = rem - pp * a.Qc;
-        hd = pp * a.ds + a.oh;
-        wd = q * a.ds + a.ow;
-        pix = ((size_t)n * a.Hd + hd) * a.Wd + wd;
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int k = n0 + wn * (BN / WN) + 32 * j + lr;
-        if (k >= a.Kd) continue;
-        float v = acc[i][j][r];
-        const size_t off = pix * a.Kd + k;
-        if (a.res.mode != RN_RES_NONE) {
-          if (dense) v += Elem<T>::to_f(reinterpret_cast<const T*>(a.res.ptr)[off]);
-          else v += res_load1<T>(a.res, n, hd, wd, k);
-        }
-        if (a.accum) v += Elem<T>::to_f(dst[off]);
-        dst[off] = Elem<T>::from_f(v);
-      }
-    }
-  }
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN>(a, acc, m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
@@ -528,7 +561,7 @@ template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   const int K = a.Kd;
   // column tile: the widest of {160,128,96,64,32} that wastes no 32-column MFMA tile
   if (K % 160 == 0) {
-    if ((g_rn_variant & 4) && a.M >= 256 * 256) return launch_cfg<T, 256, 160, 4, 1>(a, s);     // experiment: 64x160 wave tiles
+    if ((g_rn_variant & 4) && !a.stats && a.M >= 256 * 256) return launch_cfg<T, 256, 160, 4, 1>(a, s);     // experiment: 64x160 wave tiles
     return launch_cfg<T, 128, 160, 4, 1>(a, s);
   }
   if (K % 128 == 0) return launch_cfg<T, 128, 128, 2, 2>(a, s);
@@ -564,14 +597,37 @@ void fill_res(ResDesc& r, const void* res, int mode, int res_C, int dN, int dH, 
 
 }  // namespace
 
+static void fill_ep(IgemmArgs& a, const rn_conv_epilogue* ep, int tile_base) {
+  a.stats = ep ? ep->partial : nullptr;
+  a.bn_x = ep ? ep->bn_x : nullptr;
+  a.bn_mask = ep ? ep->bn_mask : nullptr;
+  a.bn_coef = ep ? ep->bn_coef : nullptr;
+  a.gscale = ep ? ep->gscale : 1.f;
+  a.tile_base = tile_base;
+}
+
+extern "C" int rn_conv_stats_rows(const rn_conv_geom* g, int is_dgrad) {
+  if (!g) return 0;
+  if (!is_dgrad) return cdiv((long)g->N * g->P * g->Q, RN_CONV_STATS_ROWS);
+  int rows = 0;
+  for (int pa = 0; pa < g->stride; ++pa)
+    for (int pb = 0; pb < g->stride; ++pb) {
+      const long pc = (g->H - pa + g->stride - 1) / g->stride, qc = (g->W - pb + g->stride - 1) / g->stride;
+      if (pc > 0 && qc > 0) rows += cdiv((long)g->N * pc * qc, RN_CONV_STATS_ROWS);
+    }
+  return rows;
+}
+
 extern "C" int rn_conv_fwd(const void* x, const void* w_fwd, void* y, const void* res, int res_mode, int res_C, int dtype,
-                           const rn_conv_geom* g, rn_stream s) {
+                           const rn_conv_geom* g, const rn_conv_epilogue* ep, rn_stream s) {
   if (int e = check_geom(g, dtype, "rn_conv_fwd")) return e;
   RN_CHECK_ARG(x && w_fwd && y, "rn_conv_fwd: null pointer");
   IgemmArgs a{};
   a.src = x; a.wt = w_fwd; a.dst = y;
   fill_res(a.res, res, res_mode, res_C, g->N, g->P, g->Q, g->K);
-  if ((g_rn_variant & 1) && g->R == 3 && g->S == 3 && g->stride == 1 && g->pad == 1) {      // LDS-resident patch kernel (opt-in) for CIFAR-sized maps
+  RN_CONV_CHECK_EP
+  fill_ep(a, ep, 0);
+  if ((g_rn_variant & 1) && !ep && g->R == 3 && g->S == 3 && g->stride == 1 && g->pad == 1) {      // LDS-resident patch kernel (opt-in) for CIFAR-sized maps
     const int e = rn_conv3x3_patch(x, w_fwd, y, a.res, 0, dtype, g->N, g->H, g->W, g->C, g->K, false, s);
     if (e >= 0) return e;
   }
@@ -593,12 +649,15 @@ extern "C" int rn_conv_fwd(const void* x, const void* w_fwd, void* y, const void
 }
 
 extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* res, int res_mode, int res_C, int flags,
-                             int dtype, const rn_conv_geom* g, rn_stream s) {
+                             int dtype, const rn_conv_geom* g, const rn_conv_epilogue* ep, rn_stream s) {
   if (int e = check_geom(g, dtype, "rn_conv_dgrad")) return e;
   RN_CHECK_ARG(dy && w_dgrad && dx, "rn_conv_dgrad: null pointer");
   const int st = g->stride;
   const int ce = dtype == RN_F32 ? 4 : 8;
-  if ((g_rn_variant & 1) && g->R == 3 && g->S == 3 && st == 1 && g->pad == 1) {
+  RN_CHECK_ARG(!ep || (ep->partial && ep->bn_x && ep->bn_coef), "rn_conv_dgrad: incomplete epilogue descriptor");
+  RN_CHECK_ARG(!ep || !(flags & RN_F_ACCUM), "rn_conv_dgrad: a fused BatchNorm-backward reduction needs the complete gradient (no RN_F_ACCUM)");
+  int tile_base = 0;
+  if ((g_rn_variant & 1) && !ep && g->R == 3 && g->S == 3 && st == 1 && g->pad == 1) {
     ResDesc rd;
     fill_res(rd, res, res_mode, res_C, g->N, g->H, g->W, g->C);
     const int e = rn_conv3x3_patch(dy, w_dgrad, dx, rd, (flags & RN_F_ACCUM) ? 1 : 0, dtype, g->N, g->H, g->W, g->K, g->C, true, s);
@@ -631,6 +690,8 @@ extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, cons
       a.cpt = g->K / ce;
       a.nk = cdiv((long)nt * a.cpt, CPR);
       a.accum = (flags & RN_F_ACCUM) ? 1 : 0;
+      fill_ep(a, ep, tile_base);
+      tile_base += cdiv(a.M, RN_CONV_STATS_ROWS);
       if (nt == 0 && a.accum && a.res.mode == RN_RES_NONE) continue;   // nothing to add to this class
       int e = dtype == RN_F32 ? launch_igemm<float>(a, as_stream(s)) : launch_igemm<bf16_t>(a, as_stream(s));
       if (e) return e;

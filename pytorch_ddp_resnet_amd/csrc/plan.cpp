@@ -125,7 +125,8 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
       return rn_pack_weights((const float*)B(0), B(1), B(2), dt, d[0], d[1], d[2], s);
     case RN_OP_CONV_FWD: {
       rn_conv_geom g = geom_of(o);
-      return rn_conv_fwd(B(0), B(1), B(2), B(3), d[11], d[12], dt, &g, s);
+      rn_conv_epilogue ep{(float*)B(4), nullptr, nullptr, nullptr, 1.f};
+      return rn_conv_fwd(B(0), B(1), B(2), B(3), d[11], d[12], dt, &g, o.buf[4] >= 0 ? &ep : nullptr, s);
     }
     case RN_OP_BN_STATS:
       return rn_bn_stats(B(0), (float*)B(1), d[2], dt, d[0], d[1], s);
@@ -154,7 +155,8 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
                              o.flags, o.fp[0], (double)d[6], s);
     case RN_OP_CONV_DGRAD: {
       rn_conv_geom g = geom_of(o);
-      return rn_conv_dgrad(B(0), B(1), B(2), B(3), d[11], d[12], o.flags, dt, &g, s);
+      rn_conv_epilogue ep{(float*)B(7), B(4), B(5), (const float*)B(6), o.fp[0]};
+      return rn_conv_dgrad(B(0), B(1), B(2), B(3), d[11], d[12], o.flags & ~RN_F_RELU, dt, &g, o.buf[7] >= 0 ? &ep : nullptr, s);
     }
     case RN_OP_CONV_WGRAD: {
       rn_conv_geom g = geom_of(o);

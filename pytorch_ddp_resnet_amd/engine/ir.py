@@ -21,12 +21,13 @@ OP_NAMES = {v: k for k, v in list(globals().items()) if k.startswith('OP_') and 
 F_RELU, F_TRAIN, F_ACCUM, F_WRITE_G, F_NEED_DGRAD_PACK, F_SKIP_FWD_PACK, F_NO_DX = (1 << i for i in range(7))
 
 OP_NBUF, OP_NDIM = 8, 20
+CONV_STATS_ROWS = 128      # RN_CONV_STATS_ROWS: output pixels per partial-sum row of a fused conv epilogue
 
 # buf[] / dim[] / fp[] meaning per kind (geom = N,H,W,C,P,Q,K,R,S,stride,pad in dim[0:11])
 OP_FIELDS = {
     OP_STEM_FWD:        ('x w bias y', 'geom', ''),
     OP_PACK_W:          ('w w_fwd w_dgrad', 'K RS C', ''),
-    OP_CONV_FWD:        ('x w_fwd y res', 'geom res_mode res_C', ''),
+    OP_CONV_FWD:        ('x w_fwd y res stats', 'geom res_mode res_C', ''),
     OP_BN_STATS:        ('x partial', 'M C nblk', ''),
     OP_BN_FINALIZE:     ('partial gamma beta running_mean running_var nbt coef', 'nblk count C', 'eps momentum'),
     OP_BN_APPLY:        ('x coef res out', 'N H W C res_mode res_C', 'p'),
@@ -38,7 +39,7 @@ OP_FIELDS = {
     OP_BN_BWD_REDUCE:   ('dout x mask coef partial', 'M C nblk', 'gscale'),
     OP_BN_BWD_FINALIZE: ('partial dsum dgamma dbeta', 'nblk C', ''),
     OP_BN_BWD_APPLY:    ('dout x mask coef dsum add dx g_out', 'N H W C add_mode add_C count', 'gscale'),
-    OP_CONV_DGRAD:      ('dy w_dgrad dx res', 'geom res_mode res_C', ''),
+    OP_CONV_DGRAD:      ('dy w_dgrad dx res bn_x bn_mask bn_coef bn_partial', 'geom res_mode res_C', 'gscale'),
     OP_CONV_WGRAD:      ('x dy dw ws', 'geom', ''),
     OP_STEM_WGRAD:      ('x dy dw db ws', 'geom', ''),
     OP_DROPOUT_BWD:     ('dout out din', 'n_lo n_hi', 'p'),

@@ -122,6 +122,11 @@ class NumpyPlan:
             if d.get('res_mode', 0):
                 y = y + res_read(B('res'), d['res_mode'], d['N'], d['P'], d['Q'], d['K'])
             put('y', y)
+            if op.buf.get('stats', -1) >= 0:      # fused epilogue: per-tile partial sums (only their total is specified)
+                part = np.zeros_like(B('stats'))
+                ym = y.reshape(-1, d['K'])
+                part[0, 0], part[0, 1] = ym.sum(0), (ym * ym).sum(0)
+                put('stats', part)
         elif k == ir.OP_BN_STATS:
             x = B('x').reshape(d['M'], d['C'])
             nblk = d['nblk']
@@ -225,6 +230,15 @@ class NumpyPlan:
             if op.flags & ir.F_ACCUM:
                 dx = dx + B('dx')
             put('dx', dx)
+            if op.buf.get('bn_partial', -1) >= 0:   # fused BatchNorm-backward reduction of the layer that fed this conv
+                coef = B('bn_coef')
+                g = dx * op.fp.get('gscale', 1.0)
+                if op.buf.get('bn_mask', -1) >= 0:
+                    g = g * (B('bn_mask') > 0)
+                xhat = (B('bn_x') - coef[2]) * coef[3]
+                part = np.zeros_like(B('bn_partial'))
+                part[0, 0], part[0, 1] = g.reshape(-1, d['C']).sum(0), (g * xhat).reshape(-1, d['C']).sum(0)
+                put('bn_partial', part)
         elif k == ir.OP_CONV_WGRAD:
             dw = ops.conv2d_wgrad(B('x'), B('dy'), d['R'], d['S'], d['stride'], d['pad'])   # KCRS
             put('dw', np.transpose(dw, (0, 2, 3, 1)))

@@ -62,3 +62,19 @@ def test_cpu_forward_refuses():
     m = ResNet('c3,16,3,1,1 n a r1 ap32,1,0 fc16,10', False, False, 0.0)
     with pytest.raises(RuntimeError, match='no CPU'):
         m(torch.zeros(2, 3, 32, 32))
+
+
+def test_conv_stats_rows_matches_library():
+    """the lowering sizes the fused-epilogue partial buffers with the same formula the library uses."""
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('librn_hip.so not built')
+    import ctypes as C
+    from pytorch_ddp_resnet_amd.engine.lowering import conv_stats_rows
+    L = _lib.lib()
+    L.rn_conv_stats_rows.argtypes = [C.POINTER(_lib.RnConvGeom), C.c_int]
+    for (N, H, W, Cc, K, k, s, p) in [(128, 32, 32, 160, 160, 3, 1, 1), (3, 9, 7, 16, 32, 3, 2, 1), (2, 8, 8, 32, 64, 1, 2, 0), (5, 7, 7, 8, 8, 3, 1, 1)]:
+        P, Q = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        g = dict(N=N, H=H, W=W, C=Cc, P=P, Q=Q, K=K, R=k, S=k, stride=s, pad=p)
+        gs = _lib.geom_struct(g)
+        assert L.rn_conv_stats_rows(C.byref(gs), 0) == conv_stats_rows(g)
+        assert L.rn_conv_stats_rows(C.byref(gs), 1) == conv_stats_rows(g, True)

@@ -123,6 +123,40 @@ def _patch_case(h, g, fp32):
     assert h.max_rel(hip['dx'], ref['dx']) < TOL[fp32]
 
 
+@pytest.mark.parametrize('fp32', DT)
+@pytest.mark.parametrize('g', [(3, 8, 8, 160, 160, 3, 1, 1), (2, 9, 7, 24, 16, 3, 1, 1), (2, 8, 8, 16, 32, 3, 2, 1), (5, 16, 16, 32, 64, 3, 1, 1)])
+def test_conv_fused_epilogues(g, fp32):
+    """forward: per-channel (sum, sum^2) of the stored output; dgrad: the BatchNorm-backward sums of the layer that fed
+    the conv (mask + gscale + xhat), both reduced inside the conv epilogue.  Only the TOTAL over tile rows is specified."""
+    h = H()
+    from pytorch_ddp_resnet_amd.engine.lowering import conv_stats_rows
+    N, Hh, W, C, K, k, s, p = g
+    gm = h.geom(*g)
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, Hh, W, C)); wf = b.slot('wf', (K, k * k, C)); wd = b.slot('wd', (C, k * k, K))
+    y = b.slot('y', (N, gm['P'], gm['Q'], K)); dy = b.slot('dy', (N, gm['P'], gm['Q'], K)); dx = b.slot('dx', (N, Hh, W, C))
+    res = b.slot('res', (N, gm['P'], gm['Q'], K))
+    st = b.slot('st', (conv_stats_rows(gm), 2, K), 'f32'); dp = b.slot('dp', (conv_stats_rows(gm, True), 2, C), 'f32')
+    bx = b.slot('bx', (N, Hh, W, C)); bm = b.slot('bm', (N, Hh, W, C)); coef = b.slot('coef', (4, C), 'f32')
+    b.op(ir.OP_CONV_FWD, buf=dict(x=x, w_fwd=wf, y=y, res=res, stats=st), dim=dict(gm, res_mode=ir.RES_SAME, res_C=K))
+    b.op(ir.OP_CONV_DGRAD, buf=dict(dy=dy, w_dgrad=wd, dx=dx, res=-1, bn_x=bx, bn_mask=bm, bn_coef=coef, bn_partial=dp),
+         dim=dict(gm, res_mode=0, res_C=0), fp=dict(gscale=1 / 0.7))
+    plan = b.plan(fp32)
+    sc = (3.0 / (k * k * C)) ** 0.5
+    cf = np.stack([fill((C,), 71, 0.2, 1.0), fill((C,), 72, 0.1), fill((C,), 73, 0.3), fill((C,), 74, 0.2, 1.0)])
+    hip, ref = h.run_both(plan, dict(x=fill((N, Hh, W, C), 61), wf=fill((K, k * k, C), 62, sc), wd=fill((C, k * k, K), 63, sc),
+                                     res=fill((N, gm['P'], gm['Q'], K), 64), dy=fill((N, gm['P'], gm['Q'], K), 65),
+                                     bx=fill((N, Hh, W, C), 66), bm=fill((N, Hh, W, C), 67), coef=cf), fp32)
+    tol = TOL[fp32]
+    assert h.max_rel(hip['y'], ref['y']) < tol and h.max_rel(hip['dx'], ref['dx']) < tol
+    # sums of ~10^3..10^4 terms of mixed sign: compare against the sum of |terms| scale
+    ysc = np.abs(ref['y']).reshape(-1, K).sum(0).max()
+    assert np.abs(hip['st'].sum(0)[0] - ref['st'].sum(0)[0]).max() < tol * ysc
+    assert np.abs(hip['st'].sum(0)[1] - ref['st'].sum(0)[1]).max() < tol * (ref['y'] ** 2).reshape(-1, K).sum(0).max()
+    dsc = np.abs(ref['dx']).reshape(-1, C).sum(0).max() / 0.7
+    assert np.abs(hip['dp'].sum(0) - ref['dp'].sum(0)).max() < 3 * tol * dsc
+
+
 def test_wgrad_many_splits_bf16_exact_integers():
     """integer-valued operands make every product and partial sum exact in fp32: the transposed-read fragment
     layout (ds_read_b64_tr_b16 -> 16x16x32 MFMA) must reproduce the oracle bit for bit, asymmetric data."""

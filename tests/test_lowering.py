@@ -116,6 +116,21 @@ def test_plan_dropout_sites(preact):
     assert abs(frac - 0.7) < 0.05
 
 
+def test_plan_with_fused_dgrad_reduction(golden):
+    """the optional BN-backward reduction inside the dgrad epilogue gives the same gradients (kept off by default)."""
+    name = 'wrn_small'
+    cfg = MODELS[name]
+    g = golden('g4_' + name)
+    shapes, st, x, y, nesterov = model_inputs(g, cfg)
+    plan, npl, logits = run_plan(cfg, st, x, y, train=True, fuse_dgrad=True)
+    assert sum(op.kind == ir.OP_BN_BWD_REDUCE for op in plan.ops) < 3
+    assert any(op.kind == ir.OP_CONV_DGRAD and op.buf.get('bn_partial', -1) >= 0 for op in plan.ops)
+    grads = npl.grads()
+    pkeys = [k for k, _ in shapes if k.endswith('weight') or k.endswith('bias')]
+    norms = np.array([np.sqrt((grads[k] ** 2).sum()) for k in pkeys])
+    assert np.abs(norms - g['grad.norms']).max() < 1e-4 * g['grad.norms'].max()
+
+
 def test_plan_structure_wrn():
     plan = lower('c3,160,3,1,1 r4 r4 r4 n a ap8,1,0 fc640,10', True, True, 0.3, 128, 32, 32, fp32=False)
     kinds = [op.kind for op in plan.ops]

@@ -10,8 +10,8 @@ from pytorch_ddp_resnet_amd import _lib
 
 L = _lib.lib()
 vp = C.c_void_p
-L.rn_conv_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(_lib.RnConvGeom), vp]
-L.rn_conv_dgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_lib.RnConvGeom), vp]
+L.rn_conv_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(_lib.RnConvGeom), vp, vp]
+L.rn_conv_dgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_lib.RnConvGeom), vp, vp]
 L.rn_conv_wgrad.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(_lib.RnConvGeom), vp]
 L.rn_set_variant.argtypes = [C.c_int]
 
@@ -38,9 +38,9 @@ def run(which, iters, variants, dtype=torch.bfloat16):
 
             def call():
                 if which == 'fwd':
-                    _lib.check(L.rn_conv_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, 0, 0, rn, C.byref(g), st))
+                    _lib.check(L.rn_conv_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, 0, 0, rn, C.byref(g), None, st))
                 elif which == 'dgrad':
-                    _lib.check(L.rn_conv_dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, 0, 0, 0, rn, C.byref(g), st))
+                    _lib.check(L.rn_conv_dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, 0, 0, 0, rn, C.byref(g), None, st))
                 else:
                     _lib.check(L.rn_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsb, 0, rn, C.byref(g), st))
             for _ in range(3):
