@@ -19,7 +19,8 @@ int rn_conv3x3_patch(const void* src, const void* wt, void* dst, const ResDesc& 
                      bool flip, rn_stream s);
 
 int g_rn_variant = 0;   // tuning switch (tools/conv_bench.py): bit0 LDS-patch 3x3 kernel, bit1 register staging w/o fragment
-                        // double-buffering, bit2 256-row tile, bit3 register-staged kernel, bit4 4-stage 64-byte-row DMA ring
+                        // double-buffering, bit2 256-row 8-wave tile, bit3 register-staged kernel, bit4 4-stage 64-byte-row DMA ring,
+                        // bit6 DMA source-window timing probe, bit7 force wave-specialised kernel (bit8: 4 stages), bit9 never use it
 extern "C" void rn_set_variant(int v) { g_rn_variant = v; }
 
 #define RN_CONV_CHECK_EP RN_CHECK_ARG(!ep || (ep->partial && !ep->bn_x), "rn_conv_fwd: the forward epilogue takes `partial` only");
@@ -48,6 +49,7 @@ struct IgemmArgs {
   const float* bn_coef;
   float gscale;
   int tile_base;
+  unsigned probe_mask;     // timing probe (rn_set_variant bit6): AND-mask on DMA source offsets, 0xFFFFFFFF in production
 };
 
 template <typename T> struct Mfma;
@@ -73,7 +75,8 @@ template <> struct Mfma<bf16_t> {
 // their own over the tensor: lane sums over its 16 rows, the two half-waves are folded with a cross-lane add, the
 // WM waves of a column strip through LDS (`red`, the staging memory, free after the K loop), one row per M tile out.
 template <typename T, int BM, int BN, int WM, int WN, int TM, int TN>
-__device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int wave, int lane, float* red) {
+__device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int wave, int lane, float* red,
+                                      bool active = true, int nthreads = WM * WN * 64) {
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 31, lh = lane >> 5;
   const int pq = a.Pc * a.Qc;
@@ -88,6 +91,7 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
     const int k = n0 + wn * (BN / WN) + 32 * j + lr;
     if (bn_bwd && k < a.Kd) { mean[j] = a.bn_coef[2 * a.Kd + k]; invstd[j] = a.bn_coef[3 * a.Kd + k]; }
   }
+  if (active) {
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -133,12 +137,13 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
       }
     }
   }
+  }   // active
   if (!want_stats) return;
   // fold the two half-waves (rows 4*lh + ...), then the WM waves of this column strip
 #pragma unroll
   for (int j = 0; j < TN; ++j) { s0[j] += __shfl_xor(s0[j], 32, 64); s1[j] += __shfl_xor(s1[j], 32, 64); }
   __syncthreads();                                            // every wave is done reading the staging LDS
-  if (lh == 0) {
+  if (active && lh == 0) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int col = wn * (BN / WN) + 32 * j + lr;
@@ -147,8 +152,8 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
     }
   }
   __syncthreads();
-  const int tid = wave * 64 + lane;
-  for (int col = tid; col < BN; col += 256) {
+  const int tid = threadIdx.x;
+  for (int col = tid; col < BN; col += nthreads) {
     const int k = n0 + col;
     if (k >= a.Kd) continue;
     float t0 = 0.f, t1 = 0.f;
@@ -378,17 +383,18 @@ template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt v
 // `s_barrier`: `__syncthreads()` would make hipcc drain every DMA in flight.  All LDS lives in ONE __shared__ array (a
 // second __shared__ object makes hipcc wait vmcnt(0) before every ds_read; cdna_hip_programming.md section 5).
 template <typename T, int BM, int BN, int WM, int WN, int CPRT, int NSTG>
-__global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
+__global__ __launch_bounds__(WM * WN * 64) void igemm_dma_kernel(const IgemmArgs a) {
+  constexpr int NW = WM * WN;                          // waves per workgroup
   constexpr int ES = (int)sizeof(T);
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int RPI = 64 / CPRT;                       // rows per DMA instruction (1 KiB)
   constexpr int AIT = BM / RPI, BIT = BN / RPI;        // DMA instructions per tile
-  constexpr int AI = AIT / 4, BI = (BIT + 3) / 4;      // per wave (B padded to a multiple of 4 instructions)
+  constexpr int AI = AIT / NW, BI = (BIT + NW - 1) / NW;   // per wave (B padded to a multiple of NW instructions)
   constexpr int PER = AI + BI;
   constexpr int KS = CPRT / 2;
   constexpr int NST = CPRT == 8 ? 2 : 1;               // distinct logical chunk columns a lane serves
-  constexpr int STAGE = (BM + 4 * BI * RPI) * CPRT;    // uint4 per stage (B region padded)
-  static_assert(WM * WN == 4 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && AIT % 4 == 0 && BN % RPI == 0 && NSTG >= 2 && NSTG <= 4, "tile");
+  constexpr int STAGE = (BM + NW * BI * RPI) * CPRT;   // uint4 per stage (B region padded)
+  static_assert((NW == 4 || NW == 8) && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && AIT % NW == 0 && BN % RPI == 0 && NSTG >= 2 && NSTG <= 4, "tile");
   __shared__ uint4 smem[NSTG * STAGE + 8];
   int* taps = reinterpret_cast<int*>(&smem[NSTG * STAGE]);     // [0..9] source byte offset of tap, [16..25] weight byte offset
 
@@ -466,14 +472,14 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
     for (int i = 0; i < AI; ++i) {
       const int j = wave * AI + i;
       const int k = NST == 2 ? (j & 1) : 0;
-      const unsigned off = (kv[k] && ((amask[i] >> tp[k]) & 1)) ? abase[i] + so[k] : OOB;
+      const unsigned off = (kv[k] && ((amask[i] >> tp[k]) & 1)) ? ((abase[i] + so[k]) & a.probe_mask) : OOB;
       dma16(ra_desc, off, base + j * 1024);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int j = wave * BI + i;
       const int k = NST == 2 ? (j & 1) : 0;
-      const unsigned off = (kv[k] && bbase[i] != OOB) ? bbase[i] + wo[k] : OOB;
+      const unsigned off = (kv[k] && bbase[i] != OOB) ? ((bbase[i] + wo[k]) & a.probe_mask) : OOB;
       dma16(rb_desc, off, base + BM * CPRT * 16 + j * 1024);
     }
 #pragma unroll
@@ -541,10 +547,186 @@ __global__ __launch_bounds__(256) void igemm_dma_kernel(const IgemmArgs a) {
   igemm_epilogue<T, BM, BN, WM, WN, TM, TN>(a, acc, m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised variant: a workgroup = 4 CONSUMER waves (fragment ds_reads + MFMA, nothing else) + 4 LOADER waves
+// (LDS-DMA of the next K tile, nothing else), one barrier per K tile.  Issuing a 64-address buffer_load costs the
+// issuing wave ~100 cycles; in the homogeneous kernels every wave paid 9 of those per 20 MFMAs and both waves of a SIMD
+// ran in phase.  Here each SIMD hosts consumers and loaders, so the matrix pipe runs under the DMA issue
+// (MI355X_MICROARCH.md "Two waves per SIMD": matrix beside memory is the complementary pairing).
+// ---------------------------------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN, int CPRT, int NSTG>
+__global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
+  constexpr int ES = (int)sizeof(T);
+  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+  constexpr int RPI = 64 / CPRT;
+  constexpr int AIT = BM / RPI, BIT = BN / RPI;
+  constexpr int AI = AIT / 4, BI = (BIT + 3) / 4;      // per LOADER wave
+  constexpr int KS = CPRT / 2;
+  constexpr int NST = CPRT == 8 ? 2 : 1;
+  constexpr int STAGE = (BM + 4 * BI * RPI) * CPRT;
+  constexpr int PER = AI + BI;                         // DMA instructions per loader wave per tile
+  static_assert(WM * WN == 4 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && AIT % 4 == 0 && BN % RPI == 0, "tile");
+  __shared__ uint4 smem[NSTG * STAGE + 8];
+  int* taps = reinterpret_cast<int*>(&smem[NSTG * STAGE]);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 4;
+  const int nmt = (a.M + BM - 1) / BM;
+  const int mt = blockIdx.x % nmt, ntile = blockIdx.x / nmt;
+  const int m0 = mt * BM, n0 = ntile * BN;
+  const int pq = a.Pc * a.Qc;
+
+  if (tid <= MAX_TAPS) {
+    int t = tid < a.nt ? tid : 0;
+    taps[tid] = tid < a.nt ? (a.dh[t] * a.Ws + a.dw[t]) * a.Cs * ES : 0;
+    taps[16 + tid] = tid < a.nt ? a.widx[t] * a.Cs * ES : 0;
+  }
+  __syncthreads();
+
+  f32x16 acc[TM][TN];
+  if (loader) {
+    const int lw = wave - 4;
+    const int n_first = m0 / pq;
+    const size_t img_bytes = (size_t)a.Hs * a.Ws * a.Cs * ES;
+    const v4i32 ra_desc = make_desc(reinterpret_cast<const char*>(a.src) + (size_t)n_first * img_bytes, (size_t)(a.N - n_first) * img_bytes);
+    const v4i32 rb_desc = make_desc(a.wt, (size_t)a.Kd * a.wrs * a.Cs * ES);
+    const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);
+    const int lrow = lane / CPRT, p = lane % CPRT;
+    unsigned abase[AI], amask[AI], bbase[BI];
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int m = m0 + RPI * (lw * AI + i) + lrow;
+      amask[i] = 0; abase[i] = 0;
+      if (m < a.M) {
+        int n = m / pq, rem = m - n * pq;
+        int pp = rem / a.Qc, q = rem - pp * a.Qc;
+        int hb = pp * a.ss, wb = q * a.ss;
+        abase[i] = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES);
+        unsigned mk = 0;
+        for (int t = 0; t < a.nt; ++t) {
+          int h = hb + a.dh[t], w = wb + a.dw[t];
+          if ((unsigned)h < (unsigned)a.Hs && (unsigned)w < (unsigned)a.Ws) mk |= 1u << t;
+        }
+        amask[i] = mk;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int rn = RPI * (lw * BI + i) + lrow;
+      const int k = n0 + rn;
+      bbase[i] = (rn < BN && k < a.Kd) ? (unsigned)((size_t)k * a.wrs * a.Cs * ES) : OOB;
+    }
+    int tapk[NST], cck[NST];
+#pragma unroll
+    for (int k = 0; k < NST; ++k) {
+      const int sw = CPRT == 8 ? (((lane >> 4) + 4 * k) & 7) : ((lane >> 4) & 3);
+      cck[k] = p ^ sw;
+      tapk[k] = 0;
+      while (cck[k] >= a.cpt) { cck[k] -= a.cpt; ++tapk[k]; }
+    }
+    auto dma_tile = [&](int stg) {
+      unsigned so[NST], wo[NST];
+      bool kv[NST];
+      int tp[NST];
+#pragma unroll
+      for (int k = 0; k < NST; ++k) {
+        kv[k] = tapk[k] < a.nt;
+        tp[k] = kv[k] ? tapk[k] : 0;
+        so[k] = (unsigned)(taps[tp[k]] + cck[k] * 16);
+        wo[k] = (unsigned)(taps[16 + tp[k]] + cck[k] * 16);
+      }
+      const unsigned base = lds0 + (unsigned)(stg * STAGE * 16);
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        const int j = lw * AI + i;
+        const int k = NST == 2 ? (j & 1) : 0;
+        dma16(ra_desc, (kv[k] && ((amask[i] >> tp[k]) & 1)) ? abase[i] + so[k] : OOB, base + j * 1024);
+      }
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        const int j = lw * BI + i;
+        const int k = NST == 2 ? (j & 1) : 0;
+        dma16(rb_desc, (kv[k] && bbase[i] != OOB) ? bbase[i] + wo[k] : OOB, base + BM * CPRT * 16 + j * 1024);
+      }
+#pragma unroll
+      for (int k = 0; k < NST; ++k) {
+        cck[k] += CPRT;
+        while (cck[k] >= a.cpt) { cck[k] -= a.cpt; ++tapk[k]; }
+      }
+    };
+    // ring of NSTG stages: tiles it+1 .. it+NSTG-1 are in flight while the consumers multiply tile it
+#pragma unroll
+    for (int t = 0; t < NSTG - 1; ++t)
+      if (t < a.nk) dma_tile(t);
+    {
+      const int behind = min(a.nk, NSTG - 1) - 1;
+      if (behind >= 2) wait_vmcnt<2 * PER>(); else if (behind == 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    int wstg = NSTG - 1;
+    for (int it = 0; it < a.nk; ++it) {
+      if (it + NSTG - 1 < a.nk) dma_tile(wstg);            // the slot the consumers finished with in iteration it-1
+      if (++wstg == NSTG) wstg = 0;
+      const int later = min(a.nk - 2 - it, NSTG - 2);      // DMA groups issued after tile it+1
+      if (later >= 2) wait_vmcnt<2 * PER>(); else if (later == 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    const int wm = wave / WN, wn = wave % WN;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int arow0 = wm * (BM / WM) + lr, brow0 = wn * (BN / WN) + lr;
+    __builtin_amdgcn_s_barrier();                        // tile 0 landed
+    int rstg = 0;
+    for (int it = 0; it < a.nk; ++it) {
+      const uint4* cur_s = &smem[rstg * STAGE];
+      if (++rstg == NSTG) rstg = 0;
+      uint4 fa[2][TM], fb[2][TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[0][i] = cur_s[swz_t<CPRT>(arow0 + 32 * i, lh)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[0][j] = cur_s[BM * CPRT + swz_t<CPRT>(brow0 + 32 * j, lh)];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < KS) {
+          const int ch = 2 * (ks + 1) + lh;
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[nxt][i] = cur_s[swz_t<CPRT>(arow0 + 32 * i, ch)];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[nxt][j] = cur_s[BM * CPRT + swz_t<CPRT>(brow0 + 32 * j, ch)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur][i], fb[cur][j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN>(a, acc, m0, n0, loader ? 0 : wave, lane, reinterpret_cast<float*>(&smem[0]), !loader, 512);
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   int nmt = cdiv(a.M, BM), nnt = cdiv(a.Kd, BN);
-  if (!(g_rn_variant & (2 | 8 | 16))) {          // shipped configuration: LDS-DMA staging, 128-byte K rows, 2 LDS stages
+  // shipped dispatch: when the grid leaves at most one workgroup per CU (256 CUs), the wave-specialised kernel (4 consumer +
+  // 4 loader waves, 3-stage DMA ring) keeps the matrix pipe fed (+21 % measured on WRN-28-10's 8x8 stage); with two or
+  // more workgroups per CU the homogeneous 4-wave DMA kernel at two workgroups per CU is faster (measured).
+  const bool one_per_cu = nmt * nnt <= 256;
+  if ((g_rn_variant & 128) || (one_per_cu && !(g_rn_variant & (2 | 8 | 16 | 512)))) {
+    if (g_rn_variant & 256) hipLaunchKernelGGL((igemm_ws_kernel<T, BM, BN, WM, WN, 8, 4>), dim3(nmt * nnt), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((igemm_ws_kernel<T, BM, BN, WM, WN, 8, 3>), dim3(nmt * nnt), dim3(512), 0, s, a);
+  } else if (!(g_rn_variant & (2 | 8 | 16))) {          // LDS-DMA staging, 128-byte K rows, 2 LDS stages
     hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, 8, 2>), dim3(nmt * nnt), dim3(256), 0, s, a);
   } else if (g_rn_variant & 16) {
     IgemmArgs b = a;
@@ -561,7 +743,12 @@ template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   const int K = a.Kd;
   // column tile: the widest of {160,128,96,64,32} that wastes no 32-column MFMA tile
   if (K % 160 == 0) {
-    if ((g_rn_variant & 4) && !a.stats && a.M >= 256 * 256) return launch_cfg<T, 256, 160, 4, 1>(a, s);     // experiment: 64x160 wave tiles
+    if ((g_rn_variant & 4) && cdiv(a.M, 256) * (K / 160) >= 256) {      // experiment: 256x160 tile shared by 8 waves
+      int nmt = cdiv(a.M, 256), nnt = K / 160;
+      hipLaunchKernelGGL((igemm_dma_kernel<T, 256, 160, 8, 1, 8, 2>), dim3(nmt * nnt), dim3(512), 0, s, a);
+      RN_CHECK_LAUNCH("igemm256");
+      return 0;
+    }
     return launch_cfg<T, 128, 160, 4, 1>(a, s);
   }
   if (K % 128 == 0) return launch_cfg<T, 128, 128, 2, 2>(a, s);
@@ -604,6 +791,7 @@ static void fill_ep(IgemmArgs& a, const rn_conv_epilogue* ep, int tile_base) {
   a.bn_coef = ep ? ep->bn_coef : nullptr;
   a.gscale = ep ? ep->gscale : 1.f;
   a.tile_base = tile_base;
+  a.probe_mask = (g_rn_variant & 64) ? 0x0000FFF0u : 0xFFFFFFFFu;
 }
 
 extern "C" int rn_conv_stats_rows(const rn_conv_geom* g, int is_dgrad) {
