@@ -17,7 +17,7 @@ __global__ void pack_w_fwd_kernel(const float* __restrict__ w, T* __restrict__ w
 // w[k][rs][c] -> wd[c][rs][k]: one 32x32 (k, c) tile per workgroup and tap, transposed through LDS so both the read
 // (along c) and the write (along k) are coalesced
 template <typename T>
-__global__ __launch_bounds__(256) void pack_w_dgrad_kernel(const float* __restrict__ w, T* __restrict__ wd, int K, int RS, int C) {
+__global__ __launch_bounds__(256) void pack_w_dgrad_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int K, int RS, int C) {
   __shared__ float tile[32][33];
   const int kt = (K + 31) / 32, ct = (C + 31) / 32;
   int b = blockIdx.x;
@@ -28,7 +28,10 @@ __global__ __launch_bounds__(256) void pack_w_dgrad_kernel(const float* __restri
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int k = k0 + ty + 8 * j, c = c0 + tx;
-    tile[ty + 8 * j][tx] = (k < K && c < C) ? w[((size_t)k * RS + rs) * C + c] : 0.f;
+    const bool ok = k < K && c < C;
+    const float v = ok ? w[((size_t)k * RS + rs) * C + c] : 0.f;
+    tile[ty + 8 * j][tx] = v;
+    if (ok && wf) wf[((size_t)k * RS + rs) * C + c] = Elem<T>::from_f(v);      // forward copy from the same read
   }
   __syncthreads();
 #pragma unroll
@@ -273,15 +276,15 @@ extern "C" int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, 
   RN_CHECK_ARG(w_krsc && (w_fwd || w_dgrad) && K > 0 && RS > 0 && C > 0, "rn_pack_weights: bad argument");
   RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "rn_pack_weights: bad dtype");
   const long n = (long)K * RS * C;
-  if (w_fwd) {
+  if (w_fwd && !w_dgrad) {
     if (dtype == RN_F32) hipLaunchKernelGGL((pack_w_fwd_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), w_krsc, (float*)w_fwd, n);
     else hipLaunchKernelGGL((pack_w_fwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), w_krsc, (bf16_t*)w_fwd, n);
     RN_CHECK_LAUNCH("pack_weights_fwd");
   }
   if (w_dgrad) {
     const int grid = cdiv(K, 32) * cdiv(C, 32) * RS;
-    if (dtype == RN_F32) hipLaunchKernelGGL((pack_w_dgrad_kernel<float>), dim3(grid), dim3(256), 0, as_stream(s), w_krsc, (float*)w_dgrad, K, RS, C);
-    else hipLaunchKernelGGL((pack_w_dgrad_kernel<bf16_t>), dim3(grid), dim3(256), 0, as_stream(s), w_krsc, (bf16_t*)w_dgrad, K, RS, C);
+    if (dtype == RN_F32) hipLaunchKernelGGL((pack_w_dgrad_kernel<float>), dim3(grid), dim3(256), 0, as_stream(s), w_krsc, (float*)w_fwd, (float*)w_dgrad, K, RS, C);
+    else hipLaunchKernelGGL((pack_w_dgrad_kernel<bf16_t>), dim3(grid), dim3(256), 0, as_stream(s), w_krsc, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, K, RS, C);
   }
   RN_CHECK_LAUNCH("pack_weights");
   return 0;

@@ -113,10 +113,22 @@ __global__ __launch_bounds__(NT) void stem_wgrad_kernel(const StemArgs a) {
       }
       patch[i] = v;
     }
-    for (int i = threadIdx.x; i < WPIX * a.KT; i += NT) {
-      const int pl = i / a.KT, kc = i - pl * a.KT;
-      const int m = m0 + pl;
-      dyt[i] = (m < a.M && kc < kt) ? Elem<T>::to_f(dy[(size_t)m * a.K + k0 + kc]) : 0.f;
+    {   // dy tile: 16-byte chunks (CE channels) per thread, converted to fp32 on the way into LDS
+      constexpr int CE = Elem<T>::CE;
+      const int cpr = a.KT / CE;                                   // KT is a multiple of 8
+      for (int i = threadIdx.x; i < WPIX * cpr; i += NT) {
+        const int pl = i / cpr, ch = i - pl * cpr;
+        const int m = m0 + pl;
+        float* d = dyt + pl * a.KT + ch * CE;
+        if (m < a.M && ch * CE < kt) {
+          Chunk<T> c = load_chunk<T>(dy + (size_t)m * a.K + k0 + ch * CE);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) d[e] = Elem<T>::to_f(c.e[e]);
+        } else {
+#pragma unroll
+          for (int e = 0; e < CE; ++e) d[e] = 0.f;
+        }
+      }
     }
     __syncthreads();
     if (active) {
@@ -137,13 +149,20 @@ __global__ __launch_bounds__(NT) void stem_wgrad_kernel(const StemArgs a) {
   }
 }
 
-__global__ void stem_wgrad_reduce_kernel(const float* __restrict__ ws, int nblk, float* __restrict__ dw, float* __restrict__ db, int K, int RSC,
-                                         int accum) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+// sums the per-workgroup slabs in a fixed order: 16 outputs x 16 slab-lanes per workgroup, double accumulation
+__global__ __launch_bounds__(256) void stem_wgrad_reduce_kernel(const float* __restrict__ ws, int nblk, float* __restrict__ dw, float* __restrict__ db, int K,
+                                                                int RSC, int accum) {
+  __shared__ double red[16][17];
   const int n = K * (RSC + 1);
-  if (i >= n) return;
+  const int ol = threadIdx.x & 15, bl = threadIdx.x >> 4;
+  const int i = blockIdx.x * 16 + ol;
   double s = 0.0;
-  for (int b = 0; b < nblk; ++b) s += (double)ws[(size_t)b * n + i];
+  if (i < n)
+    for (int b = bl; b < nblk; b += 16) s += (double)ws[(size_t)b * n + i];
+  red[bl][ol] = s;
+  __syncthreads();
+  if (bl != 0 || i >= n) return;
+  for (int l = 1; l < 16; ++l) s += red[l][ol];
   const int k = i / (RSC + 1), col = i - k * (RSC + 1);
   float* dst = col == RSC ? db + k : dw + (size_t)k * RSC + col;
   *dst = accum ? *dst + (float)s : (float)s;
@@ -173,7 +192,7 @@ inline int stem_wgrad_kt(const rn_conv_geom* g) {
   const int ncol = g->R * g->S * g->C + 1;
   int kt = 128;
   while (kt > 8 && ((ncol + (NT / kt) - 1) / (NT / kt) > MAXTG || kt > g->K)) kt /= 2;
-  return kt;
+  return kt;          // power of two >= 8: whole 16-byte chunks of either dtype
 }
 
 int check_stem(const rn_conv_geom* g, int dtype, const char* who) {
@@ -234,7 +253,7 @@ extern "C" int rn_stem_conv_wgrad(const float* x_nchw, const void* dy, int dtype
   else hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t>), grid, dim3(NT), smem, as_stream(s), a);
   RN_CHECK_LAUNCH("stem_wgrad");
   const int n = g->K * (g->R * g->S * g->C + 1);
-  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(n, 256)), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), nblk, dw_krsc, dbias,
+  hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(n, 16)), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), nblk, dw_krsc, dbias,
                      g->K, g->R * g->S * g->C, accumulate);
   RN_CHECK_LAUNCH("stem_wgrad_reduce");
   return 0;
