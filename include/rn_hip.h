@@ -69,7 +69,8 @@ enum {
   RN_F_WRITE_G = 1 << 3,      /* bn_bwd_apply also writes g = masked dout (v1 shortcut)     */
   RN_F_NEED_DGRAD_PACK = 1 << 4,
   RN_F_SKIP_FWD_PACK = 1 << 5,
-  RN_F_NO_DX = 1 << 6         /* pool_fc_bwd etc.: input gradient not needed                */
+  RN_F_NO_DX = 1 << 6,        /* pool_fc_bwd etc.: input gradient not needed                */
+  RN_F_MASK_RECOMPUTE = 1 << 7 /* bn_bwd_*: mask = [x*scale+shift > 0] & dropout hash, recomputed instead of read (mask_src NULL) */
 };
 
 #define RN_OP_NBUF 8
@@ -169,14 +170,16 @@ int rn_bn_apply(const void* x, const float* coef, const void* res, void* out, in
                 int res_mode, int res_C, int flags, float drop_p, uint32_t site, uint64_t step_seed, rn_stream s);
 /* g = dout * gscale * [mask_src > 0] (mask only with RN_F_RELU; gscale = 1/(1-p)); partial [nblk][2][C] */
 int rn_bn_bwd_reduce(const void* dout, const void* x, const void* mask_src, const float* coef, float* partial,
-                     int nblk, int dtype, int64_t M, int C, int flags, float gscale, rn_stream s);
+                     int nblk, int dtype, int64_t M, int C, int flags, float gscale, float drop_p, uint32_t site,
+                     uint64_t step_seed, rn_stream s);
 /* partial -> dsum [2][C]; dgamma/dbeta written (or accumulated with RN_F_ACCUM) */
 int rn_bn_bwd_finalize(const float* partial, int nblk, float* dsum, float* dgamma, float* dbeta, int C, int flags,
                        rn_stream s);
 /* dx = scale*(g - dsum0/count - xhat*dsum1/count) [train] | scale*g [eval]  [+ add operand];  optional g_out */
 int rn_bn_bwd_apply(const void* dout, const void* x, const void* mask_src, const float* coef, const float* dsum,
                     const void* add, void* dx, void* g_out, int dtype, int N, int H, int W, int C, int add_mode,
-                    int add_C, int flags, float gscale, double count, rn_stream s);
+                    int add_C, int flags, float gscale, double count, float drop_p, uint32_t site, uint64_t step_seed,
+                    rn_stream s);
 
 int rn_dropout_fwd(const void* x, void* out, int dtype, int64_t n, float p, uint32_t site, uint64_t step_seed, rn_stream s);
 int rn_dropout_bwd(const void* dout, const void* out, void* din, int dtype, int64_t n, float p, rn_stream s);

@@ -17,7 +17,8 @@ constexpr int NT = 256;
 template <typename T, int MODE>
 __global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dout, const T* __restrict__ mask,
                                                        const float* __restrict__ coef, float* __restrict__ partial, int M, int C,
-                                                       int rows_per_blk, int use_mask, float gscale) {
+                                                       int rows_per_blk, int use_mask, float gscale, uint32_t key, uint32_t thr) {
+  // use_mask: 0 none, 1 read `mask`, 2 recompute [x*scale+shift > 0] (and the dropout keep hash when thr != 0)
   constexpr int CE = Elem<T>::CE;
   __shared__ float red[2][NT][CE + 1];
   const int CC = C / CE;
@@ -34,10 +35,13 @@ __global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, 
     for (int e = 0; e < CE; ++e) s0[e] = s1[e] = 0.f;
     const bool active = rl < lanes && cg < CC;
     if (active) {
-      float mean[CE], invstd[CE];
+      float mean[CE], invstd[CE], sc[CE], sh[CE];
       if (MODE == 1) {
 #pragma unroll
-        for (int e = 0; e < CE; ++e) { mean[e] = coef[2 * C + cg * CE + e]; invstd[e] = coef[3 * C + cg * CE + e]; }
+        for (int e = 0; e < CE; ++e) {
+          mean[e] = coef[2 * C + cg * CE + e]; invstd[e] = coef[3 * C + cg * CE + e];
+          sc[e] = coef[cg * CE + e]; sh[e] = coef[C + cg * CE + e];
+        }
       }
 #pragma unroll 4
       for (int r = r_begin + rl; r < r_end; r += lanes) {
@@ -49,12 +53,14 @@ __global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, 
         } else {
           Chunk<T> cd = load_chunk<T>(dout + off);
           Chunk<T> cm;
-          if (use_mask) cm = load_chunk<T>(mask + off);
+          if (use_mask == 1) cm = load_chunk<T>(mask + off);
 #pragma unroll
           for (int e = 0; e < CE; ++e) {
             float g = Elem<T>::to_f(cd.e[e]) * gscale;
-            if (use_mask && !(Elem<T>::to_f(cm.e[e]) > 0.f)) g = 0.f;
-            float xh = (Elem<T>::to_f(cx.e[e]) - mean[e]) * invstd[e];
+            const float xv = Elem<T>::to_f(cx.e[e]);
+            if (use_mask == 1 && !(Elem<T>::to_f(cm.e[e]) > 0.f)) g = 0.f;
+            if (use_mask == 2 && (!(fmaf(xv, sc[e], sh[e]) > 0.f) || (thr && !rn_keep(key, (uint32_t)(off + e), thr)))) g = 0.f;
+            float xh = (xv - mean[e]) * invstd[e];
             s0[e] += g; s1[e] += g * xh;
           }
         }
@@ -206,17 +212,18 @@ template <typename T>
 __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ mask,
                                                           const float* __restrict__ coef, const float* __restrict__ dsum, ResDesc add,
                                                           T* __restrict__ dx, T* __restrict__ g_out, int M, int H, int W, int C, int rows_per_blk,
-                                                          int use_mask, int train, float gscale, float inv_count) {
+                                                          int use_mask, int train, float gscale, float inv_count, uint32_t key, uint32_t thr) {
   constexpr int CE = Elem<T>::CE;
   const int CC = C / CE;
   for (int cbase = 0; cbase < CC; cbase += NT) {
     const Slab s = make_slab(CC, M, rows_per_blk, cbase);
     if (!s.active) continue;
     const int c0 = s.cg * CE;
-    float ka[CE], kb[CE], kc[CE];
+    float ka[CE], kb[CE], kc[CE], sc[CE], sh[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) {
       const float scale = coef[c0 + e];
+      sc[e] = scale; sh[e] = coef[C + c0 + e];
       ka[e] = scale * gscale;
       if (train) {
         const float mean = coef[2 * C + c0 + e], invstd = coef[3 * C + c0 + e];
@@ -233,14 +240,16 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
       Chunk<T> cd = load_chunk<T>(dout + off);
       Chunk<T> cx = load_chunk<T>(x + off);
       Chunk<T> cm;
-      if (use_mask) cm = load_chunk<T>(mask + off);
+      if (use_mask == 1) cm = load_chunk<T>(mask + off);
       float v[CE], g[CE];
 #pragma unroll
       for (int e = 0; e < CE; ++e) {
         float gg = Elem<T>::to_f(cd.e[e]);
-        if (use_mask && !(Elem<T>::to_f(cm.e[e]) > 0.f)) gg = 0.f;
+        const float xv = Elem<T>::to_f(cx.e[e]);
+        if (use_mask == 1 && !(Elem<T>::to_f(cm.e[e]) > 0.f)) gg = 0.f;
+        if (use_mask == 2 && (!(fmaf(xv, sc[e], sh[e]) > 0.f) || (thr && !rn_keep(key, (uint32_t)(off + e), thr)))) gg = 0.f;
         g[e] = gg * gscale;
-        v[e] = fmaf(ka[e], gg, fmaf(kb[e], Elem<T>::to_f(cx.e[e]), kc[e]));
+        v[e] = fmaf(ka[e], gg, fmaf(kb[e], xv, kc[e]));
       }
       if (add.mode == RN_RES_SAME) {
         Chunk<T> cr = load_chunk<T>(reinterpret_cast<const T*>(add.ptr) + off);
@@ -352,9 +361,9 @@ extern "C" int rn_bn_stats(const void* x, float* partial, int nblk, int dtype, i
   RN_CHECK_ARG(x && partial && nblk > 0 && M < (1L << 31), "rn_bn_stats: bad argument");
   const int rows = (int)((M + nblk - 1) / nblk);
   if (dtype == RN_F32)
-    hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const float*)x, nullptr, nullptr, nullptr, partial, (int)M, C, rows, 0, 1.f);
+    hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const float*)x, nullptr, nullptr, nullptr, partial, (int)M, C, rows, 0, 1.f, 0u, 0u);
   else
-    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const bf16_t*)x, nullptr, nullptr, nullptr, partial, (int)M, C, rows, 0, 1.f);
+    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const bf16_t*)x, nullptr, nullptr, nullptr, partial, (int)M, C, rows, 0, 1.f, 0u, 0u);
   RN_CHECK_LAUNCH("bn_stats");
   return 0;
 }
@@ -396,16 +405,20 @@ extern "C" int rn_bn_apply(const void* x, const float* coef, const void* res, vo
   return 0;
 }
 
+static inline int mask_mode(int flags) { return (flags & RN_F_MASK_RECOMPUTE) ? 2 : ((flags & RN_F_RELU) ? 1 : 0); }
+
 extern "C" int rn_bn_bwd_reduce(const void* dout, const void* x, const void* mask_src, const float* coef, float* partial, int nblk, int dtype,
-                                int64_t M, int C, int flags, float gscale, rn_stream s) {
+                                int64_t M, int C, int flags, float gscale, float drop_p, uint32_t site, uint64_t step_seed, rn_stream s) {
   if (int e = check_mc(dtype, M, C, "rn_bn_bwd_reduce")) return e;
-  const int use_mask = (flags & RN_F_RELU) ? 1 : 0;
-  RN_CHECK_ARG(dout && x && coef && partial && nblk > 0 && (!use_mask || mask_src) && M < (1L << 31), "rn_bn_bwd_reduce: bad argument");
+  const int use_mask = mask_mode(flags);
+  RN_CHECK_ARG(dout && x && coef && partial && nblk > 0 && (use_mask != 1 || mask_src) && M < (1L << 31), "rn_bn_bwd_reduce: bad argument");
+  RN_CHECK_ARG(drop_p == 0.f || (use_mask == 2 && M * C < (1L << 32)), "rn_bn_bwd_reduce: dropout recompute needs RN_F_MASK_RECOMPUTE and < 2^32 elements");
+  const uint32_t thr = drop_p > 0.f ? rn_drop_threshold(drop_p) : 0u, key = rn_drop_key(site, step_seed);
   const int rows = (int)((M + nblk - 1) / nblk);
   if (dtype == RN_F32)
-    hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), dim3(nblk), dim3(NT), 0, as_stream(s), (const float*)x, (const float*)dout, (const float*)mask_src, coef, partial, (int)M, C, rows, use_mask, gscale);
+    hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), dim3(nblk), dim3(NT), 0, as_stream(s), (const float*)x, (const float*)dout, (const float*)mask_src, coef, partial, (int)M, C, rows, use_mask, gscale, key, thr);
   else
-    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), dim3(nblk), dim3(NT), 0, as_stream(s), (const bf16_t*)x, (const bf16_t*)dout, (const bf16_t*)mask_src, coef, partial, (int)M, C, rows, use_mask, gscale);
+    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), dim3(nblk), dim3(NT), 0, as_stream(s), (const bf16_t*)x, (const bf16_t*)dout, (const bf16_t*)mask_src, coef, partial, (int)M, C, rows, use_mask, gscale, key, thr);
   RN_CHECK_LAUNCH("bn_bwd_reduce");
   return 0;
 }
@@ -419,11 +432,13 @@ extern "C" int rn_bn_bwd_finalize(const float* partial, int nblk, float* dsum, f
 
 extern "C" int rn_bn_bwd_apply(const void* dout, const void* x, const void* mask_src, const float* coef, const float* dsum, const void* add,
                                void* dx, void* g_out, int dtype, int N, int H, int W, int C, int add_mode, int add_C, int flags, float gscale,
-                               double count, rn_stream s) {
+                               double count, float drop_p, uint32_t site, uint64_t step_seed, rn_stream s) {
   const long M = (long)N * H * W;
   if (int e = check_mc(dtype, M, C, "rn_bn_bwd_apply")) return e;
-  const int use_mask = (flags & RN_F_RELU) ? 1 : 0, train = (flags & RN_F_TRAIN) ? 1 : 0;
-  RN_CHECK_ARG(dout && x && coef && dx && (!train || dsum) && (!use_mask || mask_src) && count > 0, "rn_bn_bwd_apply: bad argument");
+  const int use_mask = mask_mode(flags), train = (flags & RN_F_TRAIN) ? 1 : 0;
+  RN_CHECK_ARG(dout && x && coef && dx && (!train || dsum) && (use_mask != 1 || mask_src) && count > 0, "rn_bn_bwd_apply: bad argument");
+  RN_CHECK_ARG(drop_p == 0.f || (use_mask == 2 && M * C < (1L << 32)), "rn_bn_bwd_apply: dropout recompute needs RN_F_MASK_RECOMPUTE and < 2^32 elements");
+  const uint32_t thr = drop_p > 0.f ? rn_drop_threshold(drop_p) : 0u, key = rn_drop_key(site, step_seed);
   RN_CHECK_ARG(!(flags & RN_F_WRITE_G) || g_out, "rn_bn_bwd_apply: RN_F_WRITE_G without g_out");
   ResDesc r;
   make_res(r, add, add_mode, add_C, H, W, C);
@@ -436,9 +451,9 @@ extern "C" int rn_bn_bwd_apply(const void* dout, const void* x, const void* mask
   const int rows = slab_rows(M, C, ce);
   const int grid = cdiv(M, rows);
   if (dtype == RN_F32)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid), dim3(NT), 0, as_stream(s), (const float*)dout, (const float*)x, (const float*)mask_src, coef, dsum, r, (float*)dx, (float*)g, (int)M, H, W, C, rows, use_mask, train, gscale, inv_count);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid), dim3(NT), 0, as_stream(s), (const float*)dout, (const float*)x, (const float*)mask_src, coef, dsum, r, (float*)dx, (float*)g, (int)M, H, W, C, rows, use_mask, train, gscale, inv_count, key, thr);
   else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(grid), dim3(NT), 0, as_stream(s), (const bf16_t*)dout, (const bf16_t*)x, (const bf16_t*)mask_src, coef, dsum, r, (bf16_t*)dx, (bf16_t*)g, (int)M, H, W, C, rows, use_mask, train, gscale, inv_count);
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(grid), dim3(NT), 0, as_stream(s), (const bf16_t*)dout, (const bf16_t*)x, (const bf16_t*)mask_src, coef, dsum, r, (bf16_t*)dx, (bf16_t*)g, (int)M, H, W, C, rows, use_mask, train, gscale, inv_count, key, thr);
   RN_CHECK_LAUNCH("bn_bwd_apply");
   return 0;
 }

@@ -147,12 +147,12 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
     case RN_OP_MAXPOOL_BWD:
       return rn_maxpool_bwd(B(0), B(1), B(2), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], s);
     case RN_OP_BN_BWD_REDUCE:
-      return rn_bn_bwd_reduce(B(0), B(1), B(2), (const float*)B(3), (float*)B(4), d[2], dt, d[0], d[1], o.flags, o.fp[0], s);
+      return rn_bn_bwd_reduce(B(0), B(1), B(2), (const float*)B(3), (float*)B(4), d[2], dt, d[0], d[1], o.flags, o.fp[0], o.fp[1], o.seed, step_seed, s);
     case RN_OP_BN_BWD_FINALIZE:
       return rn_bn_bwd_finalize((const float*)B(0), d[0], (float*)B(1), (float*)B(2), (float*)B(3), d[1], o.flags, s);
     case RN_OP_BN_BWD_APPLY:
       return rn_bn_bwd_apply(B(0), B(1), B(2), (const float*)B(3), (const float*)B(4), B(5), B(6), B(7), dt, d[0], d[1], d[2], d[3], d[4], d[5],
-                             o.flags, o.fp[0], (double)d[6], s);
+                             o.flags, o.fp[0], (double)d[6], o.fp[1], o.seed, step_seed, s);
     case RN_OP_CONV_DGRAD: {
       rn_conv_geom g = geom_of(o);
       rn_conv_epilogue ep{(float*)B(7), B(4), B(5), (const float*)B(6), o.fp[0]};

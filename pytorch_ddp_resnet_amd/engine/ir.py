@@ -18,7 +18,7 @@ RES_NONE, RES_SAME, RES_DOWN2PAD, RES_UP2 = 0, 1, 2, 3
 
 OP_NAMES = {v: k for k, v in list(globals().items()) if k.startswith('OP_') and isinstance(v, int)}
 
-F_RELU, F_TRAIN, F_ACCUM, F_WRITE_G, F_NEED_DGRAD_PACK, F_SKIP_FWD_PACK, F_NO_DX = (1 << i for i in range(7))
+F_RELU, F_TRAIN, F_ACCUM, F_WRITE_G, F_NEED_DGRAD_PACK, F_SKIP_FWD_PACK, F_NO_DX, F_MASK_RECOMPUTE = (1 << i for i in range(8))
 
 OP_NBUF, OP_NDIM = 8, 20
 CONV_STATS_ROWS = 128      # RN_CONV_STATS_ROWS: output pixels per partial-sum row of a fused conv epilogue
@@ -36,9 +36,9 @@ OP_FIELDS = {
     OP_POOL_FC_FWD:     ('x w b feat logits', 'N HW C O', ''),
     OP_POOL_FC_BWD:     ('dlogits feat w dx dw db', 'N HW C O', ''),
     OP_MAXPOOL_BWD:     ('dy x dx', 'N H W C k stride pad', ''),
-    OP_BN_BWD_REDUCE:   ('dout x mask coef partial', 'M C nblk', 'gscale'),
+    OP_BN_BWD_REDUCE:   ('dout x mask coef partial', 'M C nblk', 'gscale p'),
     OP_BN_BWD_FINALIZE: ('partial dsum dgamma dbeta', 'nblk C', ''),
-    OP_BN_BWD_APPLY:    ('dout x mask coef dsum add dx g_out', 'N H W C add_mode add_C count', 'gscale'),
+    OP_BN_BWD_APPLY:    ('dout x mask coef dsum add dx g_out', 'N H W C add_mode add_C count', 'gscale p'),
     OP_CONV_DGRAD:      ('dy w_dgrad dx res bn_x bn_mask bn_coef bn_partial', 'geom res_mode res_C', 'gscale'),
     OP_CONV_WGRAD:      ('x dy dw ws', 'geom', ''),
     OP_STEM_WGRAD:      ('x dy dw db ws', 'geom', ''),

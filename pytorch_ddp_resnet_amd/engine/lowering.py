@@ -96,6 +96,7 @@ class Lowering:
         self._ws_need = []              # geometries of ops that share the workspace slot
         self._stats_of: Dict[int, Tuple[int, int]] = {}    # tensor slot -> (partial slot, rows) written by its producer's epilogue
         self._dpart_of: Dict[int, Tuple[int, int]] = {}    # gradient tensor slot -> BN-backward partial sums from the dgrad epilogue
+        self._site_of: Dict[int, Tuple[float, int, bool]] = {}   # BN_APPLY output slot -> (dropout p, site, mask recomputable)
         self.fuse = True                # BN batch statistics in the producing conv's epilogue (free: no extra operand reads)
         # BN-backward sums in the dgrad epilogue: correct and tested, but the epilogue's 2-byte-per-lane access pattern makes
         # its two extra operand reads cost more than the pass it removes (+1.9 ms vs -0.95 ms per WRN-28-10 step, measured)
@@ -237,6 +238,9 @@ class Lowering:
         self.fwd.append(Op(ir.OP_BN_APPLY, buf=dict(x=x.s, coef=coef, res=res.s if res else -1, out=out.s),
                            dim=dict(N=x.N, H=x.H, W=x.W, C=x.C, res_mode=res_mode, res_C=res.C if res else 0),
                            fp=dict(p=p), flags=ir.F_RELU if relu else 0, seed=site, note=name))
+        # recomputing the mask in the backward pays only without dropout (fma + compare); re-evaluating the dropout hash
+        # per element made bn_bwd_reduce 1.7x slower than reading the saved output (measured, WRN-28-10 p=0.3)
+        self._site_of[out.s] = (p, site, res is None and p == 0.0)
         return out, p
 
     def bn_bwd(self, ops, dout: T, x: T, mask: Optional[T], coef, pre, dx_name, p=0.0, add: Optional[T] = None,
@@ -246,13 +250,21 @@ class Lowering:
         gscale = 1.0 / (1.0 - p) if p > 0 else 1.0
         dsum = self.f32(pre + ':dsum', (2, C))
         fl = (ir.F_RELU if mask is not None else 0) | (ir.F_TRAIN if self.train else 0)
+        # the ReLU/dropout mask of out = drop(relu(x*scale+shift)) is a function of x, the coefficients and the dropout
+        # hash: recompute it instead of reading the saved output (one tensor read less in each backward pass)
+        site, mslot = 0, (mask.s if mask else -1)
+        if mask is not None and self._site_of.get(mask.s, (0, 0, False))[2]:
+            p_fwd, site, _ = self._site_of[mask.s]
+            assert abs(p_fwd - p) < 1e-12
+            fl |= ir.F_MASK_RECOMPUTE
+            mslot = -1
         if dout.s in self._dpart_of:                       # the two sums were reduced by the dgrad that produced dout
             part, nblk = self._dpart_of[dout.s]
         else:
             nblk = bn_partials(x.M, C)
             part = self.f32(pre + ':dpartial', (nblk, 2, C))
-            ops.append(Op(ir.OP_BN_BWD_REDUCE, buf=dict(dout=dout.s, x=x.s, mask=mask.s if mask else -1, coef=coef, partial=part),
-                          dim=dict(M=x.M, C=C, nblk=nblk), fp=dict(gscale=gscale), flags=fl, note=pre))
+            ops.append(Op(ir.OP_BN_BWD_REDUCE, buf=dict(dout=dout.s, x=x.s, mask=mslot, coef=coef, partial=part),
+                          dim=dict(M=x.M, C=C, nblk=nblk), fp=dict(gscale=gscale, p=p if mslot < 0 else 0.0), flags=fl, seed=site, note=pre))
         dg, db = self.grad(pre + '.weight', (C,)), self.grad(pre + '.bias', (C,))
         count = x.M
         ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=dsum, dgamma=dg, dbeta=db), dim=dict(nblk=nblk, C=C), note=pre))
@@ -264,10 +276,10 @@ class Lowering:
         dx = self.act(dx_name, x.N, x.H, x.W, C)
         g = self.act(write_g_name, x.N, x.H, x.W, C) if write_g_name else None
         ops.append(Op(ir.OP_BN_BWD_APPLY,
-                      buf=dict(dout=dout.s, x=x.s, mask=mask.s if mask else -1, coef=coef, dsum=dsum,
+                      buf=dict(dout=dout.s, x=x.s, mask=mslot, coef=coef, dsum=dsum,
                                add=add.s if add else -1, dx=dx.s, g_out=g.s if g else -1),
                       dim=dict(N=x.N, H=x.H, W=x.W, C=C, add_mode=add_mode, add_C=add.C if add else 0, count=count),
-                      fp=dict(gscale=gscale), flags=fl | (ir.F_WRITE_G if g else 0), note=pre))
+                      fp=dict(gscale=gscale, p=p if mslot < 0 else 0.0), flags=fl | (ir.F_WRITE_G if g else 0), seed=site, note=pre))
         return dx, g
 
     # ---- residual blocks --------------------------------------------------------------------------------

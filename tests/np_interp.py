@@ -190,10 +190,13 @@ class NumpyPlan:
         elif k in (ir.OP_BN_BWD_REDUCE, ir.OP_BN_BWD_APPLY):
             coef = B('coef')
             g = B('dout') * op.fp.get('gscale', 1.0)
-            if op.flags & ir.F_RELU:
+            if op.flags & ir.F_MASK_RECOMPUTE:      # mask = [x*scale+shift > 0] & dropout keep hash (not read from memory)
+                m = (B('x') * coef[0] + coef[1]) > 0
+                if op.fp.get('p', 0.0) > 0:
+                    m = m & keep_mask(m.size, op.fp['p'], op.seed, step_seed).reshape(m.shape)
+                g = g * m
+            elif op.flags & ir.F_RELU:
                 g = g * (B('mask') > 0)
-            elif op.fp.get('gscale', 1.0) != 1.0:
-                g = g * (B('mask') != 0)
             xhat = (B('x') - coef[2]) * coef[3]
             C = d['C']
             if k == ir.OP_BN_BWD_REDUCE:

@@ -241,6 +241,36 @@ def test_bn_forward_backward(C, M_shape, fp32):
 
 
 @pytest.mark.parametrize('fp32', DT)
+def test_bn_backward_recomputed_mask(fp32):
+    """RN_F_MASK_RECOMPUTE: the ReLU/dropout mask rebuilt from x, the coefficients and the dropout hash gives exactly
+    the sums and gradients of the variant that reads the saved output."""
+    h = H()
+    N, Hh, W, C, nblk = 3, 8, 8, 32, 4
+    M = N * Hh * W
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, Hh, W, C)); coef = b.slot('coef', (4, C), 'f32'); out = b.slot('out', (N, Hh, W, C)); dout = b.slot('dout', (N, Hh, W, C))
+    outs = {}
+    for tag, fl, mk in (('rd', ir.F_RELU | ir.F_TRAIN, out), ('rc', ir.F_RELU | ir.F_TRAIN | ir.F_MASK_RECOMPUTE, -1)):
+        part = b.slot('part_' + tag, (nblk, 2, C), 'f32'); dsum = b.slot('dsum_' + tag, (2, C), 'f32')
+        dg = b.slot('dg_' + tag, (C,), 'f32'); db = b.slot('db_' + tag, (C,), 'f32'); dx = b.slot('dx_' + tag, (N, Hh, W, C))
+        outs[tag] = (part, dsum, dg, db, dx)
+    b.op(ir.OP_BN_APPLY, buf=dict(x=x, coef=coef, res=-1, out=out), dim=dict(N=N, H=Hh, W=W, C=C, res_mode=0, res_C=0), fp=dict(p=0.3), flags=ir.F_RELU, seed=9)
+    for tag, fl, mk in (('rd', ir.F_RELU | ir.F_TRAIN, out), ('rc', ir.F_RELU | ir.F_TRAIN | ir.F_MASK_RECOMPUTE, -1)):
+        part, dsum, dg, db, dx = outs[tag]
+        p = 0.3 if mk == -1 else 0.0
+        b.op(ir.OP_BN_BWD_REDUCE, buf=dict(dout=dout, x=x, mask=mk, coef=coef, partial=part), dim=dict(M=M, C=C, nblk=nblk), fp=dict(gscale=1 / 0.7, p=p), flags=fl, seed=9)
+        b.op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=dsum, dgamma=dg, dbeta=db), dim=dict(nblk=nblk, C=C))
+        b.op(ir.OP_BN_BWD_APPLY, buf=dict(dout=dout, x=x, mask=mk, coef=coef, dsum=dsum, add=-1, dx=dx, g_out=-1),
+             dim=dict(N=N, H=Hh, W=W, C=C, add_mode=0, add_C=0, count=M), fp=dict(gscale=1 / 0.7, p=p), flags=fl, seed=9)
+    plan = b.plan(fp32)
+    cf = np.stack([fill((C,), 81, 0.3, 1.0), fill((C,), 82, 0.4), fill((C,), 83, 0.3), fill((C,), 84, 0.2, 1.0)])
+    hip, ref = h.run_both(plan, dict(x=fill((N, Hh, W, C), 85, 1.5), coef=cf, dout=fill((N, Hh, W, C), 86)), fp32, step_seed=55555555555)
+    for name in ('dsum', 'dg', 'db', 'dx'):
+        assert np.array_equal(hip[name + '_rd'], hip[name + '_rc']), name           # identical on the GPU, bit for bit
+        assert h.max_rel(hip[name + '_rc'], ref[name + '_rc']) < max(TOL[fp32], 1e-4), name
+
+
+@pytest.mark.parametrize('fp32', DT)
 def test_bn_eval_and_residual_modes(fp32):
     h = H()
     N, Hh, C = 2, 8, 32
