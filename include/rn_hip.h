@@ -58,7 +58,10 @@ enum {
   RN_OP_DROPOUT_BWD = 18,
   RN_OP_SOFTMAX_CE = 19,    /* metrics.py:10-29: mean CE loss, top-1/top-5 error counts, dlogits                             */
   RN_OP_ZERO = 20,          /* memset of a buffer slot (split-K / accumulation targets)                                       */
-  RN_OP_ADD_RES = 21        /* dst += res (mapped): gradient merge behind a standalone v1 dropout                             */
+  RN_OP_ADD_RES = 21,       /* dst += res (mapped): gradient merge behind a standalone v1 dropout                             */
+  RN_OP_IMG_TO_NHWC = 22,   /* NCHW fp32 image -> NHWC compute dtype, channels zero-padded to one 16-byte chunk (MFMA stem)    */
+  RN_OP_PACK_STEM_W = 23,   /* stem weights [K][RS][C] fp32 -> [K][RS][CP] compute dtype (padded)                              */
+  RN_OP_UNPACK_STEM_DW = 24 /* stem weight gradient [K][RS][CP] fp32 -> [K][RS][C] (drops the padding)                          */
 };
 
 /* flags */
@@ -129,6 +132,7 @@ typedef struct rn_conv_epilogue {
   const void* bn_mask;     /* NULL: no ReLU/dropout mask */
   const float* bn_coef;    /* [4][C] of that BatchNorm */
   float gscale;            /* 1/(1-p) of the dropout behind that BatchNorm, else 1 */
+  const float* bias;       /* forward only: per-output-channel bias (the stem Conv2d, resnet.py:69-75), or NULL */
 } rn_conv_epilogue;
 int rn_conv_stats_rows(const rn_conv_geom* g, int is_dgrad);
 
@@ -141,6 +145,13 @@ int rn_stem_conv_fwd(const float* x_nchw, const float* w_krsc, const float* bias
 int rn_stem_conv_wgrad(const float* x_nchw, const void* dy, int dtype, float* dw_krsc, float* dbias, void* ws,
                        int accumulate, const rn_conv_geom* g, rn_stream s);
 size_t rn_stem_wgrad_ws_bytes(const rn_conv_geom* g);
+
+/* MFMA route of the stem (kernel 7x7: GEMM-K = 147 pays on the matrix cores): the image and the weights are brought
+ * to NHWC with the 3 channels zero-padded to CP (8 bf16 / 4 fp32 = one 16-byte chunk), then rn_conv_fwd / rn_conv_wgrad run
+ * with C = CP; rn_unpack_stem_dw drops the padding of the weight gradient */
+int rn_img_to_nhwc(const float* x_nchw, void* out, int dtype, int N, int C, int H, int W, int CP, rn_stream s);
+int rn_pack_stem_w(const float* w_krsc, void* w_padded, int dtype, int K, int RS, int C, int CP, rn_stream s);
+int rn_unpack_stem_dw(const float* dw_padded, float* dw_krsc, int K, int RS, int C, int CP, int accumulate, rn_stream s);
 
 /* fp32 KRSC master -> w_fwd [K][R*S][C] and w_dgrad [C][R*S][K] in dtype (either may be NULL) */
 int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, int dtype, int K, int RS, int C, rn_stream s);
@@ -186,9 +197,11 @@ int rn_dropout_bwd(const void* dout, const void* out, void* din, int dtype, int6
 /* dst[n,h,w,c] += res (RN_RES_* mapping) */
 int rn_add_res(void* dst, const void* res, int dtype, int N, int H, int W, int C, int res_mode, int res_C, rn_stream s);
 
-int rn_maxpool_fwd(const void* x, void* y, int dtype, int N, int H, int W, int C, int k, int stride, int pad, rn_stream s);
-int rn_maxpool_bwd(const void* dy, const void* x, void* dx, int dtype, int N, int H, int W, int C, int k, int stride,
+/* argmax: one byte per output element (window position r*k+s of the first maximum), consumed by the backward */
+int rn_maxpool_fwd(const void* x, void* y, unsigned char* argmax, int dtype, int N, int H, int W, int C, int k, int stride,
                    int pad, rn_stream s);
+int rn_maxpool_bwd(const void* dy, const unsigned char* argmax, void* dx, int dtype, int N, int H, int W, int C, int k,
+                   int stride, int pad, rn_stream s);
 
 /* logits[n,o] = b[o] + sum_c W[o,c] * mean_{hw} x[n,hw,c];  feat: [N][C] fp32 scratch kept for backward */
 int rn_pool_fc_fwd(const void* x, const float* w, const float* b, float* feat, float* logits, int dtype, int N, int HW,

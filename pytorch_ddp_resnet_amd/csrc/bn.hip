@@ -87,8 +87,9 @@ __global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, 
   }
 }
 
-// reduces [nblk][2][C] partials in double: 16 channels x 16 slab-lanes per workgroup
-constexpr int FC = 16, FL = 16;
+// reduces [nblk][2][C] partials in double: 16 channels x 64 slab-lanes per workgroup (the fused conv epilogues write one
+// partial row per 128 output pixels: up to 1024 rows)
+constexpr int FC = 16, FL = 64;
 __device__ inline void reduce_partials(const float* __restrict__ partial, int nblk, int C, int c, int bl, double& s, double& ss, double (*red)[FL][FC]) {
   s = 0.0; ss = 0.0;
   if (c < C)

@@ -5,7 +5,6 @@
 #include <stdio.h>
 #include "../../include/rn_hip.h"
 
-#define RN_OP_ADD_RES 21
 
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;

@@ -23,11 +23,11 @@ int g_rn_variant = 0;   // tuning switch (tools/conv_bench.py): bit0 LDS-patch 3
                         // bit6 DMA source-window timing probe, bit7 force wave-specialised kernel (bit8: 4 stages), bit9 never use it
 extern "C" void rn_set_variant(int v) { g_rn_variant = v; }
 
-#define RN_CONV_CHECK_EP RN_CHECK_ARG(!ep || (ep->partial && !ep->bn_x), "rn_conv_fwd: the forward epilogue takes `partial` only");
+#define RN_CONV_CHECK_EP RN_CHECK_ARG(!ep || ((ep->partial || ep->bias) && !ep->bn_x), "rn_conv_fwd: the forward epilogue takes `partial` and/or `bias`");
 
 namespace {
 
-constexpr int MAX_TAPS = 9;
+constexpr int MAX_TAPS = 49;        // 7x7 stem
 constexpr int CPR = 8;  // 16-byte chunks per LDS row (128 bytes of K per row)
 
 struct IgemmArgs {
@@ -49,6 +49,7 @@ struct IgemmArgs {
   const float* bn_coef;
   float gscale;
   int tile_base;
+  const float* bias;       // per-output-channel bias added in the epilogue (stem convolution), or NULL
   unsigned probe_mask;     // timing probe (rn_set_variant bit6): AND-mask on DMA source offsets, 0xFFFFFFFF in production
 };
 
@@ -116,6 +117,7 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
         const int k = n0 + wn * (BN / WN) + 32 * j + lr;
         if (k >= a.Kd) continue;
         float v = acc[i][j][r];
+        if (a.bias) v += a.bias[k];
         const size_t off = pix * a.Kd + k;
         if (a.res.mode != RN_RES_NONE) {
           if (dense) v += Elem<T>::to_f(reinterpret_cast<const T*>(a.res.ptr)[off]);
@@ -216,7 +218,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
   // ---- per-thread staging roles: chunk column c of rows r0 + RPP*i ----
   const int c = tid % CPR, r0 = tid / CPR;
-  unsigned abase[AR], amask[AR];
+  unsigned abase[AR];
+  unsigned long long amask[AR];
 #pragma unroll
   for (int i = 0; i < AR; ++i) {
     int m = m0 + r0 + RPP * i;
@@ -227,10 +230,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
       int p = rem / a.Qc, q = rem - p * a.Qc;
       int hb = p * a.ss, wb = q * a.ss;
       abase[i] = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES);   // may wrap for border taps: masked
-      unsigned mk = 0;
+      unsigned long long mk = 0;
       for (int t = 0; t < a.nt; ++t) {
         int h = hb + a.dh[t], w = wb + a.dw[t];
-        if ((unsigned)h < (unsigned)a.Hs && (unsigned)w < (unsigned)a.Ws) mk |= 1u << t;
+        if ((unsigned)h < (unsigned)a.Hs && (unsigned)w < (unsigned)a.Ws) mk |= 1ull << t;
       }
       amask[i] = mk;
     }
@@ -395,8 +398,8 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_dma_kernel(const IgemmArgs
   constexpr int NST = CPRT == 8 ? 2 : 1;               // distinct logical chunk columns a lane serves
   constexpr int STAGE = (BM + NW * BI * RPI) * CPRT;   // uint4 per stage (B region padded)
   static_assert((NW == 4 || NW == 8) && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && AIT % NW == 0 && BN % RPI == 0 && NSTG >= 2 && NSTG <= 4, "tile");
-  __shared__ uint4 smem[NSTG * STAGE + 8];
-  int* taps = reinterpret_cast<int*>(&smem[NSTG * STAGE]);     // [0..9] source byte offset of tap, [16..25] weight byte offset
+  __shared__ uint4 smem[NSTG * STAGE + 32];
+  int* taps = reinterpret_cast<int*>(&smem[NSTG * STAGE]);     // [0..48] source byte offset of tap, [64..112] weight byte offset
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: feeds M0 / SGPR operands
@@ -416,12 +419,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_dma_kernel(const IgemmArgs
   if (tid <= MAX_TAPS) {
     int t = tid < a.nt ? tid : 0;
     taps[tid] = tid < a.nt ? (a.dh[t] * a.Ws + a.dw[t]) * a.Cs * ES : 0;
-    taps[16 + tid] = tid < a.nt ? a.widx[t] * a.Cs * ES : 0;
+    taps[64 + tid] = tid < a.nt ? a.widx[t] * a.Cs * ES : 0;
   }
 
   // ---- per-lane DMA roles ----
   const int lrow = lane / CPRT, p = lane % CPRT;
-  unsigned abase[AI], amask[AI];
+  unsigned abase[AI];
+  unsigned long long amask[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int m = m0 + RPI * (wave * AI + i) + lrow;
@@ -431,10 +435,10 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_dma_kernel(const IgemmArgs
       int pp = rem / a.Qc, q = rem - pp * a.Qc;
       int hb = pp * a.ss, wb = q * a.ss;
       abase[i] = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES);
-      unsigned mk = 0;
+      unsigned long long mk = 0;
       for (int t = 0; t < a.nt; ++t) {
         int h = hb + a.dh[t], w = wb + a.dw[t];
-        if ((unsigned)h < (unsigned)a.Hs && (unsigned)w < (unsigned)a.Ws) mk |= 1u << t;
+        if ((unsigned)h < (unsigned)a.Hs && (unsigned)w < (unsigned)a.Ws) mk |= 1ull << t;
       }
       amask[i] = mk;
     }
@@ -465,7 +469,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_dma_kernel(const IgemmArgs
       kv[k] = tapk[k] < a.nt;
       tp[k] = kv[k] ? tapk[k] : 0;
       so[k] = (unsigned)(taps[tp[k]] + cck[k] * 16);
-      wo[k] = (unsigned)(taps[16 + tp[k]] + cck[k] * 16);
+      wo[k] = (unsigned)(taps[64 + tp[k]] + cck[k] * 16);
     }
     const unsigned base = lds0 + (unsigned)(stg * STAGE * 16);
 #pragma unroll
@@ -566,7 +570,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
   constexpr int STAGE = (BM + 4 * BI * RPI) * CPRT;
   constexpr int PER = AI + BI;                         // DMA instructions per loader wave per tile
   static_assert(WM * WN == 4 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && AIT % 4 == 0 && BN % RPI == 0, "tile");
-  __shared__ uint4 smem[NSTG * STAGE + 8];
+  __shared__ uint4 smem[NSTG * STAGE + 32];
   int* taps = reinterpret_cast<int*>(&smem[NSTG * STAGE]);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -580,7 +584,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
   if (tid <= MAX_TAPS) {
     int t = tid < a.nt ? tid : 0;
     taps[tid] = tid < a.nt ? (a.dh[t] * a.Ws + a.dw[t]) * a.Cs * ES : 0;
-    taps[16 + tid] = tid < a.nt ? a.widx[t] * a.Cs * ES : 0;
+    taps[64 + tid] = tid < a.nt ? a.widx[t] * a.Cs * ES : 0;
   }
   __syncthreads();
 
@@ -593,7 +597,8 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
     const v4i32 rb_desc = make_desc(a.wt, (size_t)a.Kd * a.wrs * a.Cs * ES);
     const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);
     const int lrow = lane / CPRT, p = lane % CPRT;
-    unsigned abase[AI], amask[AI], bbase[BI];
+    unsigned abase[AI], bbase[BI];
+    unsigned long long amask[AI];
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int m = m0 + RPI * (lw * AI + i) + lrow;
@@ -603,10 +608,10 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
         int pp = rem / a.Qc, q = rem - pp * a.Qc;
         int hb = pp * a.ss, wb = q * a.ss;
         abase[i] = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES);
-        unsigned mk = 0;
+        unsigned long long mk = 0;
         for (int t = 0; t < a.nt; ++t) {
           int h = hb + a.dh[t], w = wb + a.dw[t];
-          if ((unsigned)h < (unsigned)a.Hs && (unsigned)w < (unsigned)a.Ws) mk |= 1u << t;
+          if ((unsigned)h < (unsigned)a.Hs && (unsigned)w < (unsigned)a.Ws) mk |= 1ull << t;
         }
         amask[i] = mk;
       }
@@ -634,7 +639,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
         kv[k] = tapk[k] < a.nt;
         tp[k] = kv[k] ? tapk[k] : 0;
         so[k] = (unsigned)(taps[tp[k]] + cck[k] * 16);
-        wo[k] = (unsigned)(taps[16 + tp[k]] + cck[k] * 16);
+        wo[k] = (unsigned)(taps[64 + tp[k]] + cck[k] * 16);
       }
       const unsigned base = lds0 + (unsigned)(stg * STAGE * 16);
 #pragma unroll
@@ -791,6 +796,7 @@ static void fill_ep(IgemmArgs& a, const rn_conv_epilogue* ep, int tile_base) {
   a.bn_coef = ep ? ep->bn_coef : nullptr;
   a.gscale = ep ? ep->gscale : 1.f;
   a.tile_base = tile_base;
+  a.bias = ep ? ep->bias : nullptr;
   a.probe_mask = (g_rn_variant & 64) ? 0x0000FFF0u : 0xFFFFFFFFu;
 }
 
@@ -842,7 +848,7 @@ extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, cons
   RN_CHECK_ARG(dy && w_dgrad && dx, "rn_conv_dgrad: null pointer");
   const int st = g->stride;
   const int ce = dtype == RN_F32 ? 4 : 8;
-  RN_CHECK_ARG(!ep || (ep->partial && ep->bn_x && ep->bn_coef), "rn_conv_dgrad: incomplete epilogue descriptor");
+  RN_CHECK_ARG(!ep || (ep->partial && ep->bn_x && ep->bn_coef && !ep->bias), "rn_conv_dgrad: incomplete epilogue descriptor");
   RN_CHECK_ARG(!ep || !(flags & RN_F_ACCUM), "rn_conv_dgrad: a fused BatchNorm-backward reduction needs the complete gradient (no RN_F_ACCUM)");
   int tile_base = 0;
   if ((g_rn_variant & 1) && !ep && g->R == 3 && g->S == 3 && st == 1 && g->pad == 1) {

@@ -13,7 +13,7 @@
 
 namespace {
 
-constexpr int MAX_TAPS = 9;
+constexpr int MAX_TAPS = 49;        // 7x7 stem
 template <typename T> struct Bp { static constexpr int v = sizeof(T) == 4 ? 16 : 64; };  // pixels per LDS tile (bf16: two 32-pixel MFMA k-steps)
 
 struct WgradArgs {

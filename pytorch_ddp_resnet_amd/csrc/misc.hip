@@ -41,10 +41,42 @@ __global__ __launch_bounds__(256) void pack_w_dgrad_kernel(const float* __restri
   }
 }
 
-// ---- MaxPool2d(k, s, p), NHWC, -inf padding; backward recomputes the argmax (first maximum in (r,s) scan order wins) ---
+// ---- MFMA stem route: image / weights / weight-gradient between the reference layouts and the padded NHWC operands ----
 template <typename T>
-__global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int P, int Q, int k,
-                                                         int stride, int pad) {
+__global__ __launch_bounds__(NT) void img_to_nhwc_kernel(const float* __restrict__ x, T* __restrict__ out, int N, int C, int H, int W, int CP) {
+  const long n = (long)N * H * W;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const long hw = (long)H * W;
+    const long nn = i / hw, r = i - nn * hw;
+    T* o = out + i * CP;
+    for (int c = 0; c < CP; ++c) o[c] = Elem<T>::from_f(c < C ? x[(nn * C + c) * hw + r] : 0.f);
+  }
+}
+
+template <typename T>
+__global__ void pack_stem_w_kernel(const float* __restrict__ w, T* __restrict__ wp, long n_rows, int C, int CP) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows * CP; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / CP;
+    const int c = (int)(i - row * CP);
+    wp[i] = Elem<T>::from_f(c < C ? w[row * C + c] : 0.f);
+  }
+}
+
+__global__ void unpack_stem_dw_kernel(const float* __restrict__ dwp, float* __restrict__ dw, long n_rows, int C, int CP, int accum) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n_rows * C; i += (long)gridDim.x * blockDim.x) {
+    const long row = i / C;
+    const int c = (int)(i - row * C);
+    const float v = dwp[row * CP + c];
+    dw[i] = accum ? dw[i] + v : v;
+  }
+}
+
+// ---- MaxPool2d(k, s, p), NHWC, -inf padding.  The forward also stores the argmax (window position r*k+s, first maximum
+// in scan order wins -- torch's rule) as one byte per output element; the backward is then a gather: an input element
+// sums dy of the (at most ceil(k/s)^2) windows whose stored argmax points at it.  No atomics, no zero-fill pass.
+template <typename T>
+__global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, unsigned char* __restrict__ idx, int N, int H, int W,
+                                                         int C, int P, int Q, int k, int stride, int pad) {
   constexpr int CE = Elem<T>::CE;
   const int CC = C / CE;
   const long n = (long)N * P * Q * CC;
@@ -55,8 +87,9 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x
     const int p = (int)(pix % P);
     const int nn = (int)(pix / P);
     float m[CE];
+    unsigned char am[CE];
 #pragma unroll
-    for (int e = 0; e < CE; ++e) m[e] = -FLT_MAX;
+    for (int e = 0; e < CE; ++e) { m[e] = -FLT_MAX; am[e] = 255; }
     for (int r = 0; r < k; ++r) {
       const int h = p * stride + r - pad;
       if ((unsigned)h >= (unsigned)H) continue;
@@ -65,20 +98,26 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x
         if ((unsigned)w >= (unsigned)W) continue;
         Chunk<T> c = load_chunk<T>(x + (((size_t)nn * H + h) * W + w) * C + cg * CE);
 #pragma unroll
-        for (int e = 0; e < CE; ++e) m[e] = fmaxf(m[e], Elem<T>::to_f(c.e[e]));
+        for (int e = 0; e < CE; ++e) {
+          const float v = Elem<T>::to_f(c.e[e]);
+          if (v > m[e] || am[e] == 255) { m[e] = v; am[e] = (unsigned char)(r * k + s); }
+        }
       }
     }
     Chunk<T> o;
 #pragma unroll
     for (int e = 0; e < CE; ++e) o.e[e] = Elem<T>::from_f(m[e]);
     store_chunk<T>(y + i * CE, o);
+    if (idx) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e) idx[i * CE + e] = am[e];
+    }
   }
 }
 
-// gather form: each input element sums dy of the windows whose argmax it is (no atomics, no zero-fill pass)
 template <typename T>
-__global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ x, T* __restrict__ dx, int N, int H, int W, int C,
-                                                         int P, int Q, int k, int stride, int pad) {
+__global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx, T* __restrict__ dx, int N, int H,
+                                                         int W, int C, int P, int Q, int k, int stride, int pad) {
   constexpr int CE = Elem<T>::CE;
   const int CC = C / CE;
   const long n = (long)N * H * W * CC;
@@ -88,37 +127,19 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ d
     const int w = (int)(pix % W); pix /= W;
     const int h = (int)(pix % H);
     const int nn = (int)(pix / H);
-    Chunk<T> cx = load_chunk<T>(x + i * CE);
     float g[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) g[e] = 0.f;
-    // windows (p, q) that contain (h, w): p*stride - pad <= h < p*stride - pad + k
     const int p_lo = max(0, (h + pad - k + stride) / stride), p_hi = min(P - 1, (h + pad) / stride);
     const int q_lo = max(0, (w + pad - k + stride) / stride), q_hi = min(Q - 1, (w + pad) / stride);
     for (int p = p_lo; p <= p_hi; ++p)
       for (int q = q_lo; q <= q_hi; ++q) {
-        // is (h, w) the first maximum of window (p, q)?
-        bool win[CE];
+        const int me = (h - (p * stride - pad)) * k + (w - (q * stride - pad));       // my position inside window (p, q)
+        const size_t o = (((size_t)nn * P + p) * Q + q) * C + cg * CE;
+        Chunk<T> d = load_chunk<T>(dy + o);
+        const unsigned char* ip = idx + o;
 #pragma unroll
-        for (int e = 0; e < CE; ++e) win[e] = true;
-        for (int r = 0; r < k; ++r) {
-          const int hh = p * stride + r - pad;
-          if ((unsigned)hh >= (unsigned)H) continue;
-          for (int s = 0; s < k; ++s) {
-            const int ww = q * stride + s - pad;
-            if ((unsigned)ww >= (unsigned)W || (hh == h && ww == w)) continue;
-            const bool before = hh < h || (hh == h && ww < w);
-            Chunk<T> c = load_chunk<T>(x + (((size_t)nn * H + hh) * W + ww) * C + cg * CE);
-#pragma unroll
-            for (int e = 0; e < CE; ++e) {
-              const float o = Elem<T>::to_f(c.e[e]), me = Elem<T>::to_f(cx.e[e]);
-              if (before ? o >= me : o > me) win[e] = false;
-            }
-          }
-        }
-        Chunk<T> d = load_chunk<T>(dy + (((size_t)nn * P + p) * Q + q) * C + cg * CE);
-#pragma unroll
-        for (int e = 0; e < CE; ++e) if (win[e]) g[e] += Elem<T>::to_f(d.e[e]);
+        for (int e = 0; e < CE; ++e) if (ip[e] == me) g[e] += Elem<T>::to_f(d.e[e]);
       }
     Chunk<T> o;
 #pragma unroll
@@ -290,6 +311,33 @@ extern "C" int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, 
   return 0;
 }
 
+extern "C" int rn_img_to_nhwc(const float* x_nchw, void* out, int dtype, int N, int C, int H, int W, int CP, rn_stream s) {
+  RN_CHECK_ARG(x_nchw && out && N > 0 && C > 0 && C <= CP && (dtype == RN_F32 || dtype == RN_BF16) && CP == (dtype == RN_F32 ? 4 : 8),
+               "rn_img_to_nhwc: bad argument (C=%d CP=%d)", C, CP);
+  const long n = (long)N * H * W;
+  if (dtype == RN_F32) hipLaunchKernelGGL((img_to_nhwc_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), x_nchw, (float*)out, N, C, H, W, CP);
+  else hipLaunchKernelGGL((img_to_nhwc_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), x_nchw, (bf16_t*)out, N, C, H, W, CP);
+  RN_CHECK_LAUNCH("img_to_nhwc");
+  return 0;
+}
+
+extern "C" int rn_pack_stem_w(const float* w_krsc, void* w_padded, int dtype, int K, int RS, int C, int CP, rn_stream s) {
+  RN_CHECK_ARG(w_krsc && w_padded && K > 0 && RS > 0 && C > 0 && C <= CP && (dtype == RN_F32 || dtype == RN_BF16), "rn_pack_stem_w: bad argument");
+  const long rows = (long)K * RS;
+  if (dtype == RN_F32) hipLaunchKernelGGL((pack_stem_w_kernel<float>), dim3(ew_grid(rows * CP)), dim3(NT), 0, as_stream(s), w_krsc, (float*)w_padded, rows, C, CP);
+  else hipLaunchKernelGGL((pack_stem_w_kernel<bf16_t>), dim3(ew_grid(rows * CP)), dim3(NT), 0, as_stream(s), w_krsc, (bf16_t*)w_padded, rows, C, CP);
+  RN_CHECK_LAUNCH("pack_stem_w");
+  return 0;
+}
+
+extern "C" int rn_unpack_stem_dw(const float* dw_padded, float* dw_krsc, int K, int RS, int C, int CP, int accumulate, rn_stream s) {
+  RN_CHECK_ARG(dw_padded && dw_krsc && K > 0 && RS > 0 && C > 0 && C <= CP, "rn_unpack_stem_dw: bad argument");
+  const long rows = (long)K * RS;
+  hipLaunchKernelGGL(unpack_stem_dw_kernel, dim3(ew_grid(rows * C)), dim3(NT), 0, as_stream(s), dw_padded, dw_krsc, rows, C, CP, accumulate);
+  RN_CHECK_LAUNCH("unpack_stem_dw");
+  return 0;
+}
+
 static int check_pool(int dtype, int N, int H, int W, int C, int k, int stride, int pad, const char* who) {
   RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "%s: bad dtype", who);
   RN_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % (dtype == RN_F32 ? 4 : 8) == 0 && k > 0 && stride > 0 && pad >= 0 && 2 * pad <= k,
@@ -297,24 +345,24 @@ static int check_pool(int dtype, int N, int H, int W, int C, int k, int stride, 
   return 0;
 }
 
-extern "C" int rn_maxpool_fwd(const void* x, void* y, int dtype, int N, int H, int W, int C, int k, int stride, int pad, rn_stream s) {
+extern "C" int rn_maxpool_fwd(const void* x, void* y, unsigned char* argmax, int dtype, int N, int H, int W, int C, int k, int stride, int pad, rn_stream s) {
   if (int e = check_pool(dtype, N, H, W, C, k, stride, pad, "rn_maxpool_fwd")) return e;
-  RN_CHECK_ARG(x && y, "rn_maxpool_fwd: null pointer");
+  RN_CHECK_ARG(x && y && k * k < 255, "rn_maxpool_fwd: bad argument");
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
   const long n = (long)N * P * Q * (C / (dtype == RN_F32 ? 4 : 8));
-  if (dtype == RN_F32) hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const float*)x, (float*)y, N, H, W, C, P, Q, k, stride, pad);
-  else hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const bf16_t*)x, (bf16_t*)y, N, H, W, C, P, Q, k, stride, pad);
+  if (dtype == RN_F32) hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const float*)x, (float*)y, argmax, N, H, W, C, P, Q, k, stride, pad);
+  else hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const bf16_t*)x, (bf16_t*)y, argmax, N, H, W, C, P, Q, k, stride, pad);
   RN_CHECK_LAUNCH("maxpool_fwd");
   return 0;
 }
 
-extern "C" int rn_maxpool_bwd(const void* dy, const void* x, void* dx, int dtype, int N, int H, int W, int C, int k, int stride, int pad, rn_stream s) {
+extern "C" int rn_maxpool_bwd(const void* dy, const unsigned char* argmax, void* dx, int dtype, int N, int H, int W, int C, int k, int stride, int pad, rn_stream s) {
   if (int e = check_pool(dtype, N, H, W, C, k, stride, pad, "rn_maxpool_bwd")) return e;
-  RN_CHECK_ARG(dy && x && dx, "rn_maxpool_bwd: null pointer");
+  RN_CHECK_ARG(dy && argmax && dx, "rn_maxpool_bwd: null pointer");
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
   const long n = (long)N * H * W * (C / (dtype == RN_F32 ? 4 : 8));
-  if (dtype == RN_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const float*)dy, (const float*)x, (float*)dx, N, H, W, C, P, Q, k, stride, pad);
-  else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, N, H, W, C, P, Q, k, stride, pad);
+  if (dtype == RN_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const float*)dy, argmax, (float*)dx, N, H, W, C, P, Q, k, stride, pad);
+  else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const bf16_t*)dy, argmax, (bf16_t*)dx, N, H, W, C, P, Q, k, stride, pad);
   RN_CHECK_LAUNCH("maxpool_bwd");
   return 0;
 }

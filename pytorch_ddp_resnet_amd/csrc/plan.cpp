@@ -40,7 +40,7 @@ extern "C" int rn_plan_create(const rn_op* ops, int n_ops, int n_bufs, int dtype
   RN_CHECK_ARG(ops && out && n_ops > 0 && n_bufs > 0, "rn_plan_create: bad argument");
   RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "rn_plan_create: bad dtype %d", dtype);
   for (int i = 0; i < n_ops; ++i) {
-    RN_CHECK_ARG(ops[i].kind >= RN_OP_STEM_FWD && ops[i].kind <= RN_OP_ADD_RES, "rn_plan_create: op %d has unknown kind %d", i, ops[i].kind);
+    RN_CHECK_ARG(ops[i].kind >= RN_OP_STEM_FWD && ops[i].kind <= RN_OP_UNPACK_STEM_DW, "rn_plan_create: op %d has unknown kind %d", i, ops[i].kind);
     for (int j = 0; j < RN_OP_NBUF; ++j)
       RN_CHECK_ARG(ops[i].buf[j] >= -1 && ops[i].buf[j] < n_bufs, "rn_plan_create: op %d buffer index %d out of range", i, ops[i].buf[j]);
   }
@@ -125,8 +125,8 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
       return rn_pack_weights((const float*)B(0), B(1), B(2), dt, d[0], d[1], d[2], s);
     case RN_OP_CONV_FWD: {
       rn_conv_geom g = geom_of(o);
-      rn_conv_epilogue ep{(float*)B(4), nullptr, nullptr, nullptr, 1.f};
-      return rn_conv_fwd(B(0), B(1), B(2), B(3), d[11], d[12], dt, &g, o.buf[4] >= 0 ? &ep : nullptr, s);
+      rn_conv_epilogue ep{(float*)B(4), nullptr, nullptr, nullptr, 1.f, (const float*)B(5)};
+      return rn_conv_fwd(B(0), B(1), B(2), B(3), d[11], d[12], dt, &g, (o.buf[4] >= 0 || o.buf[5] >= 0) ? &ep : nullptr, s);
     }
     case RN_OP_BN_STATS:
       return rn_bn_stats(B(0), (float*)B(1), d[2], dt, d[0], d[1], s);
@@ -138,14 +138,14 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
     case RN_OP_DROPOUT_FWD:
       return rn_dropout_fwd(B(0), B(1), dt, ((int64_t)d[1] << 31) | (int64_t)d[0], o.fp[0], o.seed, step_seed, s);
     case RN_OP_MAXPOOL_FWD:
-      return rn_maxpool_fwd(B(0), B(1), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], s);
+      return rn_maxpool_fwd(B(0), B(1), (unsigned char*)B(2), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], s);
     case RN_OP_POOL_FC_FWD:
       return rn_pool_fc_fwd(B(0), (const float*)B(1), (const float*)B(2), (float*)B(3), (float*)B(4), dt, d[0], d[1], d[2], d[3], s);
     case RN_OP_POOL_FC_BWD:
       return rn_pool_fc_bwd((const float*)B(0), (const float*)B(1), (const float*)B(2), B(3), (float*)B(4), (float*)B(5), dt, d[0], d[1], d[2], d[3],
                             o.flags, s);
     case RN_OP_MAXPOOL_BWD:
-      return rn_maxpool_bwd(B(0), B(1), B(2), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], s);
+      return rn_maxpool_bwd(B(0), (const unsigned char*)B(1), B(2), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], s);
     case RN_OP_BN_BWD_REDUCE:
       return rn_bn_bwd_reduce(B(0), B(1), B(2), (const float*)B(3), (float*)B(4), d[2], dt, d[0], d[1], o.flags, o.fp[0], o.fp[1], o.seed, step_seed, s);
     case RN_OP_BN_BWD_FINALIZE:
@@ -155,7 +155,7 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
                              o.flags, o.fp[0], (double)d[6], o.fp[1], o.seed, step_seed, s);
     case RN_OP_CONV_DGRAD: {
       rn_conv_geom g = geom_of(o);
-      rn_conv_epilogue ep{(float*)B(7), B(4), B(5), (const float*)B(6), o.fp[0]};
+      rn_conv_epilogue ep{(float*)B(7), B(4), B(5), (const float*)B(6), o.fp[0], nullptr};
       return rn_conv_dgrad(B(0), B(1), B(2), B(3), d[11], d[12], o.flags & ~RN_F_RELU, dt, &g, o.buf[7] >= 0 ? &ep : nullptr, s);
     }
     case RN_OP_CONV_WGRAD: {
@@ -182,6 +182,12 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
     }
     case RN_OP_ADD_RES:
       return rn_add_res(B(0), B(1), dt, d[0], d[1], d[2], d[3], d[4], d[5], s);
+    case RN_OP_IMG_TO_NHWC:
+      return rn_img_to_nhwc((const float*)B(0), B(1), dt, d[0], d[1], d[2], d[3], d[4], s);
+    case RN_OP_PACK_STEM_W:
+      return rn_pack_stem_w((const float*)B(0), B(1), dt, d[0], d[1], d[2], d[3], s);
+    case RN_OP_UNPACK_STEM_DW:
+      return rn_unpack_stem_dw((const float*)B(0), (float*)B(1), d[0], d[1], d[2], d[3], (o.flags & RN_F_ACCUM) ? 1 : 0, s);
     default:
       rn_set_error("rn_plan_run: unknown op kind %d", o.kind);
       return 1;

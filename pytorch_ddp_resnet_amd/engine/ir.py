@@ -14,7 +14,8 @@ RES_NONE, RES_SAME, RES_DOWN2PAD, RES_UP2 = 0, 1, 2, 3
 
 (OP_STEM_FWD, OP_PACK_W, OP_CONV_FWD, OP_BN_STATS, OP_BN_FINALIZE, OP_BN_APPLY, OP_DROPOUT_FWD, OP_MAXPOOL_FWD,
  OP_POOL_FC_FWD, OP_POOL_FC_BWD, OP_MAXPOOL_BWD, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE, OP_BN_BWD_APPLY,
- OP_CONV_DGRAD, OP_CONV_WGRAD, OP_STEM_WGRAD, OP_DROPOUT_BWD, OP_SOFTMAX_CE, OP_ZERO, OP_ADD_RES) = range(1, 22)
+ OP_CONV_DGRAD, OP_CONV_WGRAD, OP_STEM_WGRAD, OP_DROPOUT_BWD, OP_SOFTMAX_CE, OP_ZERO, OP_ADD_RES, OP_IMG_TO_NHWC,
+ OP_PACK_STEM_W, OP_UNPACK_STEM_DW) = range(1, 25)
 
 OP_NAMES = {v: k for k, v in list(globals().items()) if k.startswith('OP_') and isinstance(v, int)}
 
@@ -27,15 +28,15 @@ CONV_STATS_ROWS = 128      # RN_CONV_STATS_ROWS: output pixels per partial-sum r
 OP_FIELDS = {
     OP_STEM_FWD:        ('x w bias y', 'geom', ''),
     OP_PACK_W:          ('w w_fwd w_dgrad', 'K RS C', ''),
-    OP_CONV_FWD:        ('x w_fwd y res stats', 'geom res_mode res_C', ''),
+    OP_CONV_FWD:        ('x w_fwd y res stats bias', 'geom res_mode res_C', ''),
     OP_BN_STATS:        ('x partial', 'M C nblk', ''),
     OP_BN_FINALIZE:     ('partial gamma beta running_mean running_var nbt coef', 'nblk count C', 'eps momentum'),
     OP_BN_APPLY:        ('x coef res out', 'N H W C res_mode res_C', 'p'),
     OP_DROPOUT_FWD:     ('x out', 'n_lo n_hi', 'p'),
-    OP_MAXPOOL_FWD:     ('x y', 'N H W C k stride pad', ''),
+    OP_MAXPOOL_FWD:     ('x y argmax', 'N H W C k stride pad', ''),
     OP_POOL_FC_FWD:     ('x w b feat logits', 'N HW C O', ''),
     OP_POOL_FC_BWD:     ('dlogits feat w dx dw db', 'N HW C O', ''),
-    OP_MAXPOOL_BWD:     ('dy x dx', 'N H W C k stride pad', ''),
+    OP_MAXPOOL_BWD:     ('dy argmax dx', 'N H W C k stride pad', ''),
     OP_BN_BWD_REDUCE:   ('dout x mask coef partial', 'M C nblk', 'gscale p'),
     OP_BN_BWD_FINALIZE: ('partial dsum dgamma dbeta', 'nblk C', ''),
     OP_BN_BWD_APPLY:    ('dout x mask coef dsum add dx g_out', 'N H W C add_mode add_C count', 'gscale p'),
@@ -46,6 +47,9 @@ OP_FIELDS = {
     OP_SOFTMAX_CE:      ('logits labels out3 dlogits', 'N O', 'scale'),
     OP_ZERO:            ('dst', 'bytes_lo bytes_hi', ''),
     OP_ADD_RES:         ('dst res', 'N H W C res_mode res_C', ''),
+    OP_IMG_TO_NHWC:     ('x out', 'N C H W CP', ''),
+    OP_PACK_STEM_W:     ('w w_padded', 'K RS C CP', ''),
+    OP_UNPACK_STEM_DW:  ('dw_padded dw', 'K RS C CP', ''),
 }
 
 GEOM = 'N H W C P Q K R S stride pad'.split()

@@ -401,8 +401,43 @@ class Lowering:
                 xin = self.slot('x', 'input', (self.N, c.cin, self.H, self.W), 'f32')
                 named['x'] = xin
                 xt = T(xin, self.N, self.H, self.W, c.cin)
-                g = self.geom(xt, c.cout, k, s, pd)
                 w, b = self.param(pre + '.weight', (c.cout, k, k, c.cin)), self.param(pre + '.bias', (c.cout,))
+                CP = 4 if self.fp32 else 8
+                if k * k * c.cin >= 64 and c.cin <= CP:
+                    # MFMA route (7x7 ImageNet stem, GEMM-K = 147): NHWC image with the channels zero-padded to one 16-byte
+                    # chunk, then the implicit-GEMM kernels with bias (+ BN statistics) in the epilogue
+                    xp = self.act(pre + ':xpad', self.N, self.H, self.W, CP)
+                    self.fwd.append(Op(ir.OP_IMG_TO_NHWC, buf=dict(x=xin, out=xp.s), dim=dict(N=self.N, C=c.cin, H=self.H, W=self.W, CP=CP), note=pre))
+                    wp = self.slot(pre + ':wpad', 'act', (c.cout, k * k, CP), 'T')
+                    self.fwd.append(Op(ir.OP_PACK_STEM_W, buf=dict(w=w, w_padded=wp), dim=dict(K=c.cout, RS=k * k, C=c.cin, CP=CP), note=pre))
+                    g = self.geom(xp, c.cout, k, s, pd)
+                    y = self.act(pre + ':y', self.N, g['P'], g['Q'], c.cout)
+                    part = -1
+                    if self.train and self.fuse:
+                        rows = conv_stats_rows(g)
+                        part = self.f32(pre + ':stats', (rows, 2, c.cout))
+                        self._stats_of[y.s] = (part, rows)
+                    self.fwd.append(Op(ir.OP_CONV_FWD, buf=dict(x=xp.s, w_fwd=wp, y=y.s, res=-1, stats=part, bias=b), dim=dict(g, res_mode=0, res_C=0), note=pre))
+
+                    def stem_back(dy: T, ops, g=g, xp=xp, pre=pre, cin=c.cin, CP=CP):
+                        K, RS = g['K'], g['R'] * g['S']
+                        dwp = self.f32(pre + ':dwpad', (K, RS, CP))
+                        ops.append(Op(ir.OP_CONV_WGRAD, buf=dict(x=xp.s, dy=dy.s, dw=dwp, ws=self.ws()), dim=dict(g), note=pre))
+                        self._ws_need.append(('wgrad', dict(g)))
+                        dw, db = self.grad(pre + '.weight', (K, g['R'], g['S'], cin)), self.grad(pre + '.bias', (K,))
+                        ops.append(Op(ir.OP_UNPACK_STEM_DW, buf=dict(dw_padded=dwp, dw=dw), dim=dict(K=K, RS=RS, C=cin, CP=CP), note=pre))
+                        nblk = bn_partials(dy.M, K)               # bias gradient = per-channel sum of dy
+                        part = self.f32(pre + ':dbpartial', (nblk, 2, K))
+                        s2, sq = self.f32(pre + ':dbsum', (2, K)), self.f32(pre + ':dbsq', (K,))       # by-products, unused
+                        ops.append(Op(ir.OP_BN_STATS, buf=dict(x=dy.s, partial=part), dim=dict(M=dy.M, C=K, nblk=nblk), note=pre))
+                        ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=s2, dgamma=sq, dbeta=db), dim=dict(nblk=nblk, C=K), note=pre))
+                        self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
+                        return None
+                    self._back.append(stem_back)
+                    cur = y
+                    idx += 1
+                    continue
+                g = self.geom(xt, c.cout, k, s, pd)
                 y = self.act(pre + ':y', self.N, g['P'], g['Q'], c.cout)
                 self.fwd.append(Op(ir.OP_STEM_FWD, buf=dict(x=xin, w=w, bias=b, y=y.s), dim=dict(g), note=pre))
 
@@ -433,11 +468,12 @@ class Lowering:
                 P, Q = (cur.H + 2 * pd - k) // s + 1, (cur.W + 2 * pd - k) // s + 1
                 y = self.act(pre + ':y', cur.N, P, Q, cur.C)
                 d = dict(N=cur.N, H=cur.H, W=cur.W, C=cur.C, k=k, stride=s, pad=pd)
-                self.fwd.append(Op(ir.OP_MAXPOOL_FWD, buf=dict(x=cur.s, y=y.s), dim=d, note=pre))
+                am = self.slot(pre + ':argmax', 'u8', (cur.N, P, Q, cur.C), 'u8') if self.need_grad else -1
+                self.fwd.append(Op(ir.OP_MAXPOOL_FWD, buf=dict(x=cur.s, y=y.s, argmax=am), dim=d, note=pre))
 
-                def mp_back(dy: T, ops, x=cur, d=d, pre=pre):
+                def mp_back(dy: T, ops, x=cur, d=d, pre=pre, am=am):
                     dx = self.act(pre + ':dx', x.N, x.H, x.W, x.C)
-                    ops.append(Op(ir.OP_MAXPOOL_BWD, buf=dict(dy=dy.s, x=x.s, dx=dx.s), dim=d, note=pre))
+                    ops.append(Op(ir.OP_MAXPOOL_BWD, buf=dict(dy=dy.s, argmax=am, dx=dx.s), dim=d, note=pre))
                     return dx
                 self._back.append(mp_back)
                 cur = y

@@ -57,7 +57,7 @@ def run_both(plan, inputs, fp32, step_seed=0):
     for i, s in enumerate(plan.slots):
         if s.role == 'ws' or eng.tensors[i] is None:
             continue
-        hip[s.name] = eng.tensors[i].detach().float().cpu().numpy().astype(np.float64) if s.dtype != 'i64' else eng.tensors[i].cpu().numpy()
+        hip[s.name] = eng.tensors[i].detach().float().cpu().numpy().astype(np.float64) if s.dtype not in ('i64', 'u8') else eng.tensors[i].cpu().numpy()
     refd = {s.name: ref.bufs[i] for i, s in enumerate(plan.slots) if s.role != 'ws'}
     return hip, refd
 

@@ -50,6 +50,9 @@ class NumpyPlan:
         for i, s in enumerate(plan.slots):
             if s.role == 'ws':
                 continue
+            if s.role == 'u8':
+                self.bufs[i] = np.zeros(s.shape, dtype=np.uint8)
+                continue
             dt = {'T': dtype, 'f32': dtype, 'i64': np.int64, 'u8': np.uint8}[s.dtype]
             self.bufs[i] = np.zeros(s.shape, dtype=dt)
 
@@ -118,7 +121,8 @@ class NumpyPlan:
             if op.buf.get('w_dgrad', -1) >= 0:
                 put('w_dgrad', np.transpose(w, (2, 1, 0)))
         elif k == ir.OP_CONV_FWD:
-            y = ops.conv2d_fwd(B('x'), w_kcrs(B('w_fwd'), d['K'], d['R'], d['S'], d['C']), d['stride'], d['pad'])
+            y = ops.conv2d_fwd(B('x'), w_kcrs(B('w_fwd'), d['K'], d['R'], d['S'], d['C']), d['stride'], d['pad'],
+                               B('bias') if op.buf.get('bias', -1) >= 0 else None)
             if d.get('res_mode', 0):
                 y = y + res_read(B('res'), d['res_mode'], d['N'], d['P'], d['Q'], d['K'])
             put('y', y)
@@ -172,11 +176,13 @@ class NumpyPlan:
         elif k == ir.OP_ADD_RES:
             put('dst', B('dst') + res_read(B('res'), d['res_mode'], d['N'], d['H'], d['W'], d['C']))
         elif k == ir.OP_MAXPOOL_FWD:
-            y, _ = ops.maxpool_fwd(B('x'), d['k'], d['stride'], d['pad'])
+            y, arg = ops.maxpool_fwd(B('x'), d['k'], d['stride'], d['pad'])
             put('y', y)
+            if op.buf.get('argmax', -1) >= 0:
+                # window-local flat index r*k+s of the FIRST maximum among the in-bounds taps (padding is -inf)
+                put('argmax', arg.astype(np.uint8))
         elif k == ir.OP_MAXPOOL_BWD:
-            _, arg = ops.maxpool_fwd(B('x'), d['k'], d['stride'], d['pad'])
-            put('dx', ops.maxpool_bwd(B('dy'), arg, d['k'], d['stride'], d['pad'], d['H'], d['W']))
+            put('dx', ops.maxpool_bwd(B('dy'), B('argmax').astype(np.int64), d['k'], d['stride'], d['pad'], d['H'], d['W']))
         elif k == ir.OP_POOL_FC_FWD:
             feat = B('x').reshape(d['N'], d['HW'], d['C']).mean(1)
             put('feat', feat)
@@ -260,6 +266,17 @@ class NumpyPlan:
             put('out3', out)
             if op.buf.get('dlogits', -1) >= 0:
                 put('dlogits', ops.cross_entropy_bwd(lg, lb) * n * op.fp['scale'])
+        elif k == ir.OP_IMG_TO_NHWC:
+            out = np.zeros(self.bufs[op.buf['out']].shape, dtype=self.dtype)
+            out[..., :d['C']] = np.transpose(B('x'), (0, 2, 3, 1))
+            put('out', out)
+        elif k == ir.OP_PACK_STEM_W:
+            wp = np.zeros((d['K'], d['RS'], d['CP']), dtype=self.dtype)
+            wp[..., :d['C']] = B('w').reshape(d['K'], d['RS'], d['C'])
+            put('w_padded', wp)
+        elif k == ir.OP_UNPACK_STEM_DW:
+            v = B('dw_padded').reshape(d['K'], d['RS'], d['CP'])[..., :d['C']]
+            put('dw', v + B('dw').reshape(v.shape) if op.flags & ir.F_ACCUM else v)
         elif k == ir.OP_ZERO:
             self.bufs[op.buf['dst']][...] = 0
         else:

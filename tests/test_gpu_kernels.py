@@ -30,6 +30,7 @@ CONV_GEOMS = [
     (2, 8, 8, 32, 64, 1, 2, 0),          # projection shortcut
     (1, 16, 16, 96, 96, 3, 1, 1),        # BN=96 tile
     (2, 7, 7, 128, 256, 3, 1, 1),        # ImageNet-like 7x7 map
+    (2, 16, 16, 8, 64, 7, 2, 3),         # 7x7 stride-2 stem on the MFMA route (49 taps, channels padded to one chunk)
 ]
 
 
@@ -321,12 +322,13 @@ def test_pools_fc_loss(fp32):
     N, Hh, C, O = 4, 8, 32, 10
     b = h.PlanBuilder()
     x = b.slot('x', (N, Hh, Hh, C)); mp = b.slot('mp', (N, 4, 4, C)); dmp = b.slot('dmp', (N, 4, 4, C)); dxm = b.slot('dxm', (N, Hh, Hh, C))
+    am = b.slot('am', (N, 4, 4, C), 'u8', role='u8')
     w = b.slot('w', (O, C), 'f32'); bias = b.slot('bias', (O,), 'f32'); feat = b.slot('feat', (N, C), 'f32'); logits = b.slot('logits', (N, O), 'f32')
     labels = b.slot('labels', (N,), 'i64'); out3 = b.slot('out3', (4,), 'f32'); dl = b.slot('dl', (N, O), 'f32')
     dxf = b.slot('dxf', (N, 4, 4, C)); dwf = b.slot('dwf', (O, C), 'f32'); dbf = b.slot('dbf', (O,), 'f32')
     dpool = dict(N=N, H=Hh, W=Hh, C=C, k=3, stride=2, pad=1)
-    b.op(ir.OP_MAXPOOL_FWD, buf=dict(x=x, y=mp), dim=dpool)
-    b.op(ir.OP_MAXPOOL_BWD, buf=dict(dy=dmp, x=x, dx=dxm), dim=dpool)
+    b.op(ir.OP_MAXPOOL_FWD, buf=dict(x=x, y=mp, argmax=am), dim=dpool)
+    b.op(ir.OP_MAXPOOL_BWD, buf=dict(dy=dmp, argmax=am, dx=dxm), dim=dpool)
     dfc = dict(N=N, HW=16, C=C, O=O)
     b.op(ir.OP_POOL_FC_FWD, buf=dict(x=mp, w=w, b=bias, feat=feat, logits=logits), dim=dfc)
     b.op(ir.OP_SOFTMAX_CE, buf=dict(logits=logits, labels=labels, out3=out3, dlogits=dl), dim=dict(N=N, O=O), fp=dict(scale=1.0 / N))
