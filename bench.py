@@ -84,6 +84,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print the per-op-kind time table to stderr')
     ap.add_argument('--sync-bn', action='store_true')
+    ap.add_argument('--per-op', type=int, default=0, help='with --breakdown: list the N slowest single ops with their geometry')
     args = ap.parse_args()
 
     cfg = dict(WORKLOADS[args.workload])
@@ -149,6 +150,7 @@ def main():
         eng = next(e for k, e in model._engines.items() if k[1] and k[2])
         nprof = max(3, min(10, args.steps))
         agg, conv_t, conv_f, nconv = {}, 0.0, 0.0, 0
+        per_op = {}
         for _ in range(nprof):
             eng.profile(True)
             step()
@@ -156,6 +158,7 @@ def main():
             for op, t_ms in eng.profile_read():
                 name = ir.OP_NAMES[op.kind]
                 agg[name] = agg.get(name, 0.0) + t_ms / nprof
+                per_op[id(op)] = (op, per_op.get(id(op), (op, 0.0))[1] + t_ms / nprof)
                 if op.kind in (ir.OP_CONV_FWD, ir.OP_CONV_DGRAD, ir.OP_CONV_WGRAD):
                     conv_t += t_ms
                     conv_f += conv_flops(op)
@@ -171,6 +174,12 @@ def main():
         if args.breakdown:
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
                 print(f'  {k:22s} {v:9.3f} ms/step', file=sys.stderr)
+            for op, t in sorted(per_op.values(), key=lambda ot: -ot[1])[:args.per_op]:
+                d = op.dim
+                geo = (f"N{d['N']} {d['H']}x{d['W']} C{d['C']}->K{d['K']} k{d['R']} s{d['stride']}" if 'R' in d else
+                       ' '.join(f'{k}{v}' for k, v in d.items() if k in ('N', 'H', 'W', 'C', 'M')))
+                extra = f" {conv_flops(op) / (t * 1e-3) / 1e12:7.1f} TFLOP/s" if 'R' in d and t > 0 else ''
+                print(f'    {ir.OP_NAMES[op.kind]:18s} {t * 1e3:9.1f} us  {geo}{extra}  [{op.note}]', file=sys.stderr)
     if world > 1:
         torch.distributed.barrier()
 

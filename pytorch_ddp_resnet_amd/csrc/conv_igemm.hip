@@ -69,98 +69,138 @@ template <> struct Mfma<bf16_t> {
 };
 
 
-// ---- epilogue shared by the register-staged and the LDS-DMA kernel ------------------------------------------------------
-// C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).  Besides the store (+ residual,
-// + accumulate) it can reduce per-channel statistics of what it stores -- the BatchNorm batch statistics of the next
-// layer (forward) or the two BatchNorm-backward sums of the previous one (dgrad) -- so those layers need no pass of
-// their own over the tensor: lane sums over its 16 rows, the two half-waves are folded with a cross-lane add, the
-// WM waves of a column strip through LDS (`red`, the staging memory, free after the K loop), one row per M tile out.
+// ---- epilogue shared by all implicit-GEMM kernels ---------------------------------------------------------------------------
+// The 32x32 MFMA leaves a lane with ONE output channel (col = lane&31) of 16 rows (row = (r&3) + 8*(r>>2) + 4*(lane>>5)):
+// storing from there means 2-byte accesses in 64-byte segments, which capped output-bound layers (1x1 convolutions at
+// 56x56) at ~0.6 TB/s.  Instead the accumulator tile goes through LDS (the staging memory, free after the K loop) in two
+// halves of 64 rows as fp32, and is read back by column-fixed threads -- thread = (16-byte output chunk column, row lane)
+// -- so every global access (store, residual, accumulate, BatchNorm operands) is a 16-byte chunk, consecutive lanes on
+// consecutive chunks of a row.  Owning a fixed channel chunk, a thread also keeps per-channel sums in registers: the
+// BatchNorm batch statistics of what it stores (forward) or the two BatchNorm-backward sums of the layer that fed the
+// convolution (dgrad), reduced over the row lanes through LDS into one partial row per M tile.
 template <typename T, int BM, int BN, int WM, int WN, int TM, int TN>
-__device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int wave, int lane, float* red,
+__device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int wave, int lane, float* lds_f,
                                       bool active = true, int nthreads = WM * WN * 64) {
+  constexpr int CE = Elem<T>::CE;
+  constexpr int HR = 64;                       // rows per half
+  constexpr int LDC = BN + 4;                  // fp32 row stride of the staged tile
+  constexpr int CCN = BN / CE;                 // output chunks per row
+  static_assert(BM % HR == 0 && BN % CE == 0, "epilogue tile");
+  float* ctile = lds_f;                        // [HR][LDC]
+  float* red = lds_f + HR * LDC;               // [row lanes][2][BN]
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 31, lh = lane >> 5;
   const int pq = a.Pc * a.Qc;
+  const int tid = threadIdx.x;
+  const int lanes = nthreads / CCN;            // row lanes (threads beyond lanes*CCN idle in phase 2)
+  const int cg = tid % CCN, rl = tid / CCN;
+  const bool p2 = rl < lanes;
+  const int k0 = n0 + cg * CE;
+  const bool colok = p2 && k0 < a.Kd;
   T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
   const bool dense = (a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME);
   const bool want_stats = a.stats != nullptr;
   const bool bn_bwd = want_stats && a.bn_x != nullptr;
-  float s0[TN], s1[TN], mean[TN], invstd[TN];
+  float s0[CE], s1[CE], mean[CE], invstd[CE], bias[CE];
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    s0[j] = s1[j] = 0.f; mean[j] = 0.f; invstd[j] = 1.f;
-    const int k = n0 + wn * (BN / WN) + 32 * j + lr;
-    if (bn_bwd && k < a.Kd) { mean[j] = a.bn_coef[2 * a.Kd + k]; invstd[j] = a.bn_coef[3 * a.Kd + k]; }
+  for (int e = 0; e < CE; ++e) {
+    s0[e] = s1[e] = 0.f; mean[e] = 0.f; invstd[e] = 1.f; bias[e] = 0.f;
+    if (colok && bn_bwd) { mean[e] = a.bn_coef[2 * a.Kd + k0 + e]; invstd[e] = a.bn_coef[3 * a.Kd + k0 + e]; }
+    if (colok && a.bias) bias[e] = a.bias[k0 + e];
   }
-  if (active) {
+  __syncthreads();                             // every wave is done with the K-loop staging memory
+#pragma unroll 1
+  for (int half = 0; half < BM / HR; ++half) {
+    // ---- phase 1: the waves whose rows fall into this half park their accumulators (fp32) ----
+    if (active) {
 #pragma unroll
-  for (int i = 0; i < TM; ++i) {
+      for (int i = 0; i < TM; ++i) {
+        const int rbase = wm * (BM / WM) + 32 * i;
+        if (rbase / HR == half) {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * (BM / WM) + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int m = m0 + row;
-      if (m >= a.M) continue;
-      size_t pix;
-      int n = 0, hd = 0, wd = 0;
-      if (dense) {
-        pix = (size_t)m;
-      } else {
-        n = m / pq;
-        int rem = m - n * pq;
-        int pp = rem / a.Qc, q = rem - pp * a.Qc;
-        hd = pp * a.ds + a.oh;
-        wd = q * a.ds + a.ow;
-        pix = ((size_t)n * a.Hd + hd) * a.Wd + wd;
-      }
+          for (int r = 0; r < 16; ++r) {
+            const int row = rbase - half * HR + (r & 3) + 8 * (r >> 2) + 4 * lh;
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int k = n0 + wn * (BN / WN) + 32 * j + lr;
-        if (k >= a.Kd) continue;
-        float v = acc[i][j][r];
-        if (a.bias) v += a.bias[k];
-        const size_t off = pix * a.Kd + k;
-        if (a.res.mode != RN_RES_NONE) {
-          if (dense) v += Elem<T>::to_f(reinterpret_cast<const T*>(a.res.ptr)[off]);
-          else v += res_load1<T>(a.res, n, hd, wd, k);
-        }
-        if (a.accum) v += Elem<T>::to_f(dst[off]);
-        const T stored = Elem<T>::from_f(v);
-        dst[off] = stored;
-        if (want_stats) {
-          const float vs = Elem<T>::to_f(stored);            // statistics of the value the next kernel will read
-          if (!bn_bwd) { s0[j] += vs; s1[j] += vs * vs; }
-          else {
-            float g = vs * a.gscale;
-            if (a.bn_mask && !(Elem<T>::to_f(reinterpret_cast<const T*>(a.bn_mask)[off]) > 0.f)) g = 0.f;
-            const float xh = (Elem<T>::to_f(reinterpret_cast<const T*>(a.bn_x)[off]) - mean[j]) * invstd[j];
-            s0[j] += g; s1[j] += g * xh;
+            for (int j = 0; j < TN; ++j) ctile[row * LDC + wn * (BN / WN) + 32 * j + lr] = acc[i][j][r];
           }
         }
       }
     }
-  }
-  }   // active
-  if (!want_stats) return;
-  // fold the two half-waves (rows 4*lh + ...), then the WM waves of this column strip
+    __syncthreads();
+    // ---- phase 2: column-fixed threads, 16-byte chunks ----
+    if (colok) {
+      for (int row = rl; row < HR; row += lanes) {
+        const int m = m0 + half * HR + row;
+        if (m >= a.M) break;
+        size_t pix;
+        int n = 0, hd = 0, wd = 0;
+        if (dense) {
+          pix = (size_t)m;
+        } else {
+          n = m / pq;
+          const int rem = m - n * pq;
+          const int pp = rem / a.Qc, q = rem - pp * a.Qc;
+          hd = pp * a.ds + a.oh;
+          wd = q * a.ds + a.ow;
+          pix = ((size_t)n * a.Hd + hd) * a.Wd + wd;
+        }
+        const size_t off = pix * a.Kd + k0;
+        float v[CE];
+        const float* cp = ctile + row * LDC + cg * CE;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) { s0[j] += __shfl_xor(s0[j], 32, 64); s1[j] += __shfl_xor(s1[j], 32, 64); }
-  __syncthreads();                                            // every wave is done reading the staging LDS
-  if (active && lh == 0) {
+        for (int e = 0; e < CE; e += 4) {
+          const float4 t = *reinterpret_cast<const float4*>(cp + e);
+          v[e] = t.x + bias[e]; v[e + 1] = t.y + bias[e + 1]; v[e + 2] = t.z + bias[e + 2]; v[e + 3] = t.w + bias[e + 3];
+        }
+        if (a.res.mode == RN_RES_SAME) {
+          Chunk<T> cr = load_chunk<T>(reinterpret_cast<const T*>(a.res.ptr) + off);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int col = wn * (BN / WN) + 32 * j + lr;
-      red[(wm * 2 + 0) * BN + col] = s0[j];
-      red[(wm * 2 + 1) * BN + col] = s1[j];
+          for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cr.e[e]);
+        } else if (a.res.mode != RN_RES_NONE) {
+          if (dense) { n = m / pq; const int rem = m - n * pq; hd = rem / a.Qc; wd = rem - hd * a.Qc; }
+          res_add_chunk<T>(a.res, n, hd, wd, k0, v);
+        }
+        if (a.accum) {
+          Chunk<T> co = load_chunk<T>(dst + off);
+#pragma unroll
+          for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(co.e[e]);
+        }
+        Chunk<T> st;
+#pragma unroll
+        for (int e = 0; e < CE; ++e) st.e[e] = Elem<T>::from_f(v[e]);
+        store_chunk<T>(dst + off, st);
+        if (want_stats) {
+          if (!bn_bwd) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) { const float vs = Elem<T>::to_f(st.e[e]); s0[e] += vs; s1[e] += vs * vs; }
+          } else {
+            Chunk<T> cx = load_chunk<T>(reinterpret_cast<const T*>(a.bn_x) + off);
+            Chunk<T> cm;
+            if (a.bn_mask) cm = load_chunk<T>(reinterpret_cast<const T*>(a.bn_mask) + off);
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+              float g = Elem<T>::to_f(st.e[e]) * a.gscale;
+              if (a.bn_mask && !(Elem<T>::to_f(cm.e[e]) > 0.f)) g = 0.f;
+              const float xh = (Elem<T>::to_f(cx.e[e]) - mean[e]) * invstd[e];
+              s0[e] += g; s1[e] += g * xh;
+            }
+          }
+        }
+      }
     }
+    __syncthreads();                           // ctile is reused by the next half / by `red`
+  }
+  if (!want_stats) return;
+  if (p2) {
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { red[(rl * 2 + 0) * BN + cg * CE + e] = s0[e]; red[(rl * 2 + 1) * BN + cg * CE + e] = s1[e]; }
   }
   __syncthreads();
-  const int tid = threadIdx.x;
   for (int col = tid; col < BN; col += nthreads) {
     const int k = n0 + col;
     if (k >= a.Kd) continue;
     float t0 = 0.f, t1 = 0.f;
-#pragma unroll
-    for (int w = 0; w < WM; ++w) { t0 += red[(w * 2 + 0) * BN + col]; t1 += red[(w * 2 + 1) * BN + col]; }
+    for (int w = 0; w < lanes; ++w) { t0 += red[(w * 2 + 0) * BN + col]; t1 += red[(w * 2 + 1) * BN + col]; }
     float* out = a.stats + ((size_t)(a.tile_base + m0 / BM) * 2) * a.Kd;
     out[k] = t0;
     out[a.Kd + k] = t1;
