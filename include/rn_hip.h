@@ -159,7 +159,8 @@ int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, int dtype, 
 /* y = conv(x, w_fwd) [+ res];  MFMA implicit GEMM, M = N*P*Q, N = K, K = R*S*C.  C % 8 == 0, K % 16 == 0 */
 int rn_conv_fwd(const void* x, const void* w_fwd, void* y, const void* res, int res_mode, int res_C, int dtype,
                 const rn_conv_geom* g, const rn_conv_epilogue* ep, rn_stream s);
-/* dx = conv_transpose(dy, w) [+ res] ; flags: RN_F_ACCUM */
+/* dx = conv_transpose(dy, w) [+ res] ; flags: RN_F_ACCUM (dx += ...).  With an epilogue descriptor the BatchNorm-backward sums are
+ * taken over the value finally stored in dx, so with RN_F_ACCUM the call must be the last accumulation into dx */
 int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* res, int res_mode, int res_C,
                   int flags, int dtype, const rn_conv_geom* g, const rn_conv_epilogue* ep, rn_stream s);
 /* dw[k,r,s,c] (fp32 KRSC) = sum_{n,p,q} dy * x ; split over pixels into ws, then reduced. flags: RN_F_ACCUM */

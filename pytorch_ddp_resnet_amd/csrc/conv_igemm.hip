@@ -889,7 +889,6 @@ extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, cons
   const int st = g->stride;
   const int ce = dtype == RN_F32 ? 4 : 8;
   RN_CHECK_ARG(!ep || (ep->partial && ep->bn_x && ep->bn_coef && !ep->bias), "rn_conv_dgrad: incomplete epilogue descriptor");
-  RN_CHECK_ARG(!ep || !(flags & RN_F_ACCUM), "rn_conv_dgrad: a fused BatchNorm-backward reduction needs the complete gradient (no RN_F_ACCUM)");
   int tile_base = 0;
   if ((g_rn_variant & 1) && !ep && g->R == 3 && g->S == 3 && st == 1 && g->pad == 1) {
     ResDesc rd;
@@ -926,7 +925,7 @@ extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, cons
       a.accum = (flags & RN_F_ACCUM) ? 1 : 0;
       fill_ep(a, ep, tile_base);
       tile_base += cdiv(a.M, RN_CONV_STATS_ROWS);
-      if (nt == 0 && a.accum && a.res.mode == RN_RES_NONE) continue;   // nothing to add to this class
+      if (nt == 0 && a.accum && a.res.mode == RN_RES_NONE && !ep) continue;   // nothing to add to this class (a fused reduction still has to see it)
       int e = dtype == RN_F32 ? launch_igemm<float>(a, as_stream(s)) : launch_igemm<bf16_t>(a, as_stream(s));
       if (e) return e;
     }

@@ -25,6 +25,7 @@ struct WgradArgs {
   int M;             // N*P*Q
   int splits, rows_per_split;
   int kt, ct;        // tiles along K and C
+  int im2col;        // 1: the taps are folded into the column dimension (stem: C = one chunk per tap), dy is read once per column tile
   int dh[MAX_TAPS], dw[MAX_TAPS];
 };
 
@@ -100,8 +101,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   constexpr int BP = Bp<T>::v, TPR = 256 / BP;          // pixels per tile, threads staging one pixel row
   constexpr int NJA = (CHA + TPR - 1) / TPR, NJB = (CHB + TPR - 1) / TPR;
   __shared__ __attribute__((aligned(16))) char lds[2][BP * (ROWA + ROWB)];
+  __shared__ int tdh[MAX_TAPS], tdw[MAX_TAPS];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < MAX_TAPS) { tdh[tid] = tid < a.RS ? a.dh[tid] : 0; tdw[tid] = tid < a.RS ? a.dw[tid] : 0; }
+  __syncthreads();
   int b = blockIdx.x;
   const int split = b % a.splits; b /= a.splits;
   const int t = b % a.nt; b /= a.nt;
@@ -135,27 +139,52 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     return make_uint4(v[0], v[1], v[2], v[3]);
   };
   unsigned cha_off[NJA], chb_off[NJB];
+  int chb_dh[NJB], chb_dw[NJB];              // im2col: tap of each B chunk
+  const int ncols = a.im2col ? a.RS * a.C : a.C;
 #pragma unroll
   for (int j = 0; j < NJA; ++j) { const int ch = cl + TPR * j; cha_off[j] = (ch < CHA && k0 + ch * CE < a.K) ? (unsigned)((k0 + ch * CE) * ES) : OOB; }
 #pragma unroll
-  for (int j = 0; j < NJB; ++j) { const int ch = cl + TPR * j; chb_off[j] = (ch < CHB && c0 + ch * CE < a.C) ? (unsigned)((c0 + ch * CE) * ES) : OOB; }
+  for (int j = 0; j < NJB; ++j) {
+    const int ch = cl + TPR * j;
+    const bool ok = ch < CHB && c0 + ch * CE < ncols;
+    chb_dh[j] = 0; chb_dw[j] = 0;
+    if (a.im2col) {                           // column chunk (c0/CE + ch) IS tap number (C == CE)
+      const int tap = ok ? c0 / CE + ch : 0;
+      chb_dh[j] = tdh[tap]; chb_dw[j] = tdw[tap];
+      chb_off[j] = ok ? 0u : OOB;
+    } else {
+      chb_off[j] = ok ? (unsigned)((c0 + ch * CE) * ES) : OOB;
+    }
+  }
 
   uint4 ra[NJA], rb[NJB];
   auto load_tile = [&](int it) {
     const int m = m_begin + it * BP + prow;
     const bool mv = m < m_end;
     unsigned xoff = OOB, yoff = OOB;
+    int n = 0, h0 = 0, w0 = 0;
     if (mv) {
-      int n = m / pq, rem = m - n * pq;
-      int p = rem / a.Q, q = rem - p * a.Q;
-      int h = p * a.stride + dht, w = q * a.stride + dwt;
+      n = m / pq;
+      const int rem = m - n * pq;
+      const int p = rem / a.Q, q = rem - p * a.Q;
+      h0 = p * a.stride; w0 = q * a.stride;
+      const int h = h0 + dht, w = w0 + dwt;
       yoff = (unsigned)(((size_t)(m - n_first * pq)) * a.K * ES);
       if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W) xoff = (unsigned)((((size_t)(n - n_first) * a.H + h) * a.W + w) * a.C * ES);
     }
 #pragma unroll
     for (int j = 0; j < NJA; ++j) ra[j] = bload(ydesc, (yoff != OOB && cha_off[j] != OOB) ? yoff + cha_off[j] : OOB);
+    if (!a.im2col) {
 #pragma unroll
-    for (int j = 0; j < NJB; ++j) rb[j] = bload(xdesc, (xoff != OOB && chb_off[j] != OOB) ? xoff + chb_off[j] : OOB);
+      for (int j = 0; j < NJB; ++j) rb[j] = bload(xdesc, (xoff != OOB && chb_off[j] != OOB) ? xoff + chb_off[j] : OOB);
+    } else {
+#pragma unroll
+      for (int j = 0; j < NJB; ++j) {
+        const int h = h0 + chb_dh[j], w = w0 + chb_dw[j];
+        const bool ok = mv && chb_off[j] != OOB && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
+        rb[j] = bload(xdesc, ok ? (unsigned)((((size_t)(n - n_first) * a.H + h) * a.W + w) * a.C * ES) : OOB);
+      }
+    }
   };
   auto store_tile = [&](int buf) {
     char* ta = lds[buf];
@@ -205,7 +234,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
         const int c = c0 + chb + 16 * j + (lane & 15);
-        if (c < a.C) out[((size_t)k * a.RS + t) * a.C + c] = acc[i][j][r];
+        if (a.im2col) { if (c < a.RS * a.C) out[(size_t)k * a.RS * a.C + c] = acc[i][j][r]; }
+        else if (c < a.C) out[((size_t)k * a.RS + t) * a.C + c] = acc[i][j][r];
       }
     }
 }
@@ -241,9 +271,11 @@ inline int pick_tile(int n) {       // block tile edge from {160,128,64,32}: few
   return best;
 }
 
-int wgrad_splits(const rn_conv_geom* g, int bk, int bc) {
+inline bool use_im2col(const rn_conv_geom* g, int dtype_ce) { return g->C == dtype_ce && g->R * g->S > 9; }
+
+int wgrad_splits(const rn_conv_geom* g, int bk, int bc, bool im2col = false) {
   const long M = (long)g->N * g->P * g->Q;
-  const int tiles = cdiv(g->K, bk) * cdiv(g->C, bc) * g->R * g->S;
+  const int tiles = im2col ? cdiv(g->K, bk) * cdiv(g->R * g->S * g->C, bc) : cdiv(g->K, bk) * cdiv(g->C, bc) * g->R * g->S;
   int splits = 512 / tiles;                              // one resident round: 2 workgroups per CU x 256 CUs
   const int max_by_rows = (int)((M + 255) / 256);      // at least 8 K-steps per block
   if (splits > max_by_rows) splits = max_by_rows;
@@ -275,9 +307,14 @@ template <typename T> int dispatch_w(const WgradArgs& a, int bk, int bc, hipStre
 
 extern "C" size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g) {
   if (!g) return 0;
-  const int bk = pick_tile(g->K), bc = pick_tile(g->C);
-  const int splits = wgrad_splits(g, bk, bc);
-  return (size_t)splits * g->K * g->R * g->S * g->C * sizeof(float);
+  size_t best = 0;
+  for (int ce : {4, 8}) {                     // the workspace is sized before the dtype is known: take the larger need
+    const bool ic = use_im2col(g, ce);
+    const int bk = pick_tile(g->K), bc = pick_tile(ic ? g->R * g->S * g->C : g->C);
+    const size_t need = (size_t)wgrad_splits(g, bk, bc, ic) * g->K * g->R * g->S * g->C * sizeof(float);
+    if (need > best) best = need;
+  }
+  return best;
 }
 
 extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void* ws, size_t ws_bytes, int flags, int dtype,
@@ -288,17 +325,19 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   RN_CHECK_ARG(g->C % ce == 0 && g->K % ce == 0, "rn_conv_wgrad: C=%d, K=%d must be multiples of %d", g->C, g->K, ce);
   RN_CHECK_ARG(g->R == g->S && g->R * g->S <= MAX_TAPS, "rn_conv_wgrad: kernel %dx%d unsupported", g->R, g->S);
   RN_CHECK_ARG((long)g->N * g->P * g->Q < (1L << 31), "rn_conv_wgrad: too many pixels");
-  const int bk = pick_tile(g->K), bc = pick_tile(g->C);
+  const bool ic = use_im2col(g, ce);
+  const int bk = pick_tile(g->K), bc = pick_tile(ic ? g->R * g->S * g->C : g->C);
   WgradArgs a{};
+  a.im2col = ic ? 1 : 0;
   a.x = x; a.dy = dy;
   a.N = g->N; a.H = g->H; a.W = g->W; a.C = g->C; a.P = g->P; a.Q = g->Q; a.K = g->K;
-  a.stride = g->stride; a.RS = g->R * g->S; a.nt = a.RS;
+  a.stride = g->stride; a.RS = g->R * g->S; a.nt = ic ? 1 : a.RS;
   for (int r = 0; r < g->R; ++r)
     for (int t = 0; t < g->S; ++t) { a.dh[r * g->S + t] = r - g->pad; a.dw[r * g->S + t] = t - g->pad; }
   a.M = g->N * g->P * g->Q;
-  a.splits = wgrad_splits(g, bk, bc);
+  a.splits = wgrad_splits(g, bk, bc, ic);
   a.rows_per_split = ((a.M + a.splits - 1) / a.splits + 31) / 32 * 32;
-  a.kt = cdiv(g->K, bk); a.ct = cdiv(g->C, bc);
+  a.kt = cdiv(g->K, bk); a.ct = cdiv(ic ? g->R * g->S * g->C : g->C, bc);
   const size_t n = (size_t)g->K * a.RS * g->C;
   const bool direct = a.splits == 1 && !(flags & RN_F_ACCUM);
   if (!direct) {

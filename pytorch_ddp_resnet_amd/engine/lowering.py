@@ -95,6 +95,7 @@ class Lowering:
         self._packed: Dict[str, Tuple[int, int]] = {}
         self._ws_need = []              # geometries of ops that share the workspace slot
         self._stats_of: Dict[int, Tuple[int, int]] = {}    # tensor slot -> (partial slot, rows) written by its producer's epilogue
+        self._tail_bn: Dict[int, dict] = {}                # output slot of a BN(+add)+ReLU -> its record: the consumer's dgrad reduces its backward sums
         self._dpart_of: Dict[int, Tuple[int, int]] = {}    # gradient tensor slot -> BN-backward partial sums from the dgrad epilogue
         self._site_of: Dict[int, Tuple[float, int, bool]] = {}   # BN_APPLY output slot -> (dropout p, site, mask recomputable)
         self.fuse = True                # BN batch statistics in the producing conv's epilogue (free: no extra operand reads)
@@ -187,7 +188,7 @@ class Lowering:
         dx = accum_into or self.act(dx_name, x.N, x.H, x.W, x.C)
         buf = dict(dy=dy.s, w_dgrad=wd, dx=dx.s, res=res.s if res else -1)
         fp, flags = {}, (ir.F_ACCUM if accum_into else 0)
-        if fuse_bn is not None and self.fuse_dgrad and accum_into is None:
+        if fuse_bn is not None and self.fuse_dgrad:        # with accum_into: this must be the LAST accumulation into dx
             rows = conv_stats_rows(g, dgrad=True)
             part = self.f32(dx_name + ':dpartial', (rows, 2, x.C))
             mask = fuse_bn['mask']
@@ -348,6 +349,7 @@ class Lowering:
                         res, mode = i, ir.RES_DOWN2PAD
                     h, _ = self.bn_apply(y, coef, f'{bp}.h', relu=True, drop=False, res=res, res_mode=mode)
                     rec.update(out=h, p=0.0)
+                    self._tail_bn[h.s] = dict(x=y, mask=h, coef=coef, p=0.0)
                 recs.append(rec)
 
             def backward(dh: T, ops):
@@ -368,8 +370,12 @@ class Lowering:
                         res, mode = None, ir.RES_NONE
                         if not proj:
                             res, mode = gm, (ir.RES_SAME if not down else ir.RES_UP2)
+                        # the BN (+add+ReLU) that produced this block's input: its backward sums are reduced by whichever
+                        # dgrad completes di (conv1's, or the projection's accumulate when there is one)
+                        tail = self._tail_bn.get(i.s) if plain else None
                         if plain:
-                            gcur = self.conv_bwd(ops, r['x'], dy, f'{bp}._conv{j}.weight', r['g'], r['wd'], f'{bp}.di', res=res, res_mode=mode)
+                            gcur = self.conv_bwd(ops, r['x'], dy, f'{bp}._conv{j}.weight', r['g'], r['wd'], f'{bp}.di', res=res, res_mode=mode,
+                                                 fuse_bn=None if proj else tail)
                         else:   # dropout1 sits between the block input and conv1: its mask applies before the merge
                             t = self.conv_bwd(ops, r['x'], dy, f'{bp}._conv{j}.weight', r['g'], r['wd'], f'{bp}.dx0')
                             gcur = self.act(f'{bp}.di', i.N, i.H, i.W, i.C)
@@ -379,7 +385,7 @@ class Lowering:
                                 ops.append(Op(ir.OP_ADD_RES, buf=dict(dst=gcur.s, res=res.s),
                                               dim=dict(N=i.N, H=i.H, W=i.W, C=i.C, res_mode=mode, res_C=res.C), note=bp))
                         if proj:
-                            self.conv_bwd(ops, i, gm, f'{bp}._proj.weight', sc_g, sc_wd, None, accum_into=gcur)
+                            self.conv_bwd(ops, i, gm, f'{bp}._proj.weight', sc_g, sc_wd, f'{bp}.di', accum_into=gcur, fuse_bn=tail)
                 return gcur
         self._back.append(backward)
         return h
@@ -452,6 +458,7 @@ class Lowering:
                 relu = idx + 1 < len(comps) and comps[idx + 1].kind == 'act'
                 coef = self.bn_coef(cur, pre)
                 out, _ = self.bn_apply(cur, coef, pre + ':out', relu=relu)
+                self._tail_bn[out.s] = dict(x=cur, mask=out if relu else None, coef=coef, p=0.0)
 
                 def norm_back(dout: T, ops, x=cur, out=out, coef=coef, pre=pre, relu=relu):
                     dx, _ = self.bn_bwd(ops, dout, x, out if relu else None, coef, pre, pre + ':dx')
