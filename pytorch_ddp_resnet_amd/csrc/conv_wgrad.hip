@@ -92,7 +92,8 @@ template <int TI, int TJ> struct WTile<float, TI, TJ> {
 constexpr int padded_row(int bytes) { return bytes % 128 == 64 ? bytes : bytes + ((64 - bytes % 128) + 128) % 128; }
 
 // block tile (2*TI*16) x (2*TJ*16): 4 waves as 2x2, each TI x TJ MFMA tiles of 16x16
-template <typename T, int TI, int TJ>
+// IC: im2col mode (the taps are folded into the column dimension; see WgradArgs::im2col)
+template <typename T, int TI, int TJ, bool IC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   constexpr int CE = Elem<T>::CE;
   constexpr int BK_ = 2 * TI * 16, BC_ = 2 * TJ * 16;
@@ -100,12 +101,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   constexpr int CHA = BK_ / CE, CHB = BC_ / CE;          // 16-byte chunks per pixel row
   constexpr int BP = Bp<T>::v, TPR = 256 / BP;          // pixels per tile, threads staging one pixel row
   constexpr int NJA = (CHA + TPR - 1) / TPR, NJB = (CHB + TPR - 1) / TPR;
-  __shared__ __attribute__((aligned(16))) char lds[2][BP * (ROWA + ROWB)];
-  __shared__ int tdh[MAX_TAPS], tdw[MAX_TAPS];
+  __shared__ __attribute__((aligned(16))) char lds[2][BP * (ROWA + ROWB)];   // the only LDS object: 2 workgroups per CU at the largest tile
+  static_assert(2 * BP * (ROWA + ROWB) >= 2 * MAX_TAPS * (int)sizeof(int), "tap tables are parked in the staging buffer during setup");
+  int* tdh = reinterpret_cast<int*>(&lds[0][0]);
+  int* tdw = tdh + MAX_TAPS;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  if (tid < MAX_TAPS) { tdh[tid] = tid < a.RS ? a.dh[tid] : 0; tdw[tid] = tid < a.RS ? a.dw[tid] : 0; }
-  __syncthreads();
+  if (IC) {
+    if (tid < MAX_TAPS) { tdh[tid] = tid < a.RS ? a.dh[tid] : 0; tdw[tid] = tid < a.RS ? a.dw[tid] : 0; }
+    __syncthreads();
+  }
   int b = blockIdx.x;
   const int split = b % a.splits; b /= a.splits;
   const int t = b % a.nt; b /= a.nt;
@@ -139,16 +144,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     return make_uint4(v[0], v[1], v[2], v[3]);
   };
   unsigned cha_off[NJA], chb_off[NJB];
-  int chb_dh[NJB], chb_dw[NJB];              // im2col: tap of each B chunk
-  const int ncols = a.im2col ? a.RS * a.C : a.C;
+  int chb_dh[IC ? NJB : 1], chb_dw[IC ? NJB : 1];   // im2col: tap of each B chunk
+  const int ncols = IC ? a.RS * a.C : a.C;
 #pragma unroll
   for (int j = 0; j < NJA; ++j) { const int ch = cl + TPR * j; cha_off[j] = (ch < CHA && k0 + ch * CE < a.K) ? (unsigned)((k0 + ch * CE) * ES) : OOB; }
 #pragma unroll
   for (int j = 0; j < NJB; ++j) {
     const int ch = cl + TPR * j;
     const bool ok = ch < CHB && c0 + ch * CE < ncols;
-    chb_dh[j] = 0; chb_dw[j] = 0;
-    if (a.im2col) {                           // column chunk (c0/CE + ch) IS tap number (C == CE)
+    if constexpr (IC) {                       // column chunk (c0/CE + ch) IS tap number (C == CE)
       const int tap = ok ? c0 / CE + ch : 0;
       chb_dh[j] = tdh[tap]; chb_dw[j] = tdw[tap];
       chb_off[j] = ok ? 0u : OOB;
@@ -156,6 +160,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
       chb_off[j] = ok ? (unsigned)((c0 + ch * CE) * ES) : OOB;
     }
   }
+  if (IC) __syncthreads();                    // the tables are dead: the staging buffer may be written
 
   uint4 ra[NJA], rb[NJB];
   auto load_tile = [&](int it) {
@@ -174,7 +179,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < NJA; ++j) ra[j] = bload(ydesc, (yoff != OOB && cha_off[j] != OOB) ? yoff + cha_off[j] : OOB);
-    if (!a.im2col) {
+    if constexpr (!IC) {
 #pragma unroll
       for (int j = 0; j < NJB; ++j) rb[j] = bload(xdesc, (xoff != OOB && chb_off[j] != OOB) ? xoff + chb_off[j] : OOB);
     } else {
@@ -234,7 +239,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 #pragma unroll
       for (int j = 0; j < TJ; ++j) {
         const int c = c0 + chb + 16 * j + (lane & 15);
-        if (a.im2col) { if (c < a.RS * a.C) out[(size_t)k * a.RS * a.C + c] = acc[i][j][r]; }
+        if (IC) { if (c < a.RS * a.C) out[(size_t)k * a.RS * a.C + c] = acc[i][j][r]; }
         else if (c < a.C) out[((size_t)k * a.RS + t) * a.C + c] = acc[i][j][r];
       }
     }
@@ -271,6 +276,8 @@ inline int pick_tile(int n) {       // block tile edge from {160,128,64,32}: few
   return best;
 }
 
+constexpr int IM2COL_BC = 160;
+inline int col_tile(const rn_conv_geom* g, bool ic) { return ic ? IM2COL_BC : pick_tile(g->C); }
 inline bool use_im2col(const rn_conv_geom* g, int dtype_ce) { return g->C == dtype_ce && g->R * g->S > 9; }
 
 int wgrad_splits(const rn_conv_geom* g, int bk, int bc, bool im2col = false) {
@@ -284,15 +291,21 @@ int wgrad_splits(const rn_conv_geom* g, int bk, int bc, bool im2col = false) {
   return splits;
 }
 
-template <typename T, int TI, int TJ>
+template <typename T, int TI, int TJ, bool IC = false>
 int launch_w(const WgradArgs& a, hipStream_t s) {
   int grid = a.kt * a.ct * a.nt * a.splits;
-  hipLaunchKernelGGL((wgrad_kernel<T, TI, TJ>), dim3(grid), dim3(256), 0, s, a);
+  hipLaunchKernelGGL((wgrad_kernel<T, TI, TJ, IC>), dim3(grid), dim3(256), 0, s, a);
   RN_CHECK_LAUNCH("wgrad");
   return 0;
 }
 
 template <typename T> int dispatch_w(const WgradArgs& a, int bk, int bc, hipStream_t s) {
+  if (a.im2col) {                                        // column tile fixed at IM2COL_BC
+    if (bk == 160) return launch_w<T, 5, IM2COL_BC / 32, true>(a, s);
+    if (bk == 128) return launch_w<T, 4, IM2COL_BC / 32, true>(a, s);
+    if (bk == 64) return launch_w<T, 2, IM2COL_BC / 32, true>(a, s);
+    return launch_w<T, 1, IM2COL_BC / 32, true>(a, s);
+  }
 #define W_CASE(BK, BC) if (bk == BK && bc == BC) return launch_w<T, BK / 32, BC / 32>(a, s);
   W_CASE(160, 160) W_CASE(160, 128) W_CASE(160, 64) W_CASE(160, 32)
   W_CASE(128, 160) W_CASE(128, 128) W_CASE(128, 64) W_CASE(128, 32)
@@ -310,7 +323,7 @@ extern "C" size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g) {
   size_t best = 0;
   for (int ce : {4, 8}) {                     // the workspace is sized before the dtype is known: take the larger need
     const bool ic = use_im2col(g, ce);
-    const int bk = pick_tile(g->K), bc = pick_tile(ic ? g->R * g->S * g->C : g->C);
+    const int bk = pick_tile(g->K), bc = col_tile(g, ic);
     const size_t need = (size_t)wgrad_splits(g, bk, bc, ic) * g->K * g->R * g->S * g->C * sizeof(float);
     if (need > best) best = need;
   }
@@ -326,7 +339,7 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   RN_CHECK_ARG(g->R == g->S && g->R * g->S <= MAX_TAPS, "rn_conv_wgrad: kernel %dx%d unsupported", g->R, g->S);
   RN_CHECK_ARG((long)g->N * g->P * g->Q < (1L << 31), "rn_conv_wgrad: too many pixels");
   const bool ic = use_im2col(g, ce);
-  const int bk = pick_tile(g->K), bc = pick_tile(ic ? g->R * g->S * g->C : g->C);
+  const int bk = pick_tile(g->K), bc = col_tile(g, ic);
   WgradArgs a{};
   a.im2col = ic ? 1 : 0;
   a.x = x; a.dy = dy;
