@@ -209,11 +209,14 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, c
 }
 
 // dx = a*g + b*x + c per channel:  a = scale, b = -scale*invstd*m1, c = scale*(invstd*m1*mean - m0), m = dsum/count
-template <typename T>
-__global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ mask,
-                                                          const float* __restrict__ coef, const float* __restrict__ dsum, ResDesc add,
-                                                          T* __restrict__ dx, T* __restrict__ g_out, int M, int H, int W, int C, int rows_per_blk,
-                                                          int use_mask, int train, float gscale, float inv_count, uint32_t key, uint32_t thr) {
+// Streaming form of the backward apply.  MASK / ADD are compile-time (no branch inside the row loop, so the loads of the
+// UNR unrolled rows are issued together), the per-channel coefficients are fetched as 16-byte vectors, and a thread
+// streams >= 8 rows (slab_rows_stream) so that fetch amortises.
+template <typename T, int MASK, int ADD, int UNR>
+__global__ __launch_bounds__(NT) void bn_bwd_apply_stream_kernel(const T* __restrict__ dout, const T* __restrict__ x, const T* __restrict__ mask,
+                                                                 const float* __restrict__ coef, const float* __restrict__ dsum, ResDesc add,
+                                                                 T* __restrict__ dx, T* __restrict__ g_out, int M, int H, int W, int C, int rows_per_blk,
+                                                                 int train, float gscale, float inv_count, uint32_t key, uint32_t thr) {
   constexpr int CE = Elem<T>::CE;
   const int CC = C / CE;
   for (int cbase = 0; cbase < CC; cbase += NT) {
@@ -222,42 +225,43 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
     const int c0 = s.cg * CE;
     float ka[CE], kb[CE], kc[CE], sc[CE], sh[CE];
 #pragma unroll
-    for (int e = 0; e < CE; ++e) {
-      const float scale = coef[c0 + e];
-      sc[e] = scale; sh[e] = coef[C + c0 + e];
-      ka[e] = scale * gscale;
+    for (int e = 0; e < CE; e += 4) {
+      const float4 vs = *reinterpret_cast<const float4*>(coef + c0 + e), vh = *reinterpret_cast<const float4*>(coef + C + c0 + e);
+      float4 vm = make_float4(0.f, 0.f, 0.f, 0.f), vi = vm, d0 = vm, d1 = vm;
       if (train) {
-        const float mean = coef[2 * C + c0 + e], invstd = coef[3 * C + c0 + e];
-        const float m0 = dsum[c0 + e] * inv_count, m1 = dsum[C + c0 + e] * inv_count;
-        kb[e] = -scale * invstd * m1;
-        kc[e] = scale * (invstd * m1 * mean - m0);
-      } else {
-        kb[e] = 0.f; kc[e] = 0.f;
+        vm = *reinterpret_cast<const float4*>(coef + 2 * C + c0 + e); vi = *reinterpret_cast<const float4*>(coef + 3 * C + c0 + e);
+        d0 = *reinterpret_cast<const float4*>(dsum + c0 + e); d1 = *reinterpret_cast<const float4*>(dsum + C + c0 + e);
+      }
+      const float a_s[4] = {vs.x, vs.y, vs.z, vs.w}, a_h[4] = {vh.x, vh.y, vh.z, vh.w}, a_m[4] = {vm.x, vm.y, vm.z, vm.w};
+      const float a_i[4] = {vi.x, vi.y, vi.z, vi.w}, a_0[4] = {d0.x, d0.y, d0.z, d0.w}, a_1[4] = {d1.x, d1.y, d1.z, d1.w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        // explicit roundings (no compiler-chosen contraction): every instantiation derives bit-identical coefficients
+        const float scale = a_s[q];
+        sc[e + q] = scale; sh[e + q] = a_h[q];
+        ka[e + q] = __fmul_rn(scale, gscale);
+        const float m0 = __fmul_rn(a_0[q], inv_count), m1 = __fmul_rn(a_1[q], inv_count);
+        const float im1 = __fmul_rn(a_i[q], m1);
+        kb[e + q] = train ? -__fmul_rn(scale, im1) : 0.f;
+        kc[e + q] = train ? __fmul_rn(scale, __fmaf_rn(im1, a_m[q], -m0)) : 0.f;
       }
     }
-#pragma unroll 2
-    for (int r = s.r_begin + s.rl; r < s.r_end; r += s.lanes) {
-      const size_t off = (size_t)r * C + c0;
-      Chunk<T> cd = load_chunk<T>(dout + off);
-      Chunk<T> cx = load_chunk<T>(x + off);
-      Chunk<T> cm;
-      if (use_mask == 1) cm = load_chunk<T>(mask + off);
+    const int hw = H * W;
+    auto one = [&](size_t off, int r, const Chunk<T>& cd, const Chunk<T>& cx, const Chunk<T>& cm, const Chunk<T>& cr) {
       float v[CE], g[CE];
 #pragma unroll
       for (int e = 0; e < CE; ++e) {
         float gg = Elem<T>::to_f(cd.e[e]);
         const float xv = Elem<T>::to_f(cx.e[e]);
-        if (use_mask == 1 && !(Elem<T>::to_f(cm.e[e]) > 0.f)) gg = 0.f;
-        if (use_mask == 2 && (!(fmaf(xv, sc[e], sh[e]) > 0.f) || (thr && !rn_keep(key, (uint32_t)(off + e), thr)))) gg = 0.f;
-        g[e] = gg * gscale;
-        v[e] = fmaf(ka[e], gg, fmaf(kb[e], xv, kc[e]));
+        if (MASK == 1 && !(Elem<T>::to_f(cm.e[e]) > 0.f)) gg = 0.f;
+        if (MASK == 2 && (!(fmaf(xv, sc[e], sh[e]) > 0.f) || (thr && !rn_keep(key, (uint32_t)(off + e), thr)))) gg = 0.f;
+        g[e] = __fmul_rn(gg, gscale);
+        v[e] = __fmaf_rn(ka[e], gg, __fmaf_rn(kb[e], xv, kc[e]));
       }
-      if (add.mode == RN_RES_SAME) {
-        Chunk<T> cr = load_chunk<T>(reinterpret_cast<const T*>(add.ptr) + off);
+      if (ADD == 1) {
 #pragma unroll
         for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cr.e[e]);
-      } else if (add.mode != RN_RES_NONE) {
-        const int hw = H * W;
+      } else if (ADD == 2) {
         const int n = r / hw, rem = r - n * hw;
         const int h = rem / W, w = rem - h * W;
         res_add_chunk<T>(add, n, h, w, c0, v);
@@ -271,9 +275,31 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_kernel(const T* __restrict__ 
         for (int e = 0; e < CE; ++e) co.e[e] = Elem<T>::from_f(g[e]);
         store_chunk<T>(g_out + off, co);
       }
+    };
+    int r = s.r_begin + s.rl;
+    for (; r + (UNR - 1) * s.lanes < s.r_end; r += UNR * s.lanes) {
+      Chunk<T> cd[UNR], cx[UNR], cm[UNR], cr[UNR];
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) {
+        const size_t off = (size_t)(r + u * s.lanes) * C + c0;
+        cd[u] = load_chunk<T>(dout + off);
+        cx[u] = load_chunk<T>(x + off);
+        if (MASK == 1) cm[u] = load_chunk<T>(mask + off);
+        if (ADD == 1) cr[u] = load_chunk<T>(reinterpret_cast<const T*>(add.ptr) + off);
+      }
+#pragma unroll
+      for (int u = 0; u < UNR; ++u) one((size_t)(r + u * s.lanes) * C + c0, r + u * s.lanes, cd[u], cx[u], cm[u], cr[u]);
+    }
+    for (; r < s.r_end; r += s.lanes) {
+      const size_t off = (size_t)r * C + c0;
+      Chunk<T> cd = load_chunk<T>(dout + off), cx = load_chunk<T>(x + off), cm, cr;
+      if (MASK == 1) cm = load_chunk<T>(mask + off);
+      if (ADD == 1) cr = load_chunk<T>(reinterpret_cast<const T*>(add.ptr) + off);
+      one(off, r, cd, cx, cm, cr);
     }
   }
 }
+
 
 template <typename T>
 __global__ __launch_bounds__(NT) void dropout_fwd_kernel(const T* __restrict__ x, T* __restrict__ out, long nchunks, float inv_keep, uint32_t key,
@@ -331,6 +357,33 @@ inline int slab_rows(long M, int C, int ce) {
   long rows = (M + blocks - 1) / blocks;
   rows = (rows + lanes - 1) / lanes * lanes;
   return (int)rows;
+}
+
+// streaming passes: >= 8 rows per thread (16 when that still leaves >= 1024 workgroups)
+inline int slab_rows_stream(long M, int C, int ce) {
+  const int CC = C / ce;
+  const int lanes = CC >= NT ? 1 : NT / CC;
+  long rpt = M / ((long)lanes * 1024);
+  if (rpt > 16) rpt = 16;
+  if (rpt < 8) rpt = 8;
+  long rows = (long)lanes * rpt;
+  if (rows > M) rows = (M + lanes - 1) / lanes * lanes;
+  return (int)rows;
+}
+
+template <typename T, int MASK, int ADD>
+void launch_bwd_apply_stream(int grid, hipStream_t st, const void* dout, const void* x, const void* mask, const float* coef, const float* dsum, const ResDesc& r,
+                             void* dx, void* g, int M, int H, int W, int C, int rows, int train, float gscale, float inv_count, uint32_t key, uint32_t thr) {
+  hipLaunchKernelGGL((bn_bwd_apply_stream_kernel<T, MASK, ADD, 4>), dim3(grid), dim3(NT), 0, st, (const T*)dout, (const T*)x, (const T*)mask, coef, dsum, r, (T*)dx, (T*)g,
+                     M, H, W, C, rows, train, gscale, inv_count, key, thr);
+}
+template <typename T>
+void dispatch_bwd_apply_stream(int use_mask, int add_kind, int grid, hipStream_t st, const void* dout, const void* x, const void* mask, const float* coef,
+                               const float* dsum, const ResDesc& r, void* dx, void* g, int M, int H, int W, int C, int rows, int train, float gscale,
+                               float inv_count, uint32_t key, uint32_t thr) {
+#define BA_CASE(MK, AD) if (use_mask == MK && add_kind == AD) return launch_bwd_apply_stream<T, MK, AD>(grid, st, dout, x, mask, coef, dsum, r, dx, g, M, H, W, C, rows, train, gscale, inv_count, key, thr);
+  BA_CASE(0, 0) BA_CASE(0, 1) BA_CASE(0, 2) BA_CASE(1, 0) BA_CASE(1, 1) BA_CASE(1, 2) BA_CASE(2, 0) BA_CASE(2, 1) BA_CASE(2, 2)
+#undef BA_CASE
 }
 
 inline int ew_grid(long nchunks) {
@@ -449,12 +502,11 @@ extern "C" int rn_bn_bwd_apply(const void* dout, const void* x, const void* mask
   const float inv_count = (float)(1.0 / count);
   RN_CHECK_ARG(M < (1L << 31), "rn_bn_bwd_apply: too many pixels");
   (void)nchunks;
-  const int rows = slab_rows(M, C, ce);
+  const int rows = slab_rows_stream(M, C, ce);
   const int grid = cdiv(M, rows);
-  if (dtype == RN_F32)
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<float>), dim3(grid), dim3(NT), 0, as_stream(s), (const float*)dout, (const float*)x, (const float*)mask_src, coef, dsum, r, (float*)dx, (float*)g, (int)M, H, W, C, rows, use_mask, train, gscale, inv_count, key, thr);
-  else
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<bf16_t>), dim3(grid), dim3(NT), 0, as_stream(s), (const bf16_t*)dout, (const bf16_t*)x, (const bf16_t*)mask_src, coef, dsum, r, (bf16_t*)dx, (bf16_t*)g, (int)M, H, W, C, rows, use_mask, train, gscale, inv_count, key, thr);
+  const int add_kind = r.mode == RN_RES_NONE ? 0 : (r.mode == RN_RES_SAME ? 1 : 2);
+  if (dtype == RN_F32) dispatch_bwd_apply_stream<float>(use_mask, add_kind, grid, as_stream(s), dout, x, mask_src, coef, dsum, r, dx, g, (int)M, H, W, C, rows, train, gscale, inv_count, key, thr);
+  else dispatch_bwd_apply_stream<bf16_t>(use_mask, add_kind, grid, as_stream(s), dout, x, mask_src, coef, dsum, r, dx, g, (int)M, H, W, C, rows, train, gscale, inv_count, key, thr);
   RN_CHECK_LAUNCH("bn_bwd_apply");
   return 0;
 }
