@@ -278,7 +278,7 @@ inline int pick_tile(int n) {       // block tile edge from {160,128,64,32}: few
 
 constexpr int IM2COL_BC = 160;
 inline int col_tile(const rn_conv_geom* g, bool ic) { return ic ? IM2COL_BC : pick_tile(g->C); }
-inline bool use_im2col(const rn_conv_geom* g, int dtype_ce) { return g->C == dtype_ce && g->R * g->S > 9; }
+inline bool use_im2col(const rn_conv_geom* g, int dtype_ce) { return g->C == dtype_ce && g->R * g->S >= 4; }   // one-chunk inputs: the stem
 
 int wgrad_splits(const rn_conv_geom* g, int bk, int bc, bool im2col = false) {
   const long M = (long)g->N * g->P * g->Q;

@@ -14,6 +14,7 @@ Weight gradients are produced in the order recorded in ``Plan.grad_order`` so th
 all-reduced bucket by bucket while the backward is still running.
 """
 from dataclasses import dataclass, field
+import os
 from typing import Dict, List, Optional, Tuple
 
 from ..architectures.spec import Component, block_convs, parse_spec
@@ -66,7 +67,7 @@ def conv_stats_rows(g: dict, dgrad: bool = False) -> int:
 
 def bn_partials(M: int, C: int) -> int:
     """number of row-slabs a statistics pass is split into (one workgroup each)."""
-    rows_per = 256
+    rows_per = min(256, max(32, M // 512))        # >= 256 workgroups once M >= 8192
     return max(1, min(1024, (M + rows_per - 1) // rows_per))
 
 
@@ -408,9 +409,9 @@ class Lowering:
                 xt = T(xin, self.N, self.H, self.W, c.cin)
                 w, b = self.param(pre + '.weight', (c.cout, k, k, c.cin)), self.param(pre + '.bias', (c.cout,))
                 CP = 4 if self.fp32 else 8
-                if k * k * c.cin >= 64 and c.cin <= CP:
-                    # MFMA route (7x7 ImageNet stem, GEMM-K = 147): NHWC image with the channels zero-padded to one 16-byte
-                    # chunk, then the implicit-GEMM kernels with bias (+ BN statistics) in the epilogue
+                if c.cin <= CP and c.cout % 16 == 0 and os.environ.get('RN_VALU_STEM', '0') != '1':
+                    # MFMA route: NHWC image with the channels zero-padded to one 16-byte chunk, then the implicit-GEMM
+                    # kernels with bias (+ BN statistics) in the epilogue and the im2col wgrad (dy read once)
                     xp = self.act(pre + ':xpad', self.N, self.H, self.W, CP)
                     self.fwd.append(Op(ir.OP_IMG_TO_NHWC, buf=dict(x=xin, out=xp.s), dim=dict(N=self.N, C=c.cin, H=self.H, W=self.W, CP=CP), note=pre))
                     wp = self.slot(pre + ':wpad', 'act', (c.cout, k * k, CP), 'T')

@@ -134,8 +134,8 @@ def test_plan_with_fused_dgrad_reduction(golden):
 def test_plan_structure_wrn():
     plan = lower('c3,160,3,1,1 r4 r4 r4 n a ap8,1,0 fc640,10', True, True, 0.3, 128, 32, 32, fp32=False)
     kinds = [op.kind for op in plan.ops]
-    assert kinds.count(ir.OP_CONV_FWD) == 26 and kinds.count(ir.OP_STEM_FWD) == 1     # 27 convs
-    assert kinds.count(ir.OP_BN_FINALIZE) == 25 and kinds.count(ir.OP_CONV_WGRAD) == 26
+    assert kinds.count(ir.OP_CONV_FWD) == 27 and kinds.count(ir.OP_STEM_FWD) == 0     # 27 convs, stem on the MFMA route
+    assert kinds.count(ir.OP_BN_FINALIZE) == 25 and kinds.count(ir.OP_CONV_WGRAD) == 27
     assert len(plan.grad_order) == len(plan.param_keys) == 80                       # 80 param tensors
     n = sum(s.numel for s in plan.slots if s.role == 'param')
     assert n == 36688330
