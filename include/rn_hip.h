@@ -97,6 +97,8 @@ const char* rn_last_error(void);
 int rn_version(void);
 /* kernel-variant switch for A/B measurements (tools/conv_bench.py; bits documented in csrc/conv_igemm.hip); 0 = shipped */
 void rn_set_variant(int v);
+/* diagnostic builds only: device buffer [grid][16] of u64 s_memtime stamps written by the implicit-GEMM kernels (NULL = off) */
+void rn_set_stamp_buffer(void* device_u64);
 
 /* ---- plan executor: the per-batch forward / backward of ResNet.forward as ONE host call each ---- */
 int rn_plan_create(const rn_op* ops, int n_ops, int n_bufs, int dtype, rn_plan** out);

@@ -22,6 +22,8 @@ int g_rn_variant = 0;   // tuning switch (tools/conv_bench.py): bit0 LDS-patch 3
                         // double-buffering, bit2 256-row 8-wave tile, bit3 register-staged kernel, bit4 4-stage 64-byte-row DMA ring,
                         // bit6 DMA source-window timing probe, bit7 force wave-specialised kernel (bit8: 4 stages), bit9 never use it
 extern "C" void rn_set_variant(int v) { g_rn_variant = v; }
+static void* g_rn_stamps = nullptr;
+extern "C" void rn_set_stamp_buffer(void* p) { g_rn_stamps = p; }
 
 #define RN_CONV_CHECK_EP RN_CHECK_ARG(!ep || ((ep->partial || ep->bias) && !ep->bn_x), "rn_conv_fwd: the forward epilogue takes `partial` and/or `bias`");
 
@@ -40,6 +42,8 @@ struct IgemmArgs {
   int Hd, Wd, Kd;
   int ss, ds, oh, ow;
   int nt, wrs, cpt, nk;
+  int nth, ntw;            // the taps form an nth x ntw grid (tap = i * ntw + j): validity is separable in (dh_i, dw_j)
+  unsigned magic_pq, magic_q;   // floor(2^32 / (Pc*Qc)), floor(2^32 / Qc): division by multiply-high + one correction (fill_magic)
   int accum;
   int dh[MAX_TAPS], dw[MAX_TAPS], widx[MAX_TAPS];
   // fused epilogues (rn_conv_epilogue): per-M-tile partial sums written to stats[(tile_base + m-tile)][2][Kd]
@@ -51,7 +55,14 @@ struct IgemmArgs {
   int tile_base;
   const float* bias;       // per-output-channel bias added in the epilogue (stem convolution), or NULL
   unsigned probe_mask;     // timing probe (rn_set_variant bit6): AND-mask on DMA source offsets, 0xFFFFFFFF in production
+  unsigned long long* stamps;   // diagnostic: per-workgroup s_memtime stamps [grid][16] (rn_set_stamp_buffer), NULL in production
+  int probe_ep;            // timing probes: 1 = skip the global stores of the epilogue, 2 = skip the epilogue
 };
+
+__device__ inline void stamp(const unsigned long long* base_c, int slot) {
+  unsigned long long* base = const_cast<unsigned long long*>(base_c);
+  if (base && threadIdx.x == 0) base[(size_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+}
 
 template <typename T> struct Mfma;
 template <> struct Mfma<float> {
@@ -81,11 +92,20 @@ template <> struct Mfma<bf16_t> {
 template <typename T, int BM, int BN, int WM, int WN, int TM, int TN>
 __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int wave, int lane, float* lds_f,
                                       bool active = true, int nthreads = WM * WN * 64) {
+  if (a.probe_ep >= 2) {                       // keep every accumulator live (no dead-code elimination of the MFMAs)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+    if (a.probe_ep == 2) return;
+  }
   constexpr int CE = Elem<T>::CE;
   constexpr int HR = 64;                       // rows per half
   constexpr int LDC = BN + 4;                  // fp32 row stride of the staged tile
   constexpr int CCN = BN / CE;                 // output chunks per row
-  static_assert(BM % HR == 0 && BN % CE == 0, "epilogue tile");
+  static_assert(BM % (2 * HR) == 0 && 2 * HR == RN_CONV_STATS_ROWS && BN % CE == 0, "epilogue tile");
   float* ctile = lds_f;                        // [HR][LDC]
   float* red = lds_f + HR * LDC;               // [row lanes][2][BN]
   const int wm = wave / WN, wn = wave % WN;
@@ -109,10 +129,11 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
     if (colok && a.bias) bias[e] = a.bias[k0 + e];
   }
   __syncthreads();                             // every wave is done with the K-loop staging memory
+  stamp(a.stamps, 2);
 #pragma unroll 1
   for (int half = 0; half < BM / HR; ++half) {
     // ---- phase 1: the waves whose rows fall into this half park their accumulators (fp32) ----
-    if (active) {
+    if (active && a.probe_ep != 3) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int rbase = wm * (BM / WM) + 32 * i;
@@ -127,8 +148,9 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
       }
     }
     __syncthreads();
+    stamp(a.stamps, 3 + 2 * (half & 1));
     // ---- phase 2: column-fixed threads, 16-byte chunks ----
-    if (colok) {
+    if (colok && a.probe_ep != 4) {
       for (int row = rl; row < HR; row += lanes) {
         const int m = m0 + half * HR + row;
         if (m >= a.M) break;
@@ -168,7 +190,7 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
         Chunk<T> st;
 #pragma unroll
         for (int e = 0; e < CE; ++e) st.e[e] = Elem<T>::from_f(v[e]);
-        store_chunk<T>(dst + off, st);
+        if (a.probe_ep != 1 || st.u.x == 0x12345678u) store_chunk<T>(dst + off, st);
         if (want_stats) {
           if (!bn_bwd) {
 #pragma unroll
@@ -188,22 +210,30 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
         }
       }
     }
-    __syncthreads();                           // ctile is reused by the next half / by `red`
-  }
-  if (!want_stats) return;
-  if (p2) {
+    if (want_stats && (half & 1)) {            // one partial row per RN_CONV_STATS_ROWS (= 2 halves) output rows
+      if (p2) {
 #pragma unroll
-    for (int e = 0; e < CE; ++e) { red[(rl * 2 + 0) * BN + cg * CE + e] = s0[e]; red[(rl * 2 + 1) * BN + cg * CE + e] = s1[e]; }
-  }
-  __syncthreads();
-  for (int col = tid; col < BN; col += nthreads) {
-    const int k = n0 + col;
-    if (k >= a.Kd) continue;
-    float t0 = 0.f, t1 = 0.f;
-    for (int w = 0; w < lanes; ++w) { t0 += red[(w * 2 + 0) * BN + col]; t1 += red[(w * 2 + 1) * BN + col]; }
-    float* out = a.stats + ((size_t)(a.tile_base + m0 / BM) * 2) * a.Kd;
-    out[k] = t0;
-    out[a.Kd + k] = t1;
+        for (int e = 0; e < CE; ++e) {
+          red[(rl * 2 + 0) * BN + cg * CE + e] = s0[e]; red[(rl * 2 + 1) * BN + cg * CE + e] = s1[e];
+          s0[e] = s1[e] = 0.f;
+        }
+      }
+      __syncthreads();
+      const int grp = half >> 1;
+      if (m0 + grp * 2 * HR < a.M) {
+        for (int col = tid; col < BN; col += nthreads) {
+          const int k = n0 + col;
+          if (k >= a.Kd) continue;
+          float t0 = 0.f, t1 = 0.f;
+          for (int w = 0; w < lanes; ++w) { t0 += red[(w * 2 + 0) * BN + col]; t1 += red[(w * 2 + 1) * BN + col]; }
+          float* out = a.stats + ((size_t)(a.tile_base + m0 / (2 * HR) + grp) * 2) * a.Kd;
+          out[k] = t0;
+          out[a.Kd + k] = t1;
+        }
+      }
+    }
+    __syncthreads();                           // ctile (and `red`) are reused by the next half
+    stamp(a.stamps, 4 + 2 * (half & 1));
   }
 }
 
@@ -417,6 +447,64 @@ __device__ inline void dma16(v4i32 desc, unsigned voff, unsigned lds_addr) {
                : "memory");
 }
 
+
+// ---- row decode + tap tables shared by the DMA kernels -------------------------------------------------------------------
+// LDS tap tables (ints): [0..63] source byte offset of a tap, [64..127] weight byte offset, [128..191] (dh << 16) | (dw & 0xFFFF).
+// The per-row validity masks read the packed (dh, dw) from LDS four taps at a time: looping over the kernel-argument
+// arrays instead costs two dependent scalar loads per tap and row (measured: 5.3 us of a 41 us tile on WRN-28-10's first stage).
+constexpr int TAP_INTS = 192;
+template <int ES>
+__device__ inline void fill_tap_tables(const IgemmArgs& a, int* taps) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const bool ok = tid < a.nt;
+    const int t = ok ? tid : 0;
+    const int dh = a.dh[t], dw = a.dw[t];
+    taps[tid] = ok ? (dh * a.Ws + dw) * a.Cs * ES : 0;
+    taps[64 + tid] = ok ? a.widx[t] * a.Cs * ES : 0;
+    taps[128 + tid] = ok ? ((dh << 16) | (dw & 0xFFFF)) : 0x40004000;      // padding taps: far out of range
+  }
+}
+__device__ inline void decode_row(const IgemmArgs& a, int m, int pq, int& n, int& pp, int& q) {
+  n = (int)__umulhi((unsigned)m, a.magic_pq);
+  int rem = m - n * pq;
+  if (rem >= pq) { ++n; rem -= pq; }
+  pp = (int)__umulhi((unsigned)rem, a.magic_q);
+  q = rem - pp * a.Qc;
+  if (q >= a.Qc) { ++pp; q -= a.Qc; }
+}
+// tap (i, j) reads source pixel (hb + dh_i, wb + dw_j): in range iff its row AND its column are, so nth + ntw checks per
+// output row, on lists fetched from LDS ONCE per thread (14 independent reads, one wait): per-row LDS reads serialise on
+// their s_waitcnt and made this setup 2.4 us of a 41 us tile
+constexpr int MAX_GRID = 7;                    // MAX_TAPS = 7 x 7
+struct TapGrid { int dh[MAX_GRID], dw[MAX_GRID]; };
+__device__ inline void load_tap_grid(const IgemmArgs& a, const int* taps, TapGrid& g) {
+#pragma unroll
+  for (int j = 0; j < MAX_GRID; ++j) {
+    const int v = taps[128 + j];
+    g.dw[j] = j < a.ntw ? (int)(short)(v & 0xFFFF) : 0x4000;
+  }
+#pragma unroll
+  for (int i = 0; i < MAX_GRID; ++i) {
+    const int v = taps[128 + min(i * a.ntw, 63)];
+    g.dh[i] = i < a.nth ? (v >> 16) : 0x4000;
+  }
+}
+__device__ inline unsigned long long tap_mask(const IgemmArgs& a, const TapGrid& g, int hb, int wb) {
+  unsigned colbits = 0;
+#pragma unroll
+  for (int j = 0; j < MAX_GRID; ++j)
+    if ((unsigned)(wb + g.dw[j]) < (unsigned)a.Ws) colbits |= 1u << j;
+  unsigned long long mk = 0;
+  int sh = 0;
+#pragma unroll
+  for (int i = 0; i < MAX_GRID; ++i) {
+    if ((unsigned)(hb + g.dh[i]) < (unsigned)a.Hs) mk |= (unsigned long long)colbits << sh;
+    sh += a.ntw;
+  }
+  return mk;
+}
+
 template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 // NSTG LDS stages form a ring: at iteration `it` the DMA of tile it+NSTG-1 is issued while tile `it` is multiplied, so a
@@ -436,12 +524,14 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_dma_kernel(const IgemmArgs
   constexpr int PER = AI + BI;
   constexpr int KS = CPRT / 2;
   constexpr int NST = CPRT == 8 ? 2 : 1;               // distinct logical chunk columns a lane serves
-  constexpr int STAGE = (BM + NW * BI * RPI) * CPRT;   // uint4 per stage (B region padded)
+  constexpr bool BDUMMY = NW * BI > BIT;               // padding DMAs (equal instruction count per wave) land in one shared dummy KiB
+  constexpr int STAGE = (BM + BN) * CPRT + (BDUMMY ? 64 : 0);   // uint4 per stage
   static_assert((NW == 4 || NW == 8) && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && AIT % NW == 0 && BN % RPI == 0 && NSTG >= 2 && NSTG <= 4, "tile");
-  __shared__ uint4 smem[NSTG * STAGE + 32];
-  int* taps = reinterpret_cast<int*>(&smem[NSTG * STAGE]);     // [0..48] source byte offset of tap, [64..112] weight byte offset
+  __shared__ uint4 smem[NSTG * STAGE + TAP_INTS / 4];
+  int* taps = reinterpret_cast<int*>(&smem[NSTG * STAGE]);     // fill_tap_tables
 
   const int tid = threadIdx.x, lane = tid & 63;
+  stamp(a.stamps, 0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: feeds M0 / SGPR operands
   const int nmt = (a.M + BM - 1) / BM;
   const int mt = blockIdx.x % nmt, ntile = blockIdx.x / nmt;
@@ -456,31 +546,27 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_dma_kernel(const IgemmArgs
   const v4i32 rb_desc = make_desc(a.wt, w_total);
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);           // LDS byte address of the ring
 
-  if (tid <= MAX_TAPS) {
-    int t = tid < a.nt ? tid : 0;
-    taps[tid] = tid < a.nt ? (a.dh[t] * a.Ws + a.dw[t]) * a.Cs * ES : 0;
-    taps[64 + tid] = tid < a.nt ? a.widx[t] * a.Cs * ES : 0;
-  }
+  stamp(a.stamps, 10);
+  fill_tap_tables<ES>(a, taps);
+  __syncthreads();          // tap tables visible (no DMA in flight yet)
+  stamp(a.stamps, 9);
 
   // ---- per-lane DMA roles ----
   const int lrow = lane / CPRT, p = lane % CPRT;
   unsigned abase[AI];
   unsigned long long amask[AI];
+  TapGrid grid;
+  load_tap_grid(a, taps, grid);
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
     const int m = m0 + RPI * (wave * AI + i) + lrow;
     amask[i] = 0; abase[i] = 0;
     if (m < a.M) {
-      int n = m / pq, rem = m - n * pq;
-      int pp = rem / a.Qc, q = rem - pp * a.Qc;
-      int hb = pp * a.ss, wb = q * a.ss;
+      int n, pp, q;
+      decode_row(a, m, pq, n, pp, q);
+      const int hb = pp * a.ss, wb = q * a.ss;
       abase[i] = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES);
-      unsigned long long mk = 0;
-      for (int t = 0; t < a.nt; ++t) {
-        int h = hb + a.dh[t], w = wb + a.dw[t];
-        if ((unsigned)h < (unsigned)a.Hs && (unsigned)w < (unsigned)a.Ws) mk |= 1ull << t;
-      }
-      amask[i] = mk;
+      amask[i] = tap_mask(a, grid, hb, wb);
     }
   }
   unsigned bbase[BI];
@@ -498,7 +584,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_dma_kernel(const IgemmArgs
     tapk[k] = 0;
     while (cck[k] >= a.cpt) { cck[k] -= a.cpt; ++tapk[k]; }
   }
-  __syncthreads();          // tap tables visible (no DMA in flight yet)
+  stamp(a.stamps, 7);
 
   auto dma_tile = [&](int stg) {
     unsigned so[NST], wo[NST];
@@ -524,7 +610,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_dma_kernel(const IgemmArgs
       const int j = wave * BI + i;
       const int k = NST == 2 ? (j & 1) : 0;
       const unsigned off = (kv[k] && bbase[i] != OOB) ? ((bbase[i] + wo[k]) & a.probe_mask) : OOB;
-      dma16(rb_desc, off, base + BM * CPRT * 16 + j * 1024);
+      dma16(rb_desc, off, base + (j < BIT ? BM * CPRT * 16 + j * 1024 : (BM + BN) * CPRT * 16));
     }
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
@@ -549,11 +635,13 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_dma_kernel(const IgemmArgs
 #pragma unroll
   for (int t = 0; t < NSTG - 1; ++t)
     if (t < a.nk) dma_tile(t);
+  stamp(a.stamps, 8);
   {
     const int inflight = min(a.nk, NSTG - 1) - 1;      // groups allowed to stay outstanding behind tile 0
     if (inflight >= 2) wait_vmcnt<2 * PER>(); else if (inflight == 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
   }
   __builtin_amdgcn_s_barrier();
+  stamp(a.stamps, 1);
   int stg = 0;
   for (int it = 0; it < a.nk; ++it) {
     const uint4* cur_s = &smem[stg * STAGE];
@@ -599,7 +687,7 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_dma_kernel(const IgemmArgs
 // (MI355X_MICROARCH.md "Two waves per SIMD": matrix beside memory is the complementary pairing).
 // ---------------------------------------------------------------------------------------------------------------------
 template <typename T, int BM, int BN, int WM, int WN, int CPRT, int NSTG>
-__global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
+__global__ __launch_bounds__(512, BM >= 256 ? 1 : 2) void igemm_ws_kernel(const IgemmArgs a) {
   constexpr int ES = (int)sizeof(T);
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
   constexpr int RPI = 64 / CPRT;
@@ -610,7 +698,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
   constexpr int STAGE = (BM + 4 * BI * RPI) * CPRT;
   constexpr int PER = AI + BI;                         // DMA instructions per loader wave per tile
   static_assert(WM * WN == 4 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && AIT % 4 == 0 && BN % RPI == 0, "tile");
-  __shared__ uint4 smem[NSTG * STAGE + 32];
+  __shared__ uint4 smem[NSTG * STAGE + TAP_INTS / 4];
   int* taps = reinterpret_cast<int*>(&smem[NSTG * STAGE]);
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -621,11 +709,7 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
   const int m0 = mt * BM, n0 = ntile * BN;
   const int pq = a.Pc * a.Qc;
 
-  if (tid <= MAX_TAPS) {
-    int t = tid < a.nt ? tid : 0;
-    taps[tid] = tid < a.nt ? (a.dh[t] * a.Ws + a.dw[t]) * a.Cs * ES : 0;
-    taps[64 + tid] = tid < a.nt ? a.widx[t] * a.Cs * ES : 0;
-  }
+  fill_tap_tables<ES>(a, taps);
   __syncthreads();
 
   f32x16 acc[TM][TN];
@@ -639,21 +723,18 @@ __global__ __launch_bounds__(512, 2) void igemm_ws_kernel(const IgemmArgs a) {
     const int lrow = lane / CPRT, p = lane % CPRT;
     unsigned abase[AI], bbase[BI];
     unsigned long long amask[AI];
+    TapGrid grid;
+    load_tap_grid(a, taps, grid);
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int m = m0 + RPI * (lw * AI + i) + lrow;
       amask[i] = 0; abase[i] = 0;
       if (m < a.M) {
-        int n = m / pq, rem = m - n * pq;
-        int pp = rem / a.Qc, q = rem - pp * a.Qc;
-        int hb = pp * a.ss, wb = q * a.ss;
+        int n, pp, q;
+        decode_row(a, m, pq, n, pp, q);
+        const int hb = pp * a.ss, wb = q * a.ss;
         abase[i] = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES);
-        unsigned long long mk = 0;
-        for (int t = 0; t < a.nt; ++t) {
-          int h = hb + a.dh[t], w = wb + a.dw[t];
-          if ((unsigned)h < (unsigned)a.Hs && (unsigned)w < (unsigned)a.Ws) mk |= 1ull << t;
-        }
-        amask[i] = mk;
+        amask[i] = tap_mask(a, grid, hb, wb);
       }
     }
 #pragma unroll
@@ -787,6 +868,26 @@ template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   const int K = a.Kd;
   // column tile: the widest of {160,128,96,64,32} that wastes no 32-column MFMA tile
+  if ((g_rn_variant & 4096) && (K % 160 == 0 || K % 128 == 0)) {           // experiment: 256-row tile, 8 homogeneous waves, 3-stage ring
+    const int bn = K % 160 == 0 ? 160 : 128;
+    const int nmt = cdiv(a.M, 256), nnt = K / bn;
+    if (nmt * nnt >= 256) {
+      if (bn == 160) hipLaunchKernelGGL((igemm_dma_kernel<T, 256, 160, 8, 1, 8, 3>), dim3(nmt * nnt), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((igemm_dma_kernel<T, 256, 128, 8, 1, 8, 3>), dim3(nmt * nnt), dim3(512), 0, s, a);
+      RN_CHECK_LAUNCH("igemm_dma256");
+      return 0;
+    }
+  }
+  if ((g_rn_variant & 2048) && (K % 160 == 0 || K % 128 == 0)) {           // experiment: 256-row tile, consumer waves 64 x BN
+    const int bn = K % 160 == 0 ? 160 : 128;
+    const int nmt = cdiv(a.M, 256), nnt = K / bn;
+    if (nmt * nnt >= 256) {
+      if (bn == 160) hipLaunchKernelGGL((igemm_ws_kernel<T, 256, 160, 4, 1, 8, 3>), dim3(nmt * nnt), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((igemm_ws_kernel<T, 256, 128, 4, 1, 8, 3>), dim3(nmt * nnt), dim3(512), 0, s, a);
+      RN_CHECK_LAUNCH("igemm_ws256");
+      return 0;
+    }
+  }
   if (K % 160 == 0) {
     if ((g_rn_variant & 4) && cdiv(a.M, 256) * (K / 160) >= 256) {      // experiment: 256x160 tile shared by 8 waves
       int nmt = cdiv(a.M, 256), nnt = K / 160;
@@ -829,6 +930,12 @@ void fill_res(ResDesc& r, const void* res, int mode, int res_C, int dN, int dH, 
 
 }  // namespace
 
+static void fill_magic(IgemmArgs& a) {
+  const unsigned long long pq = (unsigned long long)a.Pc * a.Qc;
+  a.magic_pq = pq <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / pq);
+  a.magic_q = a.Qc <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned)a.Qc);
+}
+
 static void fill_ep(IgemmArgs& a, const rn_conv_epilogue* ep, int tile_base) {
   a.stats = ep ? ep->partial : nullptr;
   a.bn_x = ep ? ep->bn_x : nullptr;
@@ -838,6 +945,8 @@ static void fill_ep(IgemmArgs& a, const rn_conv_epilogue* ep, int tile_base) {
   a.tile_base = tile_base;
   a.bias = ep ? ep->bias : nullptr;
   a.probe_mask = (g_rn_variant & 64) ? 0x0000FFF0u : 0xFFFFFFFFu;
+  a.stamps = reinterpret_cast<unsigned long long*>(g_rn_stamps);
+  a.probe_ep = (g_rn_variant & 8192) ? 1 : ((g_rn_variant & 16384) ? 2 : ((g_rn_variant & 32768) ? 3 : ((g_rn_variant & 65536) ? 4 : 0)));
 }
 
 extern "C" int rn_conv_stats_rows(const rn_conv_geom* g, int is_dgrad) {
@@ -870,6 +979,7 @@ extern "C" int rn_conv_fwd(const void* x, const void* w_fwd, void* y, const void
   a.Hd = g->P; a.Wd = g->Q; a.Kd = g->K;
   a.ss = g->stride; a.ds = 1; a.oh = a.ow = 0;
   a.nt = g->R * g->S; a.wrs = g->R * g->S;
+  a.nth = g->R; a.ntw = g->S;
   for (int r = 0; r < g->R; ++r)
     for (int t = 0; t < g->S; ++t) {
       int i = r * g->S + t;
@@ -879,6 +989,7 @@ extern "C" int rn_conv_fwd(const void* x, const void* w_fwd, void* y, const void
   a.cpt = g->C / ce;
   a.nk = cdiv((long)a.nt * a.cpt, CPR);
   a.accum = 0;
+  fill_magic(a);
   return dtype == RN_F32 ? launch_igemm<float>(a, as_stream(s)) : launch_igemm<bf16_t>(a, as_stream(s));
 }
 
@@ -920,10 +1031,14 @@ extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, cons
         }
       }
       a.nt = nt;
+      a.nth = 0; a.ntw = 0;
+      for (int r = 0; r < g->R; ++r) if ((pa + g->pad - r) % st == 0) ++a.nth;
+      for (int t = 0; t < g->S; ++t) if ((pb + g->pad - t) % st == 0) ++a.ntw;
       a.cpt = g->K / ce;
       a.nk = cdiv((long)nt * a.cpt, CPR);
       a.accum = (flags & RN_F_ACCUM) ? 1 : 0;
       fill_ep(a, ep, tile_base);
+      fill_magic(a);
       tile_base += cdiv(a.M, RN_CONV_STATS_ROWS);
       if (nt == 0 && a.accum && a.res.mode == RN_RES_NONE && !ep) continue;   // nothing to add to this class (a fused reduction still has to see it)
       int e = dtype == RN_F32 ? launch_igemm<float>(a, as_stream(s)) : launch_igemm<bf16_t>(a, as_stream(s));

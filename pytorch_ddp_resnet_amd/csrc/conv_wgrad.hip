@@ -25,6 +25,7 @@ struct WgradArgs {
   int M;             // N*P*Q
   int splits, rows_per_split;
   int kt, ct;        // tiles along K and C
+  unsigned magic_pq, magic_q;   // floor(2^32 / (P*Q)), floor(2^32 / Q): division by multiply-high + one correction
   int im2col;        // 1: the taps are folded into the column dimension (stem: C = one chunk per tap), dy is read once per column tile
   int dh[MAX_TAPS], dw[MAX_TAPS];
 };
@@ -169,9 +170,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     unsigned xoff = OOB, yoff = OOB;
     int n = 0, h0 = 0, w0 = 0;
     if (mv) {
-      n = m / pq;
-      const int rem = m - n * pq;
-      const int p = rem / a.Q, q = rem - p * a.Q;
+      n = (int)__umulhi((unsigned)m, a.magic_pq);
+      int rem = m - n * pq;
+      if (rem >= pq) { ++n; rem -= pq; }
+      int p = (int)__umulhi((unsigned)rem, a.magic_q), q = rem - p * a.Q;
+      if (q >= a.Q) { ++p; q -= a.Q; }
       h0 = p * a.stride; w0 = q * a.stride;
       const int h = h0 + dht, w = w0 + dwt;
       yoff = (unsigned)(((size_t)(m - n_first * pq)) * a.K * ES);
@@ -342,6 +345,11 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   const int bk = pick_tile(g->K), bc = col_tile(g, ic);
   WgradArgs a{};
   a.im2col = ic ? 1 : 0;
+  {
+    const unsigned long long pq = (unsigned long long)g->P * g->Q;
+    a.magic_pq = pq <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / pq);
+    a.magic_q = g->Q <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned)g->Q);
+  }
   a.x = x; a.dy = dy;
   a.N = g->N; a.H = g->H; a.W = g->W; a.C = g->C; a.P = g->P; a.Q = g->Q; a.K = g->K;
   a.stride = g->stride; a.RS = g->R * g->S; a.nt = ic ? 1 : a.RS;

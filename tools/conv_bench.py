@@ -15,24 +15,26 @@ L.rn_conv_dgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, 
 L.rn_conv_wgrad.argtypes = [vp, vp, vp, vp, C.c_size_t, C.c_int, C.c_int, C.POINTER(_lib.RnConvGeom), vp]
 L.rn_set_variant.argtypes = [C.c_int]
 
-SHAPES = [(128, 32, 32, 160, 160), (128, 16, 16, 320, 320), (128, 8, 8, 640, 640)]
+SHAPES = [(128, 32, 32, 160, 160, 3), (128, 16, 16, 320, 320, 3), (128, 8, 8, 640, 640, 3)]
+if os.environ.get('RN_CONV_SHAPES'):          # "N,H,W,C,K,k;..."
+    SHAPES = [tuple(int(v) for v in sh.split(',')) for sh in os.environ['RN_CONV_SHAPES'].split(';')]
 
 
 def run(which, iters, variants, dtype=torch.bfloat16):
     st = vp(torch.cuda.current_stream().cuda_stream)
-    for (N, H, W, Cc, K) in SHAPES:
-        g = _lib.RnConvGeom(N, H, W, Cc, H, W, K, 3, 3, 1, 1)
+    for (N, H, W, Cc, K, ks) in SHAPES:
+        g = _lib.RnConvGeom(N, H, W, Cc, H, W, K, ks, ks, 1, ks // 2)
         x = torch.randn(N, H, W, Cc, device='cuda').to(dtype)
-        w = (torch.randn(K, 9, Cc, device='cuda') * 0.05).to(dtype)
-        wd = (torch.randn(Cc, 9, K, device='cuda') * 0.05).to(dtype)
+        w = (torch.randn(K, ks * ks, Cc, device='cuda') * 0.05).to(dtype)
+        wd = (torch.randn(Cc, ks * ks, K, device='cuda') * 0.05).to(dtype)
         y = torch.empty(N, H, W, K, device='cuda', dtype=dtype)
         dy = torch.randn(N, H, W, K, device='cuda').to(dtype)
         dx = torch.empty(N, H, W, Cc, device='cuda', dtype=dtype)
-        dw = torch.empty(K, 9, Cc, device='cuda')
+        dw = torch.empty(K, ks * ks, Cc, device='cuda')
         wsb = int(L.rn_conv_wgrad_ws_bytes(C.byref(g)))
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device='cuda')
         rn = 1 if dtype == torch.bfloat16 else 0
-        flops = 2.0 * N * H * W * K * 9 * Cc
+        flops = 2.0 * N * H * W * K * ks * ks * Cc
         for v in variants:
             L.rn_set_variant(v)
 
@@ -52,7 +54,7 @@ def run(which, iters, variants, dtype=torch.bfloat16):
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) / iters * 1e3
-            print(f'{which} {N}x{H}x{W} C{Cc}->K{K} variant {v}: {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
+            print(f'{which} {N}x{H}x{W} C{Cc}->K{K} k{ks} variant {v}: {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
 
 
 if __name__ == '__main__':
