@@ -438,15 +438,18 @@ __device__ inline v4i32 make_desc(const void* base, size_t bytes) {
 
 // one LDS-DMA wave instruction, invisible to hipcc's waitcnt pass (it would otherwise drain vmcnt(0) before every
 // ds_read of the same array): LDS[m0 + lane*16 .. +16) = desc[voff .. voff+16), zeros when voff is out of range.
-// M0 is saved/restored inside the statement; completion is tracked by the caller's counted s_waitcnt vmcnt.
-__device__ inline void dma16(v4i32 desc, unsigned voff, unsigned lds_addr) {
+// Completion is tracked by the caller's counted s_waitcnt vmcnt.  M0 is saved once before a group of DMAs and restored
+// after it (m0_save / m0_restore): hipcc emits no M0-dependent instruction inside these kernels (checked in the
+// disassembly), the bracket keeps that assumption local to the address arithmetic between two DMAs of one group.
+__device__ inline unsigned m0_save() {
   unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(voff), "s"(desc), "s"(lds_addr)
-               : "memory");
+  asm volatile("s_mov_b32 %0, m0" : "=s"(keep)::"memory");
+  return keep;
 }
-
+__device__ inline void m0_restore(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep) : "memory"); }
+__device__ inline void dma16(v4i32 desc, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(desc), "s"(lds_addr) : "memory");
+}
 
 // ---- row decode + tap tables shared by the DMA kernels -------------------------------------------------------------------
 // LDS tap tables (ints): [0..63] source byte offset of a tap, [64..127] weight byte offset, [128..191] (dh << 16) | (dw & 0xFFFF).
@@ -503,6 +506,52 @@ __device__ inline unsigned long long tap_mask(const IgemmArgs& a, const TapGrid&
     sh += a.ntw;
   }
   return mk;
+}
+
+// position of one logical 16-byte chunk column of a lane in the GEMM-K order (tap-major, then channel chunks), advanced
+// by one K tile per call.  The tap-table lookups for the NEXT tile are issued at the end of advance(): their LDS latency
+// then sits behind a whole K tile of MFMAs instead of in front of the DMA issue.
+template <int CPRT> struct TapWalk {
+  int tapk, cck, tp;
+  unsigned so, wo;
+  bool kv;
+  __device__ inline void fetch(const IgemmArgs& a, const int* taps) {
+    kv = tapk < a.nt;
+    tp = kv ? tapk : 0;
+    so = (unsigned)(taps[tp] + cck * 16);
+    wo = (unsigned)(taps[64 + tp] + cck * 16);
+  }
+  __device__ inline void init(const IgemmArgs& a, const int* taps, int c0) {
+    cck = c0; tapk = 0;
+    while (cck >= a.cpt) { cck -= a.cpt; ++tapk; }
+    fetch(a, taps);
+  }
+  __device__ inline void advance(const IgemmArgs& a, const int* taps) {
+    cck += CPRT;
+    if (a.cpt >= CPRT) {                       // wave-uniform: at most one tap boundary per K tile
+      const bool w = cck >= a.cpt;
+      cck -= w ? a.cpt : 0;
+      tapk += w ? 1 : 0;
+    } else {
+      while (cck >= a.cpt) { cck -= a.cpt; ++tapk; }
+    }
+    fetch(a, taps);
+  }
+};
+
+// walk serving DMA slot j: slot parity selects the chunk column.  Field-wise selects on CONSTANT indices: a dynamically
+// indexed struct array goes to scratch memory (hipcc), which put a scratch load + vmcnt(0) in front of every DMA.
+template <int CPRT, int NST>
+__device__ inline void pick_walk(const TapWalk<CPRT> (&walk)[NST], int j, bool& kv, int& tp, unsigned& so, unsigned& wo) {
+  if constexpr (NST == 2) {
+    const bool odd = (j & 1) != 0;
+    kv = odd ? walk[1].kv : walk[0].kv;
+    tp = odd ? walk[1].tp : walk[0].tp;
+    so = odd ? walk[1].so : walk[0].so;
+    wo = odd ? walk[1].wo : walk[0].wo;
+  } else {
+    kv = walk[0].kv; tp = walk[0].tp; so = walk[0].so; wo = walk[0].wo;
+  }
 }
 
 template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -576,47 +625,36 @@ __global__ __launch_bounds__(WM * WN * 64) void igemm_dma_kernel(const IgemmArgs
     const int k = n0 + rn;
     bbase[i] = (rn < BN && k < a.Kd) ? (unsigned)((size_t)k * a.wrs * a.Cs * ES) : OOB;     // padded rows: zeros, never read
   }
-  int tapk[NST], cck[NST];
+  TapWalk<CPRT> walk[NST];
 #pragma unroll
   for (int k = 0; k < NST; ++k) {
     const int sw = CPRT == 8 ? (((lane >> 4) + 4 * k) & 7) : ((lane >> 4) & 3);
-    cck[k] = p ^ sw;
-    tapk[k] = 0;
-    while (cck[k] >= a.cpt) { cck[k] -= a.cpt; ++tapk[k]; }
+    walk[k].init(a, taps, p ^ sw);
   }
   stamp(a.stamps, 7);
 
   auto dma_tile = [&](int stg) {
-    unsigned so[NST], wo[NST];
-    bool kv[NST];
-    int tp[NST];
-#pragma unroll
-    for (int k = 0; k < NST; ++k) {
-      kv[k] = tapk[k] < a.nt;
-      tp[k] = kv[k] ? tapk[k] : 0;
-      so[k] = (unsigned)(taps[tp[k]] + cck[k] * 16);
-      wo[k] = (unsigned)(taps[64 + tp[k]] + cck[k] * 16);
-    }
     const unsigned base = lds0 + (unsigned)(stg * STAGE * 16);
+    const unsigned keep = m0_save();
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
       const int j = wave * AI + i;
-      const int k = NST == 2 ? (j & 1) : 0;
-      const unsigned off = (kv[k] && ((amask[i] >> tp[k]) & 1)) ? ((abase[i] + so[k]) & a.probe_mask) : OOB;
+      bool kv; int tp; unsigned so, wo;
+      pick_walk<CPRT, NST>(walk, j, kv, tp, so, wo);
+      const unsigned off = (kv && ((amask[i] >> tp) & 1)) ? ((abase[i] + so) & a.probe_mask) : OOB;
       dma16(ra_desc, off, base + j * 1024);
     }
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int j = wave * BI + i;
-      const int k = NST == 2 ? (j & 1) : 0;
-      const unsigned off = (kv[k] && bbase[i] != OOB) ? ((bbase[i] + wo[k]) & a.probe_mask) : OOB;
+      bool kv; int tp; unsigned so, wo;
+      pick_walk<CPRT, NST>(walk, j, kv, tp, so, wo);
+      const unsigned off = (kv && bbase[i] != OOB) ? ((bbase[i] + wo) & a.probe_mask) : OOB;
       dma16(rb_desc, off, base + (j < BIT ? BM * CPRT * 16 + j * 1024 : (BM + BN) * CPRT * 16));
     }
+    m0_restore(keep);
 #pragma unroll
-    for (int k = 0; k < NST; ++k) {
-      cck[k] += CPRT;
-      while (cck[k] >= a.cpt) { cck[k] -= a.cpt; ++tapk[k]; }
-    }
+    for (int k = 0; k < NST; ++k) walk[k].advance(a, taps);
   };
 
   f32x16 acc[TM][TN];
@@ -743,43 +781,32 @@ __global__ __launch_bounds__(512, BM >= 256 ? 1 : 2) void igemm_ws_kernel(const 
       const int k = n0 + rn;
       bbase[i] = (rn < BN && k < a.Kd) ? (unsigned)((size_t)k * a.wrs * a.Cs * ES) : OOB;
     }
-    int tapk[NST], cck[NST];
+    TapWalk<CPRT> walk[NST];
 #pragma unroll
     for (int k = 0; k < NST; ++k) {
       const int sw = CPRT == 8 ? (((lane >> 4) + 4 * k) & 7) : ((lane >> 4) & 3);
-      cck[k] = p ^ sw;
-      tapk[k] = 0;
-      while (cck[k] >= a.cpt) { cck[k] -= a.cpt; ++tapk[k]; }
+      walk[k].init(a, taps, p ^ sw);
     }
     auto dma_tile = [&](int stg) {
-      unsigned so[NST], wo[NST];
-      bool kv[NST];
-      int tp[NST];
-#pragma unroll
-      for (int k = 0; k < NST; ++k) {
-        kv[k] = tapk[k] < a.nt;
-        tp[k] = kv[k] ? tapk[k] : 0;
-        so[k] = (unsigned)(taps[tp[k]] + cck[k] * 16);
-        wo[k] = (unsigned)(taps[64 + tp[k]] + cck[k] * 16);
-      }
       const unsigned base = lds0 + (unsigned)(stg * STAGE * 16);
+      const unsigned keep = m0_save();
 #pragma unroll
       for (int i = 0; i < AI; ++i) {
         const int j = lw * AI + i;
-        const int k = NST == 2 ? (j & 1) : 0;
-        dma16(ra_desc, (kv[k] && ((amask[i] >> tp[k]) & 1)) ? abase[i] + so[k] : OOB, base + j * 1024);
+        bool kv; int tp; unsigned so, wo;
+        pick_walk<CPRT, NST>(walk, j, kv, tp, so, wo);
+        dma16(ra_desc, (kv && ((amask[i] >> tp) & 1)) ? abase[i] + so : OOB, base + j * 1024);
       }
 #pragma unroll
       for (int i = 0; i < BI; ++i) {
         const int j = lw * BI + i;
-        const int k = NST == 2 ? (j & 1) : 0;
-        dma16(rb_desc, (kv[k] && bbase[i] != OOB) ? bbase[i] + wo[k] : OOB, base + BM * CPRT * 16 + j * 1024);
+        bool kv; int tp; unsigned so, wo;
+        pick_walk<CPRT, NST>(walk, j, kv, tp, so, wo);
+        dma16(rb_desc, (kv && bbase[i] != OOB) ? bbase[i] + wo : OOB, base + BM * CPRT * 16 + j * 1024);
       }
+      m0_restore(keep);
 #pragma unroll
-      for (int k = 0; k < NST; ++k) {
-        cck[k] += CPRT;
-        while (cck[k] >= a.cpt) { cck[k] -= a.cpt; ++tapk[k]; }
-      }
+      for (int k = 0; k < NST; ++k) walk[k].advance(a, taps);
     };
     // ring of NSTG stages: tiles it+1 .. it+NSTG-1 are in flight while the consumers multiply tile it
 #pragma unroll
