@@ -14,6 +14,7 @@
 // MFMAs of tile i and written to LDS after them (one barrier per K tile).  f32 uses v_mfma_f32_32x32x2_f32 (exact
 // f32 FMA chain), bf16 v_mfma_f32_32x32x16_bf16, both fed by one 16-byte ds_read_b128 per operand per k-step.
 #include "common.h"
+#include <type_traits>
 
 int rn_conv3x3_patch(const void* src, const void* wt, void* dst, const ResDesc& res, int accum, int dtype, int N, int H, int W, int C, int K,
                      bool flip, rn_stream s);
@@ -80,6 +81,32 @@ template <> struct Mfma<bf16_t> {
 };
 
 
+// ---- row decode + tap tables shared by the DMA kernels -------------------------------------------------------------------
+// LDS tap tables (ints): [0..63] source byte offset of a tap, [64..127] weight byte offset, [128..191] (dh << 16) | (dw & 0xFFFF).
+// The per-row validity masks read the packed (dh, dw) from LDS four taps at a time: looping over the kernel-argument
+// arrays instead costs two dependent scalar loads per tap and row (measured: 5.3 us of a 41 us tile on WRN-28-10's first stage).
+constexpr int TAP_INTS = 192;
+template <int ES>
+__device__ inline void fill_tap_tables(const IgemmArgs& a, int* taps) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const bool ok = tid < a.nt;
+    const int t = ok ? tid : 0;
+    const int dh = a.dh[t], dw = a.dw[t];
+    taps[tid] = ok ? (dh * a.Ws + dw) * a.Cs * ES : 0;
+    taps[64 + tid] = ok ? a.widx[t] * a.Cs * ES : 0;
+    taps[128 + tid] = ok ? ((dh << 16) | (dw & 0xFFFF)) : 0x40004000;      // padding taps: far out of range
+  }
+}
+__device__ inline void decode_row(const IgemmArgs& a, int m, int pq, int& n, int& pp, int& q) {
+  n = (int)__umulhi((unsigned)m, a.magic_pq);
+  int rem = m - n * pq;
+  if (rem >= pq) { ++n; rem -= pq; }
+  pp = (int)__umulhi((unsigned)rem, a.magic_q);
+  q = rem - pp * a.Qc;
+  if (q >= a.Qc) { ++pp; q -= a.Qc; }
+}
+
 // ---- epilogue shared by all implicit-GEMM kernels ---------------------------------------------------------------------------
 // The 32x32 MFMA leaves a lane with ONE output channel (col = lane&31) of 16 rows (row = (r&3) + 8*(r>>2) + 4*(lane>>5)):
 // storing from there means 2-byte accesses in 64-byte segments, which capped output-bound layers (1x1 convolutions at
@@ -89,9 +116,17 @@ template <> struct Mfma<bf16_t> {
 // consecutive chunks of a row.  Owning a fixed channel chunk, a thread also keeps per-channel sums in registers: the
 // BatchNorm batch statistics of what it stores (forward) or the two BatchNorm-backward sums of the layer that fed the
 // convolution (dgrad), reduced over the row lanes through LDS into one partial row per M tile.
-template <typename T, int BM, int BN, int WM, int WN, int TM, int TN>
+// workgroup barrier that orders LDS traffic only: `__syncthreads()` also drains vmcnt, i.e. waits until the global
+// stores a wave has just issued are acknowledged (1-2 us each time in the epilogue)
+__device__ inline void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int TM, int TN, int NTH = WM * WN * 64>
 __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int wave, int lane, float* lds_f,
-                                      bool active = true, int nthreads = WM * WN * 64) {
+                                      bool active = true) {
   if (a.probe_ep >= 2) {                       // keep every accumulator live (no dead-code elimination of the MFMAs)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -105,6 +140,9 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
   constexpr int HR = 64;                       // rows per half
   constexpr int LDC = BN + 4;                  // fp32 row stride of the staged tile
   constexpr int CCN = BN / CE;                 // output chunks per row
+  constexpr int LANES = NTH / CCN;             // row lanes (threads beyond LANES*CCN idle in phase 2)
+  constexpr int NIT = (HR + LANES - 1) / LANES;          // rows a thread serves per half
+  constexpr int UBD = 1;                       // rows per batch (2 and 3 measured: no gain in the model, slower on operand-free tiles)
   static_assert(BM % (2 * HR) == 0 && 2 * HR == RN_CONV_STATS_ROWS && BN % CE == 0, "epilogue tile");
   float* ctile = lds_f;                        // [HR][LDC]
   float* red = lds_f + HR * LDC;               // [row lanes][2][BN]
@@ -112,15 +150,15 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
   const int lr = lane & 31, lh = lane >> 5;
   const int pq = a.Pc * a.Qc;
   const int tid = threadIdx.x;
-  const int lanes = nthreads / CCN;            // row lanes (threads beyond lanes*CCN idle in phase 2)
   const int cg = tid % CCN, rl = tid / CCN;
-  const bool p2 = rl < lanes;
+  const bool p2 = rl < LANES;
   const int k0 = n0 + cg * CE;
   const bool colok = p2 && k0 < a.Kd;
   T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
   const bool dense = (a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME);
   const bool want_stats = a.stats != nullptr;
   const bool bn_bwd = want_stats && a.bn_x != nullptr;
+  const bool res_same = a.res.mode == RN_RES_SAME;
   float s0[CE], s1[CE], mean[CE], invstd[CE], bias[CE];
 #pragma unroll
   for (int e = 0; e < CE; ++e) {
@@ -147,68 +185,89 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
         }
       }
     }
-    __syncthreads();
+    lds_barrier();
     stamp(a.stamps, 3 + 2 * (half & 1));
-    // ---- phase 2: column-fixed threads, 16-byte chunks ----
-    if (colok && a.probe_ep != 4) {
-      for (int row = rl; row < HR; row += lanes) {
-        const int m = m0 + half * HR + row;
-        if (m >= a.M) break;
-        size_t pix;
-        int n = 0, hd = 0, wd = 0;
-        if (dense) {
-          pix = (size_t)m;
-        } else {
-          n = m / pq;
-          const int rem = m - n * pq;
-          const int pp = rem / a.Qc, q = rem - pp * a.Qc;
-          hd = pp * a.ds + a.oh;
-          wd = q * a.ds + a.ow;
-          pix = ((size_t)n * a.Hd + hd) * a.Wd + wd;
+    // ---- phase 2: column-fixed threads, 16-byte chunks; a batch of UB rows issues every global operand load (residual,
+    // accumulate, BatchNorm operands) before the first use, so a thread pays one memory latency per batch, not per row ----
+    auto phase2 = [&](auto ubc) {
+      constexpr int UB = decltype(ubc)::value;
+#pragma unroll
+      for (int ub = 0; ub < NIT; ub += UB) {
+        bool ok[UB];
+        size_t off[UB];
+        int rn[UB], rh[UB], rw[UB];
+        Chunk<T> cr[UB], co[UB], cx[UB], cm[UB];
+#pragma unroll
+        for (int u = 0; u < UB; ++u) {
+          const int row = rl + (ub + u) * LANES;
+          const int m = m0 + half * HR + row;
+          ok[u] = (ub + u < NIT) && row < HR && m < a.M;
+          rn[u] = rh[u] = rw[u] = 0;
+          off[u] = 0;
+          if (ok[u]) {
+            size_t pix;
+            if (dense) {
+              pix = (size_t)m;
+              if (a.res.mode != RN_RES_NONE && !res_same) decode_row(a, m, pq, rn[u], rh[u], rw[u]);
+            } else {
+              int n, pp, q;
+              decode_row(a, m, pq, n, pp, q);
+              rn[u] = n; rh[u] = pp * a.ds + a.oh; rw[u] = q * a.ds + a.ow;
+              pix = ((size_t)n * a.Hd + rh[u]) * a.Wd + rw[u];
+            }
+            off[u] = pix * a.Kd + k0;
+            if (res_same) cr[u] = load_chunk<T>(reinterpret_cast<const T*>(a.res.ptr) + off[u]);
+            if (a.accum) co[u] = load_chunk<T>(dst + off[u]);
+            if (bn_bwd) {
+              cx[u] = load_chunk<T>(reinterpret_cast<const T*>(a.bn_x) + off[u]);
+              if (a.bn_mask) cm[u] = load_chunk<T>(reinterpret_cast<const T*>(a.bn_mask) + off[u]);
+            }
+          }
         }
-        const size_t off = pix * a.Kd + k0;
-        float v[CE];
-        const float* cp = ctile + row * LDC + cg * CE;
 #pragma unroll
-        for (int e = 0; e < CE; e += 4) {
-          const float4 t = *reinterpret_cast<const float4*>(cp + e);
-          v[e] = t.x + bias[e]; v[e + 1] = t.y + bias[e + 1]; v[e + 2] = t.z + bias[e + 2]; v[e + 3] = t.w + bias[e + 3];
-        }
-        if (a.res.mode == RN_RES_SAME) {
-          Chunk<T> cr = load_chunk<T>(reinterpret_cast<const T*>(a.res.ptr) + off);
+        for (int u = 0; u < UB; ++u) {
+          if (!ok[u]) continue;
+          const int row = rl + (ub + u) * LANES;
+          float v[CE];
+          const float* cp = ctile + row * LDC + cg * CE;
 #pragma unroll
-          for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cr.e[e]);
-        } else if (a.res.mode != RN_RES_NONE) {
-          if (dense) { n = m / pq; const int rem = m - n * pq; hd = rem / a.Qc; wd = rem - hd * a.Qc; }
-          res_add_chunk<T>(a.res, n, hd, wd, k0, v);
-        }
-        if (a.accum) {
-          Chunk<T> co = load_chunk<T>(dst + off);
+          for (int e = 0; e < CE; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(cp + e);
+            v[e] = t.x + bias[e]; v[e + 1] = t.y + bias[e + 1]; v[e + 2] = t.z + bias[e + 2]; v[e + 3] = t.w + bias[e + 3];
+          }
+          if (res_same) {
 #pragma unroll
-          for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(co.e[e]);
-        }
-        Chunk<T> st;
+            for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cr[u].e[e]);
+          } else if (a.res.mode != RN_RES_NONE) {
+            res_add_chunk<T>(a.res, rn[u], rh[u], rw[u], k0, v);
+          }
+          if (a.accum) {
 #pragma unroll
-        for (int e = 0; e < CE; ++e) st.e[e] = Elem<T>::from_f(v[e]);
-        if (a.probe_ep != 1 || st.u.x == 0x12345678u) store_chunk<T>(dst + off, st);
-        if (want_stats) {
-          if (!bn_bwd) {
+            for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(co[u].e[e]);
+          }
+          Chunk<T> st;
 #pragma unroll
-            for (int e = 0; e < CE; ++e) { const float vs = Elem<T>::to_f(st.e[e]); s0[e] += vs; s1[e] += vs * vs; }
-          } else {
-            Chunk<T> cx = load_chunk<T>(reinterpret_cast<const T*>(a.bn_x) + off);
-            Chunk<T> cm;
-            if (a.bn_mask) cm = load_chunk<T>(reinterpret_cast<const T*>(a.bn_mask) + off);
+          for (int e = 0; e < CE; ++e) st.e[e] = Elem<T>::from_f(v[e]);
+          if (a.probe_ep != 1 || st.u.x == 0x12345678u) store_chunk<T>(dst + off[u], st);
+          if (want_stats) {
+            if (!bn_bwd) {
 #pragma unroll
-            for (int e = 0; e < CE; ++e) {
-              float g = Elem<T>::to_f(st.e[e]) * a.gscale;
-              if (a.bn_mask && !(Elem<T>::to_f(cm.e[e]) > 0.f)) g = 0.f;
-              const float xh = (Elem<T>::to_f(cx.e[e]) - mean[e]) * invstd[e];
-              s0[e] += g; s1[e] += g * xh;
+              for (int e = 0; e < CE; ++e) { const float vs = Elem<T>::to_f(st.e[e]); s0[e] += vs; s1[e] += vs * vs; }
+            } else {
+#pragma unroll
+              for (int e = 0; e < CE; ++e) {
+                float g = Elem<T>::to_f(st.e[e]) * a.gscale;
+                if (a.bn_mask && !(Elem<T>::to_f(cm[u].e[e]) > 0.f)) g = 0.f;
+                const float xh = (Elem<T>::to_f(cx[u].e[e]) - mean[e]) * invstd[e];
+                s0[e] += g; s1[e] += g * xh;
+              }
             }
           }
         }
       }
+    };
+    if (colok && a.probe_ep != 4) {
+      phase2(std::integral_constant<int, UBD>{});
     }
     if (want_stats && (half & 1)) {            // one partial row per RN_CONV_STATS_ROWS (= 2 halves) output rows
       if (p2) {
@@ -218,21 +277,21 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
           s0[e] = s1[e] = 0.f;
         }
       }
-      __syncthreads();
+      lds_barrier();
       const int grp = half >> 1;
       if (m0 + grp * 2 * HR < a.M) {
-        for (int col = tid; col < BN; col += nthreads) {
+        for (int col = tid; col < BN; col += NTH) {
           const int k = n0 + col;
           if (k >= a.Kd) continue;
           float t0 = 0.f, t1 = 0.f;
-          for (int w = 0; w < lanes; ++w) { t0 += red[(w * 2 + 0) * BN + col]; t1 += red[(w * 2 + 1) * BN + col]; }
+          for (int w = 0; w < LANES; ++w) { t0 += red[(w * 2 + 0) * BN + col]; t1 += red[(w * 2 + 1) * BN + col]; }
           float* out = a.stats + ((size_t)(a.tile_base + m0 / (2 * HR) + grp) * 2) * a.Kd;
           out[k] = t0;
           out[a.Kd + k] = t1;
         }
       }
     }
-    __syncthreads();                           // ctile (and `red`) are reused by the next half
+    lds_barrier();                             // ctile (and `red`) are reused by the next half
     stamp(a.stamps, 4 + 2 * (half & 1));
   }
 }
@@ -451,31 +510,6 @@ __device__ inline void dma16(v4i32 desc, unsigned voff, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(desc), "s"(lds_addr) : "memory");
 }
 
-// ---- row decode + tap tables shared by the DMA kernels -------------------------------------------------------------------
-// LDS tap tables (ints): [0..63] source byte offset of a tap, [64..127] weight byte offset, [128..191] (dh << 16) | (dw & 0xFFFF).
-// The per-row validity masks read the packed (dh, dw) from LDS four taps at a time: looping over the kernel-argument
-// arrays instead costs two dependent scalar loads per tap and row (measured: 5.3 us of a 41 us tile on WRN-28-10's first stage).
-constexpr int TAP_INTS = 192;
-template <int ES>
-__device__ inline void fill_tap_tables(const IgemmArgs& a, int* taps) {
-  const int tid = threadIdx.x;
-  if (tid < 64) {
-    const bool ok = tid < a.nt;
-    const int t = ok ? tid : 0;
-    const int dh = a.dh[t], dw = a.dw[t];
-    taps[tid] = ok ? (dh * a.Ws + dw) * a.Cs * ES : 0;
-    taps[64 + tid] = ok ? a.widx[t] * a.Cs * ES : 0;
-    taps[128 + tid] = ok ? ((dh << 16) | (dw & 0xFFFF)) : 0x40004000;      // padding taps: far out of range
-  }
-}
-__device__ inline void decode_row(const IgemmArgs& a, int m, int pq, int& n, int& pp, int& q) {
-  n = (int)__umulhi((unsigned)m, a.magic_pq);
-  int rem = m - n * pq;
-  if (rem >= pq) { ++n; rem -= pq; }
-  pp = (int)__umulhi((unsigned)rem, a.magic_q);
-  q = rem - pp * a.Qc;
-  if (q >= a.Qc) { ++pp; q -= a.Qc; }
-}
 // tap (i, j) reads source pixel (hb + dh_i, wb + dw_j): in range iff its row AND its column are, so nth + ntw checks per
 // output row, on lists fetched from LDS ONCE per thread (14 independent reads, one wait): per-row LDS reads serialise on
 // their s_waitcnt and made this setup 2.4 us of a 41 us tile
@@ -563,7 +597,7 @@ template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt v
 // `s_barrier`: `__syncthreads()` would make hipcc drain every DMA in flight.  All LDS lives in ONE __shared__ array (a
 // second __shared__ object makes hipcc wait vmcnt(0) before every ds_read; cdna_hip_programming.md section 5).
 template <typename T, int BM, int BN, int WM, int WN, int CPRT, int NSTG>
-__global__ __launch_bounds__(WM * WN * 64) void igemm_dma_kernel(const IgemmArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmArgs a) {   // 2 waves per SIMD: <= 256 registers (two 4-wave workgroups per CU)
   constexpr int NW = WM * WN;                          // waves per workgroup
   constexpr int ES = (int)sizeof(T);
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -866,7 +900,7 @@ __global__ __launch_bounds__(512, BM >= 256 ? 1 : 2) void igemm_ws_kernel(const 
       __builtin_amdgcn_s_barrier();
     }
   }
-  igemm_epilogue<T, BM, BN, WM, WN, TM, TN>(a, acc, m0, n0, loader ? 0 : wave, lane, reinterpret_cast<float*>(&smem[0]), !loader, 512);
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 512>(a, acc, m0, n0, loader ? 0 : wave, lane, reinterpret_cast<float*>(&smem[0]), !loader);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>

@@ -6,6 +6,8 @@ L = _lib.lib()
 vp = C.c_void_p
 L.rn_conv_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(_lib.RnConvGeom), vp, vp]
 L.rn_set_stamp_buffer.argtypes = [vp]
+L.rn_set_variant.argtypes = [C.c_int]
+L.rn_set_variant(int(os.environ.get('RN_VARIANT', '0')))
 N, H, W, Cc, K, ks = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else '128,32,32,160,160,3').split(',')]
 g = _lib.RnConvGeom(N, H, W, Cc, H, W, K, ks, ks, 1, ks // 2)
 dt = torch.bfloat16
