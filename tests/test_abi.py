@@ -78,3 +78,49 @@ def test_conv_stats_rows_matches_library():
         gs = _lib.geom_struct(g)
         assert L.rn_conv_stats_rows(C.byref(gs), 0) == conv_stats_rows(g)
         assert L.rn_conv_stats_rows(C.byref(gs), 1) == conv_stats_rows(g, True)
+
+
+# ---- kernel resource budget (build/<file>.res is written by the Makefile from hipcc's -Rpass-analysis remarks) ----------
+def _kernel_resources():
+    import glob
+    import re
+    out = {}
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'pytorch_ddp_resnet_amd', 'csrc', 'build')
+    for path in glob.glob(os.path.join(root, '*.res')):
+        cur = None
+        for line in open(path):
+            m = re.search(r'remark: Function Name: (\S+)', line)
+            if m:
+                cur = out.setdefault(m.group(1), {})
+                continue
+            m = re.search(r'remark:\s+([A-Za-z ]+?)(?: \[[^\]]*\])?: (\d+) \[-Rpass', line)
+            if m and cur is not None:
+                cur[m.group(1).strip()] = int(m.group(2))
+    return out
+
+
+def test_hot_kernels_keep_their_occupancy():
+    """The conv kernels are tuned at an occupancy edge (255 of 256 registers; 81,920 of 81,920 LDS bytes): a change that
+    tips one over silently halves its throughput (seen twice while tuning).  No production kernel may use scratch."""
+    res = _kernel_resources()
+    if not res:
+        pytest.skip('no build/*.res (library not built by the Makefile in this tree)')
+    LDS_CU = 160 * 1024
+
+    def find(*parts):
+        hits = [k for k in res if all(p in k for p in parts)]
+        assert len(hits) == 1, (parts, hits)
+        return res[hits[0]]
+    k = find('igemm_dma_kernelIDF16bLi128ELi160ELi4ELi1ELi8ELi2E')          # WRN-28-10 fwd/dgrad, two workgroups per CU
+    assert k['Occupancy'] >= 2 and 2 * k['LDS Size'] <= LDS_CU and k['ScratchSize'] == 0, k
+    k = find('igemm_dma_kernelIDF16bLi128ELi128ELi2ELi2ELi8ELi2E')
+    assert k['Occupancy'] >= 2 and 2 * k['LDS Size'] <= LDS_CU and k['ScratchSize'] == 0, k
+    k = find('igemm_ws_kernelIDF16bLi128ELi160ELi4ELi1ELi8ELi3E')           # one workgroup per CU (8 waves)
+    assert k['Occupancy'] >= 2 and k['LDS Size'] <= LDS_CU and k['ScratchSize'] == 0, k
+    k = find('wgrad_kernelIDF16bLi5ELi5ELb0E')                               # 160x160 weight-gradient tile, two workgroups per CU
+    assert k['Occupancy'] >= 2 and 2 * k['LDS Size'] <= LDS_CU and k['ScratchSize'] == 0, k
+    experimental = ('Li256E',)                                               # opt-in 256-row tiles (rn_set_variant)
+    for name, k in res.items():
+        if any(e in name for e in experimental):
+            continue
+        assert k.get('ScratchSize', 0) == 0, (name, k)
