@@ -18,26 +18,58 @@ __global__ void pack_w_fwd_kernel(const float* __restrict__ w, T* __restrict__ w
 // (along c) and the write (along k) are coalesced
 template <typename T>
 __global__ __launch_bounds__(256) void pack_w_dgrad_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int K, int RS, int C) {
-  __shared__ float tile[32][33];
-  const int kt = (K + 31) / 32, ct = (C + 31) / 32;
+  // one 64(k) x 64(c) tile of one tap: 16-byte reads along c, 16-byte (bf16: 8 k) stores along k of the transposed copy.
+  // K and C are multiples of 8 (bf16) / 4 (fp32) (conv geometry check), so every 4-wide / 8-wide group is whole.
+  constexpr int CE = Elem<T>::CE;
+  __shared__ float tile[64][65];
+  const int ct = (C + 63) / 64;
   int b = blockIdx.x;
   const int rs = b % RS; b /= RS;
-  const int c0 = (b % ct) * 32, k0 = (b / ct) * 32;
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  (void)kt;
+  const int c0 = (b % ct) * 64, k0 = (b / ct) * 64;
+  const int t = threadIdx.x;
+  {
+    const int c4 = (t & 15) * 4, r = t >> 4;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int k = k0 + ty + 8 * j, c = c0 + tx;
-    const bool ok = k < K && c < C;
-    const float v = ok ? w[((size_t)k * RS + rs) * C + c] : 0.f;
-    tile[ty + 8 * j][tx] = v;
-    if (ok && wf) wf[((size_t)k * RS + rs) * C + c] = Elem<T>::from_f(v);      // forward copy from the same read
+    for (int j = 0; j < 4; ++j) {
+      const int k = k0 + r + 16 * j, c = c0 + c4;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      const bool ok = k < K && c < C;
+      if (ok) {
+        const size_t off = ((size_t)k * RS + rs) * C + c;
+        v = *reinterpret_cast<const float4*>(w + off);
+        if (wf) {                                  // forward copy from the same read
+          if constexpr (CE == 8) {
+            bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
+            *reinterpret_cast<bf16x4*>(wf + off) = o;
+          } else {
+            *reinterpret_cast<float4*>(wf + off) = v;
+          }
+        }
+      }
+      tile[r + 16 * j][c4] = v.x; tile[r + 16 * j][c4 + 1] = v.y; tile[r + 16 * j][c4 + 2] = v.z; tile[r + 16 * j][c4 + 3] = v.w;
+    }
   }
   __syncthreads();
+  {
+    const int k8 = (t & 7) * 8, cc = t >> 3;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int c = c0 + ty + 8 * j, k = k0 + tx;
-    if (k < K && c < C) wd[((size_t)c * RS + rs) * K + k] = Elem<T>::from_f(tile[tx][ty + 8 * j]);
+    for (int j = 0; j < 2; ++j) {
+      const int c = c0 + cc + 32 * j, k = k0 + k8;
+      if (c >= C || k >= K) continue;
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = tile[k8 + i][cc + 32 * j];
+      T* dst = wd + ((size_t)c * RS + rs) * K + k;
+      if constexpr (CE == 8) {
+        Chunk<T> o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o.e[i] = Elem<T>::from_f(v[i]);
+        store_chunk<T>(dst, o);
+      } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+        if (k + 4 < K) *reinterpret_cast<float4*>(dst + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+    }
   }
 }
 
@@ -296,6 +328,7 @@ inline int ew_grid(long n) {
 extern "C" int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, int dtype, int K, int RS, int C, rn_stream s) {
   RN_CHECK_ARG(w_krsc && (w_fwd || w_dgrad) && K > 0 && RS > 0 && C > 0, "rn_pack_weights: bad argument");
   RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "rn_pack_weights: bad dtype");
+  RN_CHECK_ARG(!w_dgrad || (C % (dtype == RN_F32 ? 4 : 8) == 0 && K % (dtype == RN_F32 ? 4 : 8) == 0), "rn_pack_weights: C=%d and K=%d must be multiples of %d for this dtype", C, K, dtype == RN_F32 ? 4 : 8);
   const long n = (long)K * RS * C;
   if (w_fwd && !w_dgrad) {
     if (dtype == RN_F32) hipLaunchKernelGGL((pack_w_fwd_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), w_krsc, (float*)w_fwd, n);
@@ -303,7 +336,7 @@ extern "C" int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, 
     RN_CHECK_LAUNCH("pack_weights_fwd");
   }
   if (w_dgrad) {
-    const int grid = cdiv(K, 32) * cdiv(C, 32) * RS;
+    const int grid = cdiv(K, 64) * cdiv(C, 64) * RS;
     if (dtype == RN_F32) hipLaunchKernelGGL((pack_w_dgrad_kernel<float>), dim3(grid), dim3(256), 0, as_stream(s), w_krsc, (float*)w_fwd, (float*)w_dgrad, K, RS, C);
     else hipLaunchKernelGGL((pack_w_dgrad_kernel<bf16_t>), dim3(grid), dim3(256), 0, as_stream(s), w_krsc, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, K, RS, C);
   }
