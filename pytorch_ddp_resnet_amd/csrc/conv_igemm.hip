@@ -19,9 +19,8 @@
 int rn_conv3x3_patch(const void* src, const void* wt, void* dst, const ResDesc& res, int accum, int dtype, int N, int H, int W, int C, int K,
                      bool flip, rn_stream s);
 
-int g_rn_variant = 0;   // tuning switch (tools/conv_bench.py): bit0 LDS-patch 3x3 kernel, bit1 register staging w/o fragment
-                        // double-buffering, bit2 256-row 8-wave tile, bit3 register-staged kernel, bit4 4-stage 64-byte-row DMA ring,
-                        // bit6 DMA source-window timing probe, bit7 force wave-specialised kernel (bit8: 4 stages), bit9 never use it
+int g_rn_variant = 0;   // tuning switch (tools/conv_bench.py): 1 LDS-patch 3x3 kernel (conv3x3.hip), 64 DMA source-window timing probe,
+                        // 128 force / 512 forbid the wave-specialised kernel, 8192.. epilogue timing probes (fill_ep)
 extern "C" void rn_set_variant(int v) { g_rn_variant = v; }
 static void* g_rn_stamps = nullptr;
 extern "C" void rn_set_stamp_buffer(void* p) { g_rn_stamps = p; }
@@ -33,6 +32,9 @@ namespace {
 constexpr int MAX_TAPS = 49;        // 7x7 stem
 constexpr int CPR = 8;  // 16-byte chunks per LDS row (128 bytes of K per row)
 
+// Kernel arguments.  Every scalar a kernel reads sits in the first 200 bytes and is fetched by ONE batch of scalar loads at
+// kernel entry (preload_args): left to the compiler, the fields were loaded one by one at first use, each a dependent
+// s_load + s_waitcnt out of kernarg memory -- ~2 us of a 9 us tile on 1x1 convolutions.  The tap arrays come last.
 struct IgemmArgs {
   const void* src;
   const void* wt;
@@ -46,19 +48,32 @@ struct IgemmArgs {
   int nth, ntw;            // the taps form an nth x ntw grid (tap = i * ntw + j): validity is separable in (dh_i, dw_j)
   unsigned magic_pq, magic_q;   // floor(2^32 / (Pc*Qc)), floor(2^32 / Qc): division by multiply-high + one correction (fill_magic)
   int accum;
-  int dh[MAX_TAPS], dw[MAX_TAPS], widx[MAX_TAPS];
   // fused epilogues (rn_conv_epilogue): per-M-tile partial sums written to stats[(tile_base + m-tile)][2][Kd]
+  int tile_base;
   float* stats;            // forward: (sum y, sum y^2) of the stored output
   const void* bn_x;        // dgrad: (sum g, sum g*xhat), g = dx * gscale * [mask > 0], xhat = (bn_x - mean) * invstd
   const void* bn_mask;
   const float* bn_coef;
-  float gscale;
-  int tile_base;
   const float* bias;       // per-output-channel bias added in the epilogue (stem convolution), or NULL
+  float gscale;
   unsigned probe_mask;     // timing probe (rn_set_variant bit6): AND-mask on DMA source offsets, 0xFFFFFFFF in production
   unsigned long long* stamps;   // diagnostic: per-workgroup s_memtime stamps [grid][16] (rn_set_stamp_buffer), NULL in production
   int probe_ep;            // timing probes: 1 = skip the global stores of the epilogue, 2 = skip the epilogue
+  int dh[MAX_TAPS], dw[MAX_TAPS], widx[MAX_TAPS];
 };
+
+// materialise every scalar argument in SGPRs now: the loads are adjacent, hipcc merges them into a few wide s_loads + one wait
+__device__ inline void preload_args(const IgemmArgs& a) {
+#define RN_TOUCH(x) asm volatile("" ::"s"(x))
+  RN_TOUCH(a.src); RN_TOUCH(a.wt); RN_TOUCH(a.dst); RN_TOUCH(a.res.ptr); RN_TOUCH(a.res.mode); RN_TOUCH(a.res.C); RN_TOUCH(a.res.H); RN_TOUCH(a.res.W);
+  RN_TOUCH(a.N); RN_TOUCH(a.Hs); RN_TOUCH(a.Ws); RN_TOUCH(a.Cs); RN_TOUCH(a.Pc); RN_TOUCH(a.Qc); RN_TOUCH(a.M);
+  RN_TOUCH(a.Hd); RN_TOUCH(a.Wd); RN_TOUCH(a.Kd); RN_TOUCH(a.ss); RN_TOUCH(a.ds); RN_TOUCH(a.oh); RN_TOUCH(a.ow);
+  RN_TOUCH(a.nt); RN_TOUCH(a.wrs); RN_TOUCH(a.cpt); RN_TOUCH(a.nk); RN_TOUCH(a.nth); RN_TOUCH(a.ntw);
+  RN_TOUCH(a.magic_pq); RN_TOUCH(a.magic_q); RN_TOUCH(a.accum); RN_TOUCH(a.tile_base);
+  RN_TOUCH(a.stats); RN_TOUCH(a.bn_x); RN_TOUCH(a.bn_mask); RN_TOUCH(a.bn_coef); RN_TOUCH(a.bias); RN_TOUCH(a.gscale);
+  RN_TOUCH(a.probe_mask); RN_TOUCH(a.stamps); RN_TOUCH(a.probe_ep);
+#undef RN_TOUCH
+}
 
 __device__ inline void stamp(const unsigned long long* base_c, int slot) {
   unsigned long long* base = const_cast<unsigned long long*>(base_c);
@@ -137,13 +152,13 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
     if (a.probe_ep == 2) return;
   }
   constexpr int CE = Elem<T>::CE;
-  constexpr int HR = 64;                       // rows per half
+  constexpr int HR = 64;                       // staged rows per half
   constexpr int LDC = BN + 4;                  // fp32 row stride of the staged tile
   constexpr int CCN = BN / CE;                 // output chunks per row
   constexpr int LANES = NTH / CCN;             // row lanes (threads beyond LANES*CCN idle in phase 2)
-  constexpr int NIT = (HR + LANES - 1) / LANES;          // rows a thread serves per half
-  constexpr int UBD = 1;                       // rows per batch (2 and 3 measured: no gain in the model, slower on operand-free tiles)
-  static_assert(BM % (2 * HR) == 0 && 2 * HR == RN_CONV_STATS_ROWS && BN % CE == 0, "epilogue tile");
+  static_assert(BM == 2 * HR && 2 * HR == RN_CONV_STATS_ROWS && BN % CE == 0, "epilogue tile");
+  // A half takes 16 of the 32 rows of EVERY 32-row MFMA block (accumulator registers 8h .. 8h+7), so all waves park in
+  // both halves: staged row s = blk*16 + j  <->  tile row blk*32 + 16*half + j
   float* ctile = lds_f;                        // [HR][LDC]
   float* red = lds_f + HR * LDC;               // [row lanes][2][BN]
   const int wm = wave / WN, wn = wave % WN;
@@ -159,6 +174,8 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
   const bool want_stats = a.stats != nullptr;
   const bool bn_bwd = want_stats && a.bn_x != nullptr;
   const bool res_same = a.res.mode == RN_RES_SAME;
+  // the common forward case gets its own row loop: no residual / accumulate / BatchNorm-backward operands, no bias
+  const bool simple = dense && a.res.mode == RN_RES_NONE && !a.accum && !bn_bwd && !a.bias;
   float s0[CE], s1[CE], mean[CE], invstd[CE], bias[CE];
 #pragma unroll
   for (int e = 0; e < CE; ++e) {
@@ -168,314 +185,128 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
   }
   __syncthreads();                             // every wave is done with the K-loop staging memory
   stamp(a.stamps, 2);
-#pragma unroll 1
-  for (int half = 0; half < BM / HR; ++half) {
-    // ---- phase 1: the waves whose rows fall into this half park their accumulators (fp32) ----
+#pragma unroll
+  for (int half = 0; half < 2; ++half) {
+    // ---- phase 1: every wave parks 8 of the 16 accumulator rows-groups of each of its MFMA blocks (fp32) ----
     if (active && a.probe_ep != 3) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int rbase = wm * (BM / WM) + 32 * i;
-        if (rbase / HR == half) {
+        const int blk = wm * TM + i;
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int row = rbase - half * HR + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        for (int r8 = 0; r8 < 8; ++r8) {
+          const int srow = blk * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * lh;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) ctile[row * LDC + wn * (BN / WN) + 32 * j + lr] = acc[i][j][r];
+          for (int j = 0; j < TN; ++j) {
+            const float v = half == 0 ? acc[i][j][r8] : acc[i][j][8 + r8];
+            ctile[srow * LDC + wn * (BN / WN) + 32 * j + lr] = v;
           }
         }
       }
     }
     lds_barrier();
-    stamp(a.stamps, 3 + 2 * (half & 1));
-    // ---- phase 2: column-fixed threads, 16-byte chunks; a batch of UB rows issues every global operand load (residual,
-    // accumulate, BatchNorm operands) before the first use, so a thread pays one memory latency per batch, not per row ----
-    auto phase2 = [&](auto ubc) {
-      constexpr int UB = decltype(ubc)::value;
+    stamp(a.stamps, 3 + 2 * half);
+    // ---- phase 2: column-fixed threads, 16-byte chunks ----
+    if (colok && a.probe_ep != 4) {
+      if (simple) {
+        for (int srow = rl; srow < HR; srow += LANES) {
+          const int m = m0 + (srow >> 4) * 32 + 16 * half + (srow & 15);
+          if (m >= a.M) break;
+          const float* cp = ctile + srow * LDC + cg * CE;
+          Chunk<T> st;
 #pragma unroll
-      for (int ub = 0; ub < NIT; ub += UB) {
-        bool ok[UB];
-        size_t off[UB];
-        int rn[UB], rh[UB], rw[UB];
-        Chunk<T> cr[UB], co[UB], cx[UB], cm[UB];
+          for (int e = 0; e < CE; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(cp + e);
+            st.e[e] = Elem<T>::from_f(t.x); st.e[e + 1] = Elem<T>::from_f(t.y); st.e[e + 2] = Elem<T>::from_f(t.z); st.e[e + 3] = Elem<T>::from_f(t.w);
+          }
+          if (a.probe_ep != 1 || st.u.x == 0x12345678u) store_chunk<T>(dst + (size_t)m * a.Kd + k0, st);
+          if (want_stats) {
 #pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          const int row = rl + (ub + u) * LANES;
-          const int m = m0 + half * HR + row;
-          ok[u] = (ub + u < NIT) && row < HR && m < a.M;
-          rn[u] = rh[u] = rw[u] = 0;
-          off[u] = 0;
-          if (ok[u]) {
-            size_t pix;
-            if (dense) {
-              pix = (size_t)m;
-              if (a.res.mode != RN_RES_NONE && !res_same) decode_row(a, m, pq, rn[u], rh[u], rw[u]);
-            } else {
-              int n, pp, q;
-              decode_row(a, m, pq, n, pp, q);
-              rn[u] = n; rh[u] = pp * a.ds + a.oh; rw[u] = q * a.ds + a.ow;
-              pix = ((size_t)n * a.Hd + rh[u]) * a.Wd + rw[u];
-            }
-            off[u] = pix * a.Kd + k0;
-            if (res_same) cr[u] = load_chunk<T>(reinterpret_cast<const T*>(a.res.ptr) + off[u]);
-            if (a.accum) co[u] = load_chunk<T>(dst + off[u]);
-            if (bn_bwd) {
-              cx[u] = load_chunk<T>(reinterpret_cast<const T*>(a.bn_x) + off[u]);
-              if (a.bn_mask) cm[u] = load_chunk<T>(reinterpret_cast<const T*>(a.bn_mask) + off[u]);
-            }
+            for (int e = 0; e < CE; ++e) { const float vs = Elem<T>::to_f(st.e[e]); s0[e] += vs; s1[e] += vs * vs; }
           }
         }
-#pragma unroll
-        for (int u = 0; u < UB; ++u) {
-          if (!ok[u]) continue;
-          const int row = rl + (ub + u) * LANES;
+      } else {
+        for (int srow = rl; srow < HR; srow += LANES) {
+          const int m = m0 + (srow >> 4) * 32 + 16 * half + (srow & 15);
+          if (m >= a.M) break;
+          size_t pix;
+          int n = 0, hd = 0, wd = 0;
+          if (dense) {
+            pix = (size_t)m;
+          } else {
+            int pp, q;
+            decode_row(a, m, pq, n, pp, q);
+            hd = pp * a.ds + a.oh;
+            wd = q * a.ds + a.ow;
+            pix = ((size_t)n * a.Hd + hd) * a.Wd + wd;
+          }
+          const size_t off = pix * a.Kd + k0;
           float v[CE];
-          const float* cp = ctile + row * LDC + cg * CE;
+          const float* cp = ctile + srow * LDC + cg * CE;
 #pragma unroll
           for (int e = 0; e < CE; e += 4) {
             const float4 t = *reinterpret_cast<const float4*>(cp + e);
             v[e] = t.x + bias[e]; v[e + 1] = t.y + bias[e + 1]; v[e + 2] = t.z + bias[e + 2]; v[e + 3] = t.w + bias[e + 3];
           }
           if (res_same) {
+            Chunk<T> cr = load_chunk<T>(reinterpret_cast<const T*>(a.res.ptr) + off);
 #pragma unroll
-            for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cr[u].e[e]);
+            for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cr.e[e]);
           } else if (a.res.mode != RN_RES_NONE) {
-            res_add_chunk<T>(a.res, rn[u], rh[u], rw[u], k0, v);
+            res_add_chunk<T>(a.res, n, hd, wd, k0, v);
           }
           if (a.accum) {
+            Chunk<T> co = load_chunk<T>(dst + off);
 #pragma unroll
-            for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(co[u].e[e]);
+            for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(co.e[e]);
           }
           Chunk<T> st;
 #pragma unroll
           for (int e = 0; e < CE; ++e) st.e[e] = Elem<T>::from_f(v[e]);
-          if (a.probe_ep != 1 || st.u.x == 0x12345678u) store_chunk<T>(dst + off[u], st);
+          if (a.probe_ep != 1 || st.u.x == 0x12345678u) store_chunk<T>(dst + off, st);
           if (want_stats) {
             if (!bn_bwd) {
 #pragma unroll
               for (int e = 0; e < CE; ++e) { const float vs = Elem<T>::to_f(st.e[e]); s0[e] += vs; s1[e] += vs * vs; }
             } else {
+              Chunk<T> cx = load_chunk<T>(reinterpret_cast<const T*>(a.bn_x) + off);
+              Chunk<T> cm;
+              if (a.bn_mask) cm = load_chunk<T>(reinterpret_cast<const T*>(a.bn_mask) + off);
 #pragma unroll
               for (int e = 0; e < CE; ++e) {
                 float g = Elem<T>::to_f(st.e[e]) * a.gscale;
-                if (a.bn_mask && !(Elem<T>::to_f(cm[u].e[e]) > 0.f)) g = 0.f;
-                const float xh = (Elem<T>::to_f(cx[u].e[e]) - mean[e]) * invstd[e];
+                if (a.bn_mask && !(Elem<T>::to_f(cm.e[e]) > 0.f)) g = 0.f;
+                const float xh = (Elem<T>::to_f(cx.e[e]) - mean[e]) * invstd[e];
                 s0[e] += g; s1[e] += g * xh;
               }
             }
           }
         }
       }
-    };
-    if (colok && a.probe_ep != 4) {
-      phase2(std::integral_constant<int, UBD>{});
     }
-    if (want_stats && (half & 1)) {            // one partial row per RN_CONV_STATS_ROWS (= 2 halves) output rows
+    if (want_stats && half == 1) {             // one partial row per RN_CONV_STATS_ROWS (= this tile's) output rows
       if (p2) {
 #pragma unroll
-        for (int e = 0; e < CE; ++e) {
-          red[(rl * 2 + 0) * BN + cg * CE + e] = s0[e]; red[(rl * 2 + 1) * BN + cg * CE + e] = s1[e];
-          s0[e] = s1[e] = 0.f;
-        }
+        for (int e = 0; e < CE; ++e) { red[(rl * 2 + 0) * BN + cg * CE + e] = s0[e]; red[(rl * 2 + 1) * BN + cg * CE + e] = s1[e]; }
       }
       lds_barrier();
-      const int grp = half >> 1;
-      if (m0 + grp * 2 * HR < a.M) {
+      if (m0 < a.M) {
         for (int col = tid; col < BN; col += NTH) {
           const int k = n0 + col;
           if (k >= a.Kd) continue;
           float t0 = 0.f, t1 = 0.f;
           for (int w = 0; w < LANES; ++w) { t0 += red[(w * 2 + 0) * BN + col]; t1 += red[(w * 2 + 1) * BN + col]; }
-          float* out = a.stats + ((size_t)(a.tile_base + m0 / (2 * HR) + grp) * 2) * a.Kd;
+          float* out = a.stats + ((size_t)(a.tile_base + m0 / (2 * HR)) * 2) * a.Kd;
           out[k] = t0;
           out[a.Kd + k] = t1;
         }
       }
     }
     lds_barrier();                             // ctile (and `red`) are reused by the next half
-    stamp(a.stamps, 4 + 2 * (half & 1));
+    stamp(a.stamps, 4 + 2 * half);
   }
-}
-
-typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-
-// 128-byte K rows (8 chunks of 16 B): chunk' = chunk ^ ((row>>1)&7) makes the ds_read_b128 of 16 consecutive rows at a
-// fixed chunk hit 16 distinct 16-byte slots of the 256-byte bank row, and keeps the 8-lane ds_write_b128 groups whole
-__device__ inline int swz(int row, int chunk) { return row * CPR + (chunk ^ ((row >> 1) & 7)); }
-
-__device__ inline uint4 bload(__amdgpu_buffer_rsrc_t r, unsigned off) {
-  u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);     // out-of-range offset -> zeros, no branch
-  return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
 constexpr unsigned OOB = 0xFFFFFFF0u;
-
-template <typename T, int BM, int BN, int WM, int WN, int VAR>
-__global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
-  constexpr int CE = Elem<T>::CE;
-  constexpr int ES = (int)sizeof(T);
-  constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-  constexpr int RPP = 256 / CPR;                       // rows staged per pass (32)
-  constexpr int AR = BM / RPP, BR = (BN + RPP - 1) / RPP;
-  constexpr int KS = CPR / 2;                          // MFMA k-steps per tile (2 chunks each)
-  static_assert(WM * WN == 4 && BM % (WM * 32) == 0 && BN % (WN * 32) == 0 && BM % RPP == 0, "tile");
-  __shared__ uint4 lds[2][(BM + BN) * CPR];
-  __shared__ int tap_src[MAX_TAPS + 1], tap_w[MAX_TAPS + 1];
-
-  const int tid = threadIdx.x;
-  const int nmt = (a.M + BM - 1) / BM;
-  const int mt = blockIdx.x % nmt, ntile = blockIdx.x / nmt;
-  const int m0 = mt * BM, n0 = ntile * BN;
-  const int pq = a.Pc * a.Qc;
-
-  // buffer descriptors: the activation descriptor is rebased on the first image of this tile so that per-lane byte
-  // offsets fit 32 bits for any tensor size; out-of-range offsets (padding taps, K tail) return zeros in hardware
-  const int n_first = m0 / pq;
-  const size_t img_bytes = (size_t)a.Hs * a.Ws * a.Cs * ES;
-  const size_t a_total = (size_t)a.N * img_bytes, a_base = (size_t)n_first * img_bytes;
-  const size_t a_left = a_total - a_base;
-  const __amdgpu_buffer_rsrc_t ra_desc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<char*>(reinterpret_cast<const char*>(a.src)) + a_base, (short)0, (int)(a_left > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (unsigned)a_left), 0x00020000);
-  const size_t w_total = (size_t)a.Kd * a.wrs * a.Cs * ES;
-  const __amdgpu_buffer_rsrc_t rb_desc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<void*>(a.wt), (short)0, (int)(w_total > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (unsigned)w_total), 0x00020000);
-
-  if (tid <= MAX_TAPS) {
-    int t = tid < a.nt ? tid : 0;
-    tap_src[tid] = tid < a.nt ? (a.dh[t] * a.Ws + a.dw[t]) * a.Cs * ES : 0;
-    tap_w[tid] = tid < a.nt ? a.widx[t] * a.Cs * ES : 0;
-  }
-
-  // ---- per-thread staging roles: chunk column c of rows r0 + RPP*i ----
-  const int c = tid % CPR, r0 = tid / CPR;
-  unsigned abase[AR];
-  unsigned long long amask[AR];
-#pragma unroll
-  for (int i = 0; i < AR; ++i) {
-    int m = m0 + r0 + RPP * i;
-    amask[i] = 0;
-    abase[i] = 0;
-    if (m < a.M) {
-      int n = m / pq, rem = m - n * pq;
-      int p = rem / a.Qc, q = rem - p * a.Qc;
-      int hb = p * a.ss, wb = q * a.ss;
-      abase[i] = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES);   // may wrap for border taps: masked
-      unsigned long long mk = 0;
-      for (int t = 0; t < a.nt; ++t) {
-        int h = hb + a.dh[t], w = wb + a.dw[t];
-        if ((unsigned)h < (unsigned)a.Hs && (unsigned)w < (unsigned)a.Ws) mk |= 1ull << t;
-      }
-      amask[i] = mk;
-    }
-  }
-  unsigned bbase[BR];
-#pragma unroll
-  for (int i = 0; i < BR; ++i) {
-    int rn = r0 + RPP * i;
-    int k = n0 + rn;
-    bbase[i] = (rn < BN && k < a.Kd) ? (unsigned)((size_t)k * a.wrs * a.Cs * ES) : OOB;     // weights < 4 GB (checked on the host)
-  }
-  __syncthreads();
-
-  uint4 ra[AR], rb[BR];
-  int tap = 0, cc = c;
-  while (cc >= a.cpt) { cc -= a.cpt; ++tap; }
-
-  auto load_tile = [&]() {
-    const bool kv = tap < a.nt;
-    const int tp = kv ? tap : 0;
-    const unsigned so = (unsigned)(tap_src[tp] + cc * 16), wo = (unsigned)(tap_w[tp] + cc * 16);
-#pragma unroll
-    for (int i = 0; i < AR; ++i) ra[i] = bload(ra_desc, (kv && ((amask[i] >> tp) & 1)) ? abase[i] + so : OOB);
-#pragma unroll
-    for (int i = 0; i < BR; ++i) rb[i] = bload(rb_desc, (kv && bbase[i] != OOB) ? bbase[i] + wo : OOB);
-    cc += CPR;
-    while (cc >= a.cpt) { cc -= a.cpt; ++tap; }
-  };
-  auto store_tile = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < AR; ++i) lds[buf][swz(r0 + RPP * i, c)] = ra[i];
-#pragma unroll
-    for (int i = 0; i < BR; ++i) {
-      int rn = r0 + RPP * i;
-      if (rn < BN) lds[buf][BM * CPR + swz(rn, c)] = rb[i];
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int wave = tid >> 6, lane = tid & 63;
-  const int wm = wave / WN, wn = wave % WN;
-  const int lr = lane & 31, lh = lane >> 5;
-  const int arow0 = wm * (BM / WM) + lr, brow0 = wn * (BN / WN) + lr;
-
-  if (a.nk > 0) {
-    load_tile();
-    store_tile(0);
-  }
-  __syncthreads();
-  for (int it = 0; it < a.nk; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < a.nk) load_tile();
-    if constexpr (VAR & 1) {
-      // fragment double buffering: the ds_reads of k-step ks+1 are in flight under the MFMAs of k-step ks
-      uint4 fa[2][TM], fb[2][TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) fa[0][i] = lds[buf][swz(arow0 + 32 * i, lh)];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[0][j] = lds[buf][BM * CPR + swz(brow0 + 32 * j, lh)];
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int cur = ks & 1, nxt = cur ^ 1;
-        if (ks + 1 < KS) {
-          const int ch = 2 * (ks + 1) + lh;
-#pragma unroll
-          for (int i = 0; i < TM; ++i) fa[nxt][i] = lds[buf][swz(arow0 + 32 * i, ch)];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) fb[nxt][j] = lds[buf][BM * CPR + swz(brow0 + 32 * j, ch)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur][i], fb[cur][j], acc[i][j]);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-#pragma unroll
-      for (int ks = 0; ks < KS; ++ks) {
-        const int ch = 2 * ks + lh;
-        uint4 fa[TM], fb[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) fa[i] = lds[buf][swz(arow0 + 32 * i, ch)];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[j] = lds[buf][BM * CPR + swz(brow0 + 32 * j, ch)];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[i], fb[j], acc[i][j]);
-      }
-    }
-    if (it + 1 < a.nk) store_tile(buf ^ 1);
-    __syncthreads();
-  }
-
-  igemm_epilogue<T, BM, BN, WM, WN, TM, TN>(a, acc, m0, n0, tid >> 6, tid & 63, reinterpret_cast<float*>(&lds[0][0]));
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// LDS-DMA variant: the A (activation) and B (weight) tiles go global -> LDS directly with `buffer_load_dwordx4 ... lds`
-// (no staging VGPRs, no ds_write: the VGPR->LDS store path was the busiest LDS client of the register-staged kernel).
-// Facts it relies on (tools/probes/lds_dma_oob.hip, measured on gfx950): the LDS destination of a wave instruction is
-// base + lane*16 (lane-linear, 1 KiB per instruction); an out-of-range buffer offset writes ZEROS (padding taps, K tail);
-// masked lanes write nothing.  The XOR swizzle therefore moves to the SOURCE side: lane l of an instruction covering rows
-// [R0, R0+64/CPRT) owns physical slot p = l % CPRT of row R0 + l / CPRT and fetches logical chunk p ^ swz(row).
-// ---------------------------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 template <int CPRT> __device__ inline int swz_t(int row, int chunk) {
@@ -528,14 +359,18 @@ __device__ inline void load_tap_grid(const IgemmArgs& a, const int* taps, TapGri
   }
 }
 __device__ inline unsigned long long tap_mask(const IgemmArgs& a, const TapGrid& g, int hb, int wb) {
+  // the loop bounds are wave-uniform (scalar branches): a 1x1 kernel runs 1 + 1 checks, a 3x3 kernel 3 + 3
   unsigned colbits = 0;
 #pragma unroll
-  for (int j = 0; j < MAX_GRID; ++j)
+  for (int j = 0; j < MAX_GRID; ++j) {
+    if (j >= a.ntw) break;
     if ((unsigned)(wb + g.dw[j]) < (unsigned)a.Ws) colbits |= 1u << j;
+  }
   unsigned long long mk = 0;
   int sh = 0;
 #pragma unroll
   for (int i = 0; i < MAX_GRID; ++i) {
+    if (i >= a.nth) break;
     if ((unsigned)(hb + g.dh[i]) < (unsigned)a.Hs) mk |= (unsigned long long)colbits << sh;
     sh += a.ntw;
   }
@@ -613,6 +448,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
   __shared__ uint4 smem[NSTG * STAGE + TAP_INTS / 4];
   int* taps = reinterpret_cast<int*>(&smem[NSTG * STAGE]);     // fill_tap_tables
 
+  preload_args(a);
   const int tid = threadIdx.x, lane = tid & 63;
   stamp(a.stamps, 0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: feeds M0 / SGPR operands
@@ -773,6 +609,7 @@ __global__ __launch_bounds__(512, BM >= 256 ? 1 : 2) void igemm_ws_kernel(const 
   __shared__ uint4 smem[NSTG * STAGE + TAP_INTS / 4];
   int* taps = reinterpret_cast<int*>(&smem[NSTG * STAGE]);
 
+  preload_args(a);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= 4;
@@ -906,21 +743,15 @@ __global__ __launch_bounds__(512, BM >= 256 ? 1 : 2) void igemm_ws_kernel(const 
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   int nmt = cdiv(a.M, BM), nnt = cdiv(a.Kd, BN);
-  // shipped dispatch: when the grid leaves at most one workgroup per CU (256 CUs), the wave-specialised kernel (4 consumer +
-  // 4 loader waves, 3-stage DMA ring) keeps the matrix pipe fed (+21 % measured on WRN-28-10's 8x8 stage); with two or
-  // more workgroups per CU the homogeneous 4-wave DMA kernel at two workgroups per CU is faster (measured).
+  // when the grid leaves at most one workgroup per CU (256 CUs), the wave-specialised kernel (4 consumer + 4 loader waves,
+  // 3-stage DMA ring) keeps the matrix pipe fed (+21 % measured on WRN-28-10's 8x8 stage); with two or more workgroups per
+  // CU the homogeneous 4-wave DMA kernel at two workgroups per CU is faster (measured).  rn_set_variant: 128 forces the
+  // wave-specialised kernel, 512 forbids it (A/B in tools/conv_bench.py).
   const bool one_per_cu = nmt * nnt <= 256;
-  if ((g_rn_variant & 128) || (one_per_cu && !(g_rn_variant & (2 | 8 | 16 | 512)))) {
-    if (g_rn_variant & 256) hipLaunchKernelGGL((igemm_ws_kernel<T, BM, BN, WM, WN, 8, 4>), dim3(nmt * nnt), dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((igemm_ws_kernel<T, BM, BN, WM, WN, 8, 3>), dim3(nmt * nnt), dim3(512), 0, s, a);
-  } else if (!(g_rn_variant & (2 | 8 | 16))) {          // LDS-DMA staging, 128-byte K rows, 2 LDS stages
+  if ((g_rn_variant & 128) || (one_per_cu && !(g_rn_variant & 512)))
+    hipLaunchKernelGGL((igemm_ws_kernel<T, BM, BN, WM, WN, 8, 3>), dim3(nmt * nnt), dim3(512), 0, s, a);
+  else
     hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, 8, 2>), dim3(nmt * nnt), dim3(256), 0, s, a);
-  } else if (g_rn_variant & 16) {
-    IgemmArgs b = a;
-    b.nk = cdiv((long)a.nt * a.cpt, 4);
-    hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, 4, 4>), dim3(nmt * nnt), dim3(256), 0, s, b);
-  } else if (g_rn_variant & 2) hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, 0>), dim3(nmt * nnt), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((igemm_kernel<T, BM, BN, WM, WN, 1>), dim3(nmt * nnt), dim3(256), 0, s, a);      // bit3: register-staged kernel
   RN_CHECK_LAUNCH("igemm");
   return 0;
 }
@@ -928,36 +759,9 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   const int K = a.Kd;
-  // column tile: the widest of {160,128,96,64,32} that wastes no 32-column MFMA tile
-  if ((g_rn_variant & 4096) && (K % 160 == 0 || K % 128 == 0)) {           // experiment: 256-row tile, 8 homogeneous waves, 3-stage ring
-    const int bn = K % 160 == 0 ? 160 : 128;
-    const int nmt = cdiv(a.M, 256), nnt = K / bn;
-    if (nmt * nnt >= 256) {
-      if (bn == 160) hipLaunchKernelGGL((igemm_dma_kernel<T, 256, 160, 8, 1, 8, 3>), dim3(nmt * nnt), dim3(512), 0, s, a);
-      else hipLaunchKernelGGL((igemm_dma_kernel<T, 256, 128, 8, 1, 8, 3>), dim3(nmt * nnt), dim3(512), 0, s, a);
-      RN_CHECK_LAUNCH("igemm_dma256");
-      return 0;
-    }
-  }
-  if ((g_rn_variant & 2048) && (K % 160 == 0 || K % 128 == 0)) {           // experiment: 256-row tile, consumer waves 64 x BN
-    const int bn = K % 160 == 0 ? 160 : 128;
-    const int nmt = cdiv(a.M, 256), nnt = K / bn;
-    if (nmt * nnt >= 256) {
-      if (bn == 160) hipLaunchKernelGGL((igemm_ws_kernel<T, 256, 160, 4, 1, 8, 3>), dim3(nmt * nnt), dim3(512), 0, s, a);
-      else hipLaunchKernelGGL((igemm_ws_kernel<T, 256, 128, 4, 1, 8, 3>), dim3(nmt * nnt), dim3(512), 0, s, a);
-      RN_CHECK_LAUNCH("igemm_ws256");
-      return 0;
-    }
-  }
-  if (K % 160 == 0) {
-    if ((g_rn_variant & 4) && cdiv(a.M, 256) * (K / 160) >= 256) {      // experiment: 256x160 tile shared by 8 waves
-      int nmt = cdiv(a.M, 256), nnt = K / 160;
-      hipLaunchKernelGGL((igemm_dma_kernel<T, 256, 160, 8, 1, 8, 2>), dim3(nmt * nnt), dim3(512), 0, s, a);
-      RN_CHECK_LAUNCH("igemm256");
-      return 0;
-    }
-    return launch_cfg<T, 128, 160, 4, 1>(a, s);
-  }
+  // column tile: the widest of {160,128,96,64,32} that wastes no 32-column MFMA tile.  (256-row tiles -- 4 consumer waves of
+  // 64 x BN, or 8 homogeneous waves with a 3-stage ring -- were measured 5-12 % slower on the WRN-28-10 shapes and removed.)
+  if (K % 160 == 0) return launch_cfg<T, 128, 160, 4, 1>(a, s);
   if (K % 128 == 0) return launch_cfg<T, 128, 128, 2, 2>(a, s);
   if (K % 96 == 0) return launch_cfg<T, 128, 96, 4, 1>(a, s);
   if (K > 32) return launch_cfg<T, 128, 64, 2, 2>(a, s);
