@@ -2,6 +2,7 @@
 // Linear (resnet.py:77-81,117-120), softmax cross-entropy + top-k error (metrics.py:10-29) and a fused flat SGD step
 // (torch.optim.SGD rule; optim_util.py:11-18, config.yaml:22-28).  gfx950.
 #include "common.h"
+#include <algorithm>
 #include <float.h>
 
 namespace {
@@ -150,33 +151,58 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x
 template <typename T>
 __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx, T* __restrict__ dx, int N, int H,
                                                          int W, int C, int P, int Q, int k, int stride, int pad) {
+  // gather form: an input pixel collects from the <= ceil(k/stride)^2 windows that cover it.  One workgroup walks image
+  // rows (n, h); threads walk (w, channel chunk) with 32-bit index math; the argmax bytes of a chunk come in ONE load.
   constexpr int CE = Elem<T>::CE;
   const int CC = C / CE;
-  const long n = (long)N * H * W * CC;
-  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
-    const int cg = (int)(i % CC);
-    long pix = i / CC;
-    const int w = (int)(pix % W); pix /= W;
-    const int h = (int)(pix % H);
-    const int nn = (int)(pix / H);
-    float g[CE];
-#pragma unroll
-    for (int e = 0; e < CE; ++e) g[e] = 0.f;
+  const int per_row = W * CC;
+  for (int row = blockIdx.x; row < N * H; row += gridDim.x) {
+    const int nn = row / H, h = row - nn * H;
     const int p_lo = max(0, (h + pad - k + stride) / stride), p_hi = min(P - 1, (h + pad) / stride);
-    const int q_lo = max(0, (w + pad - k + stride) / stride), q_hi = min(Q - 1, (w + pad) / stride);
-    for (int p = p_lo; p <= p_hi; ++p)
-      for (int q = q_lo; q <= q_hi; ++q) {
-        const int me = (h - (p * stride - pad)) * k + (w - (q * stride - pad));       // my position inside window (p, q)
+    for (int j = threadIdx.x; j < per_row; j += NT) {
+      const int w = j / CC, cg = j - w * CC;
+      const int q_lo = max(0, (w + pad - k + stride) / stride), q_hi = min(Q - 1, (w + pad) / stride);
+      float g[CE];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) g[e] = 0.f;
+      auto take = [&](int p, int q, const Chunk<T>& d, const unsigned char* ib) {
+        const unsigned me = (unsigned)((h - (p * stride - pad)) * k + (w - (q * stride - pad)));     // my position inside window (p, q)
+#pragma unroll
+        for (int e = 0; e < CE; ++e) if (ib[e] == me) g[e] += Elem<T>::to_f(d.e[e]);
+      };
+      auto fetch = [&](int p, int q, Chunk<T>& d, unsigned char* ib) {
         const size_t o = (((size_t)nn * P + p) * Q + q) * C + cg * CE;
-        Chunk<T> d = load_chunk<T>(dy + o);
-        const unsigned char* ip = idx + o;
+        d = load_chunk<T>(dy + o);
+        if constexpr (CE == 8) { *reinterpret_cast<uint2*>(ib) = *reinterpret_cast<const uint2*>(idx + o); }
+        else { *reinterpret_cast<unsigned*>(ib) = *reinterpret_cast<const unsigned*>(idx + o); }
+      };
+      if (p_hi - p_lo <= 1 && q_hi - q_lo <= 1) {            // <= 2 x 2 windows (3x3 stride 2): all loads issued before the first use
+        Chunk<T> d[4];
+        unsigned char ib[4][CE];
+        bool ok[4];
 #pragma unroll
-        for (int e = 0; e < CE; ++e) if (ip[e] == me) g[e] += Elem<T>::to_f(d.e[e]);
+        for (int u = 0; u < 4; ++u) {
+          const int p = p_lo + (u >> 1), q = q_lo + (u & 1);
+          ok[u] = p <= p_hi && q <= q_hi;
+          if (ok[u]) fetch(p, q, d[u], ib[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ok[u]) take(p_lo + (u >> 1), q_lo + (u & 1), d[u], ib[u]);
+      } else {
+        for (int p = p_lo; p <= p_hi; ++p)
+          for (int q = q_lo; q <= q_hi; ++q) {
+            Chunk<T> d;
+            unsigned char ib[CE];
+            fetch(p, q, d, ib);
+            take(p, q, d, ib);
+          }
       }
-    Chunk<T> o;
+      Chunk<T> o;
 #pragma unroll
-    for (int e = 0; e < CE; ++e) o.e[e] = Elem<T>::from_f(g[e]);
-    store_chunk<T>(dx + i * CE, o);
+      for (int e = 0; e < CE; ++e) o.e[e] = Elem<T>::from_f(g[e]);
+      store_chunk<T>(dx + ((size_t)row * W + w) * C + cg * CE, o);
+    }
   }
 }
 
@@ -393,9 +419,9 @@ extern "C" int rn_maxpool_bwd(const void* dy, const unsigned char* argmax, void*
   if (int e = check_pool(dtype, N, H, W, C, k, stride, pad, "rn_maxpool_bwd")) return e;
   RN_CHECK_ARG(dy && argmax && dx, "rn_maxpool_bwd: null pointer");
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
-  const long n = (long)N * H * W * (C / (dtype == RN_F32 ? 4 : 8));
-  if (dtype == RN_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const float*)dy, argmax, (float*)dx, N, H, W, C, P, Q, k, stride, pad);
-  else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const bf16_t*)dy, argmax, (bf16_t*)dx, N, H, W, C, P, Q, k, stride, pad);
+  const int rows_grid = (int)std::min<long>((long)N * H, 8192);
+  if (dtype == RN_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(rows_grid), dim3(NT), 0, as_stream(s), (const float*)dy, argmax, (float*)dx, N, H, W, C, P, Q, k, stride, pad);
+  else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(rows_grid), dim3(NT), 0, as_stream(s), (const bf16_t*)dy, argmax, (bf16_t*)dx, N, H, W, C, P, Q, k, stride, pad);
   RN_CHECK_LAUNCH("maxpool_bwd");
   return 0;
 }
