@@ -19,15 +19,29 @@ import torch.distributed as dist
 
 
 class BucketPlan:
-    """splits the production-ordered flat gradient buffer into contiguous buckets of at least `cap_bytes`."""
+    """splits the production-ordered flat gradient buffer into contiguous buckets of at least `cap_bytes`.  The gradients
+    produced LAST (stem, first block) get a small bucket of their own (<= `last_cap_bytes`): only that collective cannot
+    overlap with the backward, so its size is the exposed tail of every step."""
 
-    def __init__(self, grad_order: List[str], offsets: dict, total_elems: int, cap_bytes: int, first_cap_bytes: Optional[int] = None):
+    def __init__(self, grad_order: List[str], offsets: dict, total_elems: int, cap_bytes: int, first_cap_bytes: Optional[int] = None,
+                 last_cap_bytes: int = 0):
+        n = len(grad_order)
+        starts = [offsets[k] for k in grad_order]
+        ends = starts[1:] + [total_elems]
+        tail_from = n                                   # index of the first gradient of the tail bucket (n: no tail bucket)
+        if last_cap_bytes > 0 and n > 1:
+            tail_from = n - 1                           # at least the last gradient, then as many as fit under the cap
+            while tail_from > 1 and (total_elems - starts[tail_from - 1]) * 4 <= last_cap_bytes:
+                tail_from -= 1
         self.bounds = []          # (last_grad_index, start_elem, end_elem)
         start, cap = 0, (first_cap_bytes or cap_bytes)
-        for i, key in enumerate(grad_order):
-            end = offsets[grad_order[i + 1]] if i + 1 < len(grad_order) else total_elems
-            if (end - start) * 4 >= cap or i + 1 == len(grad_order):
-                self.bounds.append((i, start, end))
+        for i in range(n):
+            end = ends[i]
+            last = i + 1 == n
+            cut_for_tail = (i + 1 == tail_from) and end > start
+            if (end - start) * 4 >= cap or last or cut_for_tail:
+                if end > start:
+                    self.bounds.append((i, start, end))
                 start, cap = end, cap_bytes
         assert not self.bounds or self.bounds[-1][2] == total_elems
 
@@ -36,9 +50,9 @@ class GradReducer:
     """attach to a ResNet: ``reducer = GradReducer(model, world_size)``; after ``loss.backward()`` call
     ``reducer.finish()`` -- gradients in ``p.grad`` are then the mean over ranks (views of the flat buffer)."""
 
-    def __init__(self, model, world_size: int, bucket_cap_mb: float = 32.0, first_bucket_mb: float = 4.0, group=None):
+    def __init__(self, model, world_size: int, bucket_cap_mb: float = 32.0, first_bucket_mb: float = 4.0, last_bucket_mb: float = 1.0, group=None):
         self.model, self.world, self.group = model, world_size, group
-        self.cap, self.first_cap = int(bucket_cap_mb * 2 ** 20), int(first_bucket_mb * 2 ** 20)
+        self.cap, self.first_cap, self.last_cap = int(bucket_cap_mb * 2 ** 20), int(first_bucket_mb * 2 ** 20), int(last_bucket_mb * 2 ** 20)
         self._plans = {}
         self._eng = None
         self._next = 0
@@ -65,7 +79,7 @@ class GradReducer:
     def _bplan(self, eng):
         bp = self._plans.get(id(eng))
         if bp is None:
-            bp = BucketPlan(eng.plan.grad_order, eng.grad_offsets, eng.flat_grad.numel(), self.cap, self.first_cap)
+            bp = BucketPlan(eng.plan.grad_order, eng.grad_offsets, eng.flat_grad.numel(), self.cap, self.first_cap, self.last_cap)
             self._plans[id(eng)] = bp
         return bp
 

@@ -216,3 +216,23 @@ def test_two_ranks_on_gpu_match_single_process(tmp_path, sync_bn):
         scale = max(np.abs(v).max() for v in gs[0].values())
         for k in gs[0]:
             assert np.abs(got['g.' + k] - 0.5 * (gs[0][k] + gs[1][k])).max() < 1e-4 * scale, k
+
+
+def test_bucket_plan_tail_bucket():
+    """the gradients produced last (the only collective that cannot overlap with the backward) get a small bucket."""
+    from pytorch_ddp_resnet_amd.ddp import BucketPlan
+    sizes = [1000] * 3 + [8_000_000] * 4 + [200_000] * 3 + [4000, 100]
+    order = [f'g{i}' for i in range(len(sizes))]
+    off, o = {}, 0
+    for k, sz in zip(order, sizes):
+        off[k] = o
+        o += sz
+    bp = BucketPlan(order, off, o, 32 << 20, 4 << 20, 1 << 20)
+    assert bp.bounds[0][1] == 0 and bp.bounds[-1][2] == o
+    for (_, a0, b0), (_, a1, _) in zip(bp.bounds, bp.bounds[1:]):
+        assert b0 == a1 and b0 > a0
+    last = bp.bounds[-1]
+    assert (last[2] - last[1]) * 4 <= (1 << 20) and last[0] == len(order) - 1
+    assert (bp.bounds[-2][2] - bp.bounds[-2][1]) * 4 >= (32 << 20)         # the bucket in front of it was not shrunk
+    one = BucketPlan(order[:1], {order[0]: 0}, sizes[0], 32 << 20, 4 << 20, 1 << 20)
+    assert one.bounds == [(0, 0, sizes[0])]
