@@ -265,6 +265,46 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
   }
 }
 
+// Small outputs split many ways (1x1 convolutions of thin layers: 1,024 outputs x 512 slabs): one thread per output would walk
+// the slabs serially (measured 43 us).  Here 16 threads share an output chunk, each sums every 16th slab with 4 loads in
+// flight, and the 16 partial sums are combined through LDS in a fixed order (bitwise reproducible).
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n, int splits, int accum) {
+  __shared__ float4 part[16][17];
+  const long n4 = n >> 2;
+  const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
+  for (long base = (long)blockIdx.x * 16; base < n4; base += (long)gridDim.x * 16) {
+    const long i = base + o;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < n4) {
+      int k = sl;
+      for (; k + 48 < splits; k += 64) {
+        const float4 v0 = reinterpret_cast<const float4*>(ws + (size_t)k * n)[i];
+        const float4 v1 = reinterpret_cast<const float4*>(ws + (size_t)(k + 16) * n)[i];
+        const float4 v2 = reinterpret_cast<const float4*>(ws + (size_t)(k + 32) * n)[i];
+        const float4 v3 = reinterpret_cast<const float4*>(ws + (size_t)(k + 48) * n)[i];
+        s.x += v0.x; s.y += v0.y; s.z += v0.z; s.w += v0.w;
+        s.x += v1.x; s.y += v1.y; s.z += v1.z; s.w += v1.w;
+        s.x += v2.x; s.y += v2.y; s.z += v2.z; s.w += v2.w;
+        s.x += v3.x; s.y += v3.y; s.z += v3.z; s.w += v3.w;
+      }
+      for (; k < splits; k += 16) {
+        const float4 v = reinterpret_cast<const float4*>(ws + (size_t)k * n)[i];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+    }
+    part[sl][o] = s;
+    __syncthreads();
+    if (sl == 0 && i < n4) {
+      float4 t = part[0][o];
+#pragma unroll
+      for (int l = 1; l < 16; ++l) { const float4 v = part[l][o]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+      if (accum) { const float4 v = reinterpret_cast<float4*>(dw)[i]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+      reinterpret_cast<float4*>(dw)[i] = t;
+    }
+    __syncthreads();
+  }
+}
+
 struct WCfg { int bk, bc; };
 
 inline int pick_tile(int n) {       // block tile edge from {160,128,64,32}: fewest tiles, then least padding
@@ -369,11 +409,19 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   int e = dtype == RN_F32 ? dispatch_w<float>(a, bk, bc, as_stream(s)) : dispatch_w<bf16_t>(a, bk, bc, as_stream(s));
   if (e) return e;
   if (!direct) {
-    int blocks = (int)((n / 4 + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), dw_krsc, (long)n,
-                       a.splits, (flags & RN_F_ACCUM) ? 1 : 0);
+    const long n4 = (long)(n / 4);
+    if (a.splits >= 32 && n4 < 65536) {                  // few outputs, many slabs: split the slab walk over 16 threads
+      int blocks = (int)((n4 + 15) / 16);
+      if (blocks > 4096) blocks = 4096;
+      hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(blocks), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), dw_krsc, (long)n,
+                         a.splits, (flags & RN_F_ACCUM) ? 1 : 0);
+    } else {
+      int blocks = (int)((n4 + 255) / 256);
+      if (blocks > 2048) blocks = 2048;
+      if (blocks < 1) blocks = 1;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), dw_krsc, (long)n,
+                         a.splits, (flags & RN_F_ACCUM) ? 1 : 0);
+    }
     RN_CHECK_LAUNCH("wgrad_reduce");
   }
   return 0;
