@@ -84,12 +84,15 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print the per-op-kind time table to stderr')
     ap.add_argument('--sync-bn', action='store_true')
+    ap.add_argument('--dropout', type=float, default=None, help='override the workload\'s dropout probability (diagnostics)')
     ap.add_argument('--per-op', type=int, default=0, help='with --breakdown: list the N slowest single ops with their geometry')
     args = ap.parse_args()
 
     cfg = dict(WORKLOADS[args.workload])
     if args.batch:
         cfg['batch'] = args.batch
+    if args.dropout is not None:
+        cfg['p'] = args.dropout
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -5,6 +5,7 @@ PyTorch is used here for device memory (torch.empty on the caching allocator), t
 ddp.py, torch.distributed; all arithmetic of the hot path happens inside the library.
 """
 import ctypes as C
+import os
 from typing import Callable, Dict, Optional
 
 import torch
@@ -89,7 +90,7 @@ class Engine:
         # host launch path, which is what bounds thin networks (ResNet-v1-20: ~150 launches, v2-164: ~1500 per step).
         # Only for ranges with nothing host-side in between (no hook consumer) and no per-step kernel argument (the
         # dropout seed is one): captured once per binding, invalidated when any bound pointer changes.
-        self.use_graphs = not any(op.seed for op in plan.ops)
+        self.use_graphs = not any(op.seed for op in plan.ops) and os.environ.get('RN_NO_GRAPHS', '0') != '1'
         self._graphs = {}
         self._profiling = False
 
