@@ -169,7 +169,22 @@ def main():
         eng.profile(False)
         achieved = conv_f / (conv_t * 1e-3) / 1e12 if conv_t > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
-        roof = dict(bound='mfma', achieved=round(achieved, 1), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4), traffic=None,
+        # HBM-side bytes per conv launch: from the committed PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE, separate
+        # rocprofv3 --pmc runs, tools/summarize_profiles.py); a PMC pass cannot run inside the timed process
+        traffic, traffic_src = None, None
+        pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'latest_pmc_summary.json')
+        if args.workload == 'wrn-28-10' and args.dtype == 'bf16' and os.path.exists(pmc):
+            ks = json.load(open(pmc))
+            tot_b = tot_n = 0.0
+            for name, e in ks['kernels'].items():
+                if name.startswith(('igemm_', 'wgrad_kernel')) and 'hbm_read_MB_per_launch' in e:
+                    n_l = e['launches_in_trace']
+                    tot_b += n_l * (e['hbm_read_MB_per_launch'] + e.get('hbm_write_MB_per_launch', 0.0)) * 1e6
+                    tot_n += n_l
+            if tot_n:
+                traffic, traffic_src = int(tot_b / tot_n), f"profiles/{ks['tag']}_pmc_summary.json"
+        roof = dict(bound='mfma', achieved=round(achieved, 1), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4), traffic=traffic,
+                    traffic_unit='bytes per conv launch (HBM side)', traffic_source=traffic_src,
                     kernel='igemm_kernel + wgrad_kernel (implicit-GEMM conv fwd/dgrad/wgrad launches)',
                     launches_per_step=nconv // nprof, avg_launch_ms=round(conv_t / max(nconv, 1), 4),
                     algorithmic_gflop_per_launch=round(conv_f / max(nconv, 1) / 1e9, 2),

@@ -59,6 +59,7 @@ struct IgemmArgs {
   unsigned probe_mask;     // timing probe (rn_set_variant bit6): AND-mask on DMA source offsets, 0xFFFFFFFF in production
   unsigned long long* stamps;   // diagnostic: per-workgroup s_memtime stamps [grid][16] (rn_set_stamp_buffer), NULL in production
   int probe_ep;            // timing probes: 1 = skip the global stores of the epilogue, 2 = skip the epilogue
+  int xcd_remap;           // 1: blockIdx -> tile through the bijective XCD remap, column tiles fastest
   int dh[MAX_TAPS], dw[MAX_TAPS], widx[MAX_TAPS];
 };
 
@@ -71,7 +72,7 @@ __device__ inline void preload_args(const IgemmArgs& a) {
   RN_TOUCH(a.nt); RN_TOUCH(a.wrs); RN_TOUCH(a.cpt); RN_TOUCH(a.nk); RN_TOUCH(a.nth); RN_TOUCH(a.ntw);
   RN_TOUCH(a.magic_pq); RN_TOUCH(a.magic_q); RN_TOUCH(a.accum); RN_TOUCH(a.tile_base);
   RN_TOUCH(a.stats); RN_TOUCH(a.bn_x); RN_TOUCH(a.bn_mask); RN_TOUCH(a.bn_coef); RN_TOUCH(a.bias); RN_TOUCH(a.gscale);
-  RN_TOUCH(a.probe_mask); RN_TOUCH(a.stamps); RN_TOUCH(a.probe_ep);
+  RN_TOUCH(a.probe_mask); RN_TOUCH(a.stamps); RN_TOUCH(a.probe_ep); RN_TOUCH(a.xcd_remap);
 #undef RN_TOUCH
 }
 
@@ -453,7 +454,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
   stamp(a.stamps, 0);
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably wave-uniform: feeds M0 / SGPR operands
   const int nmt = (a.M + BM - 1) / BM;
-  const int mt = blockIdx.x % nmt, ntile = blockIdx.x / nmt;
+  // tile order: the column tiles of one row tile are neighbours (they read the same input rows), then the next row tile
+  // (which shares its halo rows); the XCD remap puts consecutive tiles on ONE XCD, so those re-reads hit its L2
+  int bid = blockIdx.x;
+  if (a.xcd_remap) {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nnt_ = gridDim.x / nmt;
+  const int ntile = a.xcd_remap ? bid % nnt_ : bid / nmt, mt = a.xcd_remap ? bid / nnt_ : bid % nmt;
   const int m0 = mt * BM, n0 = ntile * BN;
   const int pq = a.Pc * a.Qc;
 
@@ -616,7 +625,15 @@ __global__ __launch_bounds__(512, BM >= 256 ? 1 : 2) void igemm_ws_kernel(const 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= 4;
   const int nmt = (a.M + BM - 1) / BM;
-  const int mt = blockIdx.x % nmt, ntile = blockIdx.x / nmt;
+  // tile order: the column tiles of one row tile are neighbours (they read the same input rows), then the next row tile
+  // (which shares its halo rows); the XCD remap puts consecutive tiles on ONE XCD, so those re-reads hit its L2
+  int bid = blockIdx.x;
+  if (a.xcd_remap) {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nnt_ = gridDim.x / nmt;
+  const int ntile = a.xcd_remap ? bid % nnt_ : bid / nmt, mt = a.xcd_remap ? bid / nnt_ : bid % nmt;
   const int m0 = mt * BM, n0 = ntile * BN;
   const int pq = a.Pc * a.Qc;
 
@@ -813,6 +830,7 @@ static void fill_ep(IgemmArgs& a, const rn_conv_epilogue* ep, int tile_base) {
   a.bias = ep ? ep->bias : nullptr;
   a.probe_mask = (g_rn_variant & 64) ? 0x0000FFF0u : 0xFFFFFFFFu;
   a.stamps = reinterpret_cast<unsigned long long*>(g_rn_stamps);
+  a.xcd_remap = (g_rn_variant & 8) ? 0 : 1;
   a.probe_ep = (g_rn_variant & 8192) ? 1 : ((g_rn_variant & 16384) ? 2 : ((g_rn_variant & 32768) ? 3 : ((g_rn_variant & 65536) ? 4 : 0)));
 }
 

@@ -26,6 +26,7 @@ struct WgradArgs {
   int splits, rows_per_split;
   int kt, ct;        // tiles along K and C
   unsigned magic_pq, magic_q;   // floor(2^32 / (P*Q)), floor(2^32 / Q): division by multiply-high + one correction
+  int xcd_remap;     // 1: blockIdx -> work item through the bijective XCD remap
   int im2col;        // 1: the taps are folded into the column dimension (stem: C = one chunk per tap), dy is read once per column tile
   int dh[MAX_TAPS], dw[MAX_TAPS];
 };
@@ -112,10 +113,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     if (tid < MAX_TAPS) { tdh[tid] = tid < a.RS ? a.dh[tid] : 0; tdw[tid] = tid < a.RS ? a.dw[tid] : 0; }
     __syncthreads();
   }
+  // work order: tap fastest, then C tile, K tile, pixel split slowest -- the workgroups that read the same dy / x rows are
+  // neighbours.  With the XCD remap (consecutive work items on ONE XCD instead of round-robin over the 8) their re-reads
+  // hit that XCD's L2 instead of going to the memory side 9 times (one per tap).
   int b = blockIdx.x;
-  const int split = b % a.splits; b /= a.splits;
+  if (a.xcd_remap) {
+    const int nwg = gridDim.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
   const int t = b % a.nt; b /= a.nt;
-  const int ctile = b % a.ct, ktile = b / a.ct;
+  const int ctile = b % a.ct; b /= a.ct;
+  const int ktile = b % a.kt;
+  const int split = b / a.kt;
   const int k0 = ktile * BK_, c0 = ctile * BC_;
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
@@ -385,6 +394,7 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   const int bk = pick_tile(g->K), bc = col_tile(g, ic);
   WgradArgs a{};
   a.im2col = ic ? 1 : 0;
+  { extern int g_rn_variant; a.xcd_remap = (g_rn_variant & 4) ? 0 : 1; }
   {
     const unsigned long long pq = (unsigned long long)g->P * g->Q;
     a.magic_pq = pq <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / pq);
