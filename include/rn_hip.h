@@ -73,7 +73,8 @@ enum {
   RN_F_NEED_DGRAD_PACK = 1 << 4,
   RN_F_SKIP_FWD_PACK = 1 << 5,
   RN_F_NO_DX = 1 << 6,        /* pool_fc_bwd etc.: input gradient not needed                */
-  RN_F_MASK_RECOMPUTE = 1 << 7 /* bn_bwd_*: mask = [x*scale+shift > 0] & dropout hash, recomputed instead of read (mask_src NULL) */
+  RN_F_MASK_RECOMPUTE = 1 << 7, /* bn_bwd_*: mask = [x*scale+shift > 0] & dropout hash, recomputed instead of read (mask_src NULL) */
+  RN_F_FORK = 1 << 8          /* plan executor: run this weight-gradient op on the side stream (rn_plan_set_overlap) */
 };
 
 #define RN_OP_NBUF 8
@@ -107,6 +108,10 @@ int rn_plan_bind(rn_plan* plan, const void* const* device_ptrs, int n_bufs);
 int rn_plan_set_bytes(rn_plan* plan, int slot, size_t bytes);
 /* runs ops [first, last) in order on `stream`; step_seed feeds the dropout hash (same value forward and backward) */
 int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_seed, rn_stream stream);
+/* weight-gradient ops of the plan on a second (low-priority) stream, forked by events at their list position; the
+ * caller joins before it consumes weight gradients (end of the backward, or before reducing a gradient bucket) */
+int rn_plan_set_overlap(rn_plan* plan, int enable);
+int rn_plan_join(rn_plan* plan, rn_stream stream);
 int rn_plan_num_ops(const rn_plan* plan);
 /* per-op hipEvent pairs on the launch stream; rn_plan_profile_read blocks and returns ms per op (0 = not run) */
 int rn_plan_profile(rn_plan* plan, int enable);

@@ -33,7 +33,19 @@ struct rn_plan {
   bool profile = false;            // per-op hipEvent pairs on the launch stream (bench.py roofline leg)
   std::vector<hipEvent_t> ev;      // 2 per op
   std::vector<char> ev_set;
-  ~rn_plan() { for (auto e : ev) hipEventDestroy(e); }
+  // Weight-gradient ops (rn_plan_set_overlap) run on a second, low-priority stream: each is forked off the launch stream by
+  // an event at its position in the op list and needs only its layer's x and dy, which nothing overwrites before the join;
+  // their results are consumed after rn_plan_join.  They overlap the data-gradient / BatchNorm chain, which is the critical
+  // path of the backward and leaves matrix-pipe and HBM idle time in every kernel's prologue, epilogue and tail round.
+  bool overlap = false, side_pending = false;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  ~rn_plan() {
+    for (auto e : ev) (void)hipEventDestroy(e);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
+    if (side) (void)hipStreamDestroy(side);
+  }
 };
 
 extern "C" int rn_plan_create(const rn_op* ops, int n_ops, int n_bufs, int dtype, rn_plan** out) {
@@ -89,6 +101,34 @@ extern "C" int rn_plan_profile_read(rn_plan* plan, float* ms, int n) {
       return 2;
     }
   }
+  return 0;
+}
+
+extern "C" int rn_plan_set_overlap(rn_plan* plan, int enable) {
+  RN_CHECK_ARG(plan != nullptr, "rn_plan_set_overlap: null plan");
+  if (enable && !plan->side) {
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (hipStreamCreateWithPriority(&plan->side, hipStreamNonBlocking, least) != hipSuccess ||
+        hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) != hipSuccess) {
+      rn_set_error("rn_plan_set_overlap: could not create the side stream / events");
+      return 2;
+    }
+  }
+  plan->overlap = enable != 0;
+  return 0;
+}
+
+// makes `stream` wait for every weight-gradient op forked so far (no-op when none is pending)
+extern "C" int rn_plan_join(rn_plan* plan, rn_stream stream) {
+  RN_CHECK_ARG(plan != nullptr, "rn_plan_join: null plan");
+  if (!plan->side_pending) return 0;
+  if (hipEventRecord(plan->ev_join, plan->side) != hipSuccess || hipStreamWaitEvent(as_stream(stream), plan->ev_join, 0) != hipSuccess) {
+    rn_set_error("rn_plan_join: event record / wait failed");
+    return 2;
+  }
+  plan->side_pending = false;
   return 0;
 }
 
@@ -198,9 +238,19 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
   RN_CHECK_ARG(plan != nullptr, "rn_plan_run: null plan");
   RN_CHECK_ARG(first >= 0 && last <= (int)plan->ops.size() && first <= last, "rn_plan_run: bad range [%d, %d)", first, last);
   for (int i = first; i < last; ++i) {
-    if (plan->profile) hipEventRecord(plan->ev[2 * i], as_stream(stream));
-    int e = run_op(plan, i, step_seed, stream);
-    if (plan->profile) { hipEventRecord(plan->ev[2 * i + 1], as_stream(stream)); plan->ev_set[i] = 1; }
+    const bool forked = plan->overlap && !plan->profile && (plan->ops[i].flags & RN_F_FORK);   // flagged ops own a workspace of their own
+    rn_stream s = stream;
+    if (forked) {
+      if (hipEventRecord(plan->ev_fork, as_stream(stream)) != hipSuccess || hipStreamWaitEvent(plan->side, plan->ev_fork, 0) != hipSuccess) {
+        rn_set_error("rn_plan_run: fork onto the side stream failed at op %d", i);
+        return 2;
+      }
+      s = reinterpret_cast<rn_stream>(plan->side);
+      plan->side_pending = true;
+    }
+    if (plan->profile) (void)hipEventRecord(plan->ev[2 * i], as_stream(stream));
+    int e = run_op(plan, i, step_seed, s);
+    if (plan->profile) { (void)hipEventRecord(plan->ev[2 * i + 1], as_stream(stream)); plan->ev_set[i] = 1; }
     if (e) {
       std::string msg = g_err;
       rn_set_error("op %d (kind %d): %s", i, plan->ops[i].kind, msg.c_str());

@@ -90,6 +90,8 @@ class GradReducer:
         _, a, b = bound
         buf = eng.flat_grad[a:b]
         if buf.is_cuda:
+            if hasattr(eng, 'join'):
+                eng.join()                                       # weight gradients are produced on the engine's side stream
             if self._comm_stream is None:
                 self._comm_stream = torch.cuda.Stream(device=buf.device)
             ev = torch.cuda.Event()

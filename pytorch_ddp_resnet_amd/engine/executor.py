@@ -78,8 +78,9 @@ class Engine:
                 ops[j].fp[k] = fp[k]
         self._h = C.c_void_p()
         _lib.check(self.L.rn_plan_create(ops, len(plan.ops), len(plan.slots), self.rn_dtype, C.byref(self._h)))
-        if 'ws' in plan.slot_of:
-            _lib.check(self.L.rn_plan_set_bytes(self._h, plan.slot_of['ws'], max(ws_bytes, 16)))
+        for i, sl in enumerate(plan.slots):
+            if sl.role == 'ws':                     # the main-stream workspace and the side stream's own
+                _lib.check(self.L.rn_plan_set_bytes(self._h, i, max(ws_bytes, 16)))
         self._ptrs = (C.c_void_p * len(plan.slots))()
         self._bound = None
         self._hooks = {}
@@ -90,7 +91,11 @@ class Engine:
         # host launch path, which is what bounds thin networks (ResNet-v1-20: ~150 launches, v2-164: ~1500 per step).
         # Only for ranges with nothing host-side in between (no hook consumer) and no per-step kernel argument (the
         # dropout seed is one): captured once per binding, invalidated when any bound pointer changes.
-        self.use_graphs = not any(op.seed for op in plan.ops) and os.environ.get('RN_NO_GRAPHS', '0') != '1'
+        # ... and none with forked weight-gradient ops: replaying a captured fork/join was measured 25 % SLOWER than eager
+        # launches (the graph's internal streams ignore the side stream's low priority)
+        self.use_graphs = (not any(op.seed or (op.flags & ir.F_FORK) for op in plan.ops)) and os.environ.get('RN_NO_GRAPHS', '0') != '1'
+        # weight-gradient ops on a second stream, overlapped with the data-gradient / BatchNorm chain (plan.cpp)
+        _lib.check(self.L.rn_plan_set_overlap(self._h, 0 if os.environ.get('RN_NO_OVERLAP', '0') == '1' else 1))
         self._graphs = {}
         self._profiling = False
 
@@ -165,6 +170,11 @@ class Engine:
                 hook_fn(self, h)
         if last > pos:
             _lib.check(self.L.rn_plan_run(self._h, pos, last, step_seed, stream))
+        _lib.check(self.L.rn_plan_join(self._h, stream))       # forked weight-gradient ops: joined at the end of every range
+
+    def join(self):
+        """the current stream waits for the weight-gradient ops forked so far (before their results are read)."""
+        _lib.check(self.L.rn_plan_join(self._h, C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)))
 
     def forward(self, step_seed=0, hook_fn=None):
         self.generation += 1

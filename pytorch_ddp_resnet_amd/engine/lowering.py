@@ -139,6 +139,22 @@ class Lowering:
             self._named['ws'] = self.slot('workspace', 'ws', (0,), 'u8')
         return self._named['ws']
 
+    def ws_side(self):
+        if 'ws_side' not in self._named:
+            self._named['ws_side'] = self.slot('workspace_side', 'ws', (0,), 'u8')
+        return self._named['ws_side']
+
+    def fork_wgrad(self, g) -> bool:
+        """weight-gradient ops that run on the executor's side stream, beside the data-gradient / BatchNorm chain (which is
+        the critical path of the backward and leaves matrix-pipe / HBM idle time in every kernel's prologue, epilogue and
+        tail round).  Measured (eager launches): WRN-28-10 +6 %, WRN-50-2 +2.5...4.7 %.  Thin CIFAR nets are launch-bound
+        and run as hipGraphs, where a captured fork/join replays 25 % slower than no fork at all, so only GEMMs of at
+        least 5 GFLOP are forked and a plan with forked ops is not graph-captured (executor.py)."""
+        mode = os.environ.get('RN_FORK_WGRAD', 'auto')
+        if mode in ('0', '1'):
+            return mode == '1'
+        return 2.0 * g['N'] * g['P'] * g['Q'] * g['K'] * g['R'] * g['S'] * g['C'] >= 5e9
+
     # ---- small emitters ---------------------------------------------------------------------------------
     def geom(self, x: T, K, k, stride, pad):
         P = (x.H + 2 * pad - k) // stride + 1
@@ -181,7 +197,9 @@ class Lowering:
         """emits wgrad (+ dgrad).  returns dx tensor (or None).  fuse_bn = dict(x, mask, coef, p) of the BN+ReLU(+dropout)
         that produced this conv's input: the dgrad epilogue then also reduces that layer's two backward sums."""
         dw = self.grad(key, (g['K'], g['R'], g['S'], g['C']))
-        ops.append(Op(ir.OP_CONV_WGRAD, buf=dict(x=x.s, dy=dy.s, dw=dw, ws=self.ws()), dim=dict(g), note=key))
+        fork = self.fork_wgrad(g)
+        ops.append(Op(ir.OP_CONV_WGRAD, buf=dict(x=x.s, dy=dy.s, dw=dw, ws=self.ws_side() if fork else self.ws()), dim=dict(g),
+                      flags=ir.F_FORK if fork else 0, note=key))
         self._ws_need.append(('wgrad', dict(g)))
         self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
         if not need_dx:
