@@ -36,8 +36,12 @@ template <typename T, int TI, int TJ> struct WTile;  // per-wave MFMA work on on
 // bf16: A fragment of a 16-channel group = 8 pixels per lane via two transposed 4x16 block reads
 template <int TI, int TJ> struct WTile<bf16_t, TI, TJ> {
   __device__ static inline bf16x8 frag(const char* tile, int rowb, int ch0, int lane) {
+    // One transposed read serves, per 32-lane half, pixels {a..a+3} and {a+8..a+11}; 8 row strides are a multiple of 64 banks
+    // for every 32-byte-aligned stride, so those two pixel groups would hit the same banks (measured: a third of all LDS
+    // cycles were conflict cycles).  The 32-byte channel octets of a row are therefore swapped pairwise in rows whose pixel
+    // index has bit 3 set (store_tile writes them that way): the two groups land on octets of different parity.
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
-    const char* a0 = tile + (size_t)(8 * g + q) * rowb + (ch0 + 4 * p) * 2;
+    const char* a0 = tile + (size_t)(8 * g + q) * rowb + ((ch0 ^ ((g & 1) << 4)) + 4 * p) * 2;
     typedef __attribute__((address_space(3))) bf16x4* lp;
     bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(a0));
     bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(a0 + 4 * rowb));
@@ -101,6 +105,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   constexpr int BK_ = 2 * TI * 16, BC_ = 2 * TJ * 16;
   constexpr int ROWA = padded_row(BK_ * (int)sizeof(T)), ROWB = padded_row(BC_ * (int)sizeof(T));
   constexpr int CHA = BK_ / CE, CHB = BC_ / CE;          // 16-byte chunks per pixel row
+  static_assert(CE != 8 || (CHA % 4 == 0 && CHB % 4 == 0), "octet swap needs whole octet pairs");
   constexpr int BP = Bp<T>::v, TPR = 256 / BP;          // pixels per tile, threads staging one pixel row
   constexpr int NJA = (CHA + TPR - 1) / TPR, NJB = (CHB + TPR - 1) / TPR;
   __shared__ __attribute__((aligned(16))) char lds[2][BP * (ROWA + ROWB)];   // the only LDS object: 2 workgroups per CU at the largest tile
@@ -206,15 +211,16 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   auto store_tile = [&](int buf) {
     char* ta = lds[buf];
     char* tb = lds[buf] + BP * ROWA;
+    const int sw = CE == 8 ? ((prow >> 3) & 1) << 1 : 0;       // bf16: octet swap of the transposed-read layout (WTile::frag)
 #pragma unroll
     for (int j = 0; j < NJA; ++j) {
       const int ch = cl + TPR * j;
-      if (ch < CHA) *reinterpret_cast<uint4*>(ta + prow * ROWA + ch * 16) = ra[j];
+      if (ch < CHA) *reinterpret_cast<uint4*>(ta + prow * ROWA + (ch ^ sw) * 16) = ra[j];
     }
 #pragma unroll
     for (int j = 0; j < NJB; ++j) {
       const int ch = cl + TPR * j;
-      if (ch < CHB) *reinterpret_cast<uint4*>(tb + prow * ROWB + ch * 16) = rb[j];
+      if (ch < CHB) *reinterpret_cast<uint4*>(tb + prow * ROWB + (ch ^ sw) * 16) = rb[j];
     }
   };
 
