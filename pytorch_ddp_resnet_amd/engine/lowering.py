@@ -163,7 +163,9 @@ class Lowering:
 
     def packed_weights(self, key, K, k, C, need_dgrad):
         """per-forward repack of one conv weight into the compute dtype (KRSC for fwd/wgrad, CRSK for dgrad).
-        fp32 plans read the master parameter directly as the forward operand."""
+        fp32 plans read the master parameter directly as the forward operand.  (Packing the transposed copy by an op of its
+        own on the side stream during the forward was measured 3 % slower: twice the reads, and it competes with the
+        forward's kernels.)"""
         w = self.param(key, (K, k, k, C))
         if key in self._packed:
             return self._packed[key]
