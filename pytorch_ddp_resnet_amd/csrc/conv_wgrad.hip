@@ -11,6 +11,8 @@
 // second kernel sums the slabs in a fixed order (bitwise reproducible; no float atomics).
 #include "common.h"
 
+extern int g_rn_variant;   // conv_igemm.hip (rn_set_variant)
+
 namespace {
 
 constexpr int MAX_TAPS = 49;        // 7x7 stem
@@ -341,7 +343,8 @@ inline bool use_im2col(const rn_conv_geom* g, int dtype_ce) { return g->C == dty
 int wgrad_splits(const rn_conv_geom* g, int bk, int bc, bool im2col = false) {
   const long M = (long)g->N * g->P * g->Q;
   const int tiles = im2col ? cdiv(g->K, bk) * cdiv(g->R * g->S * g->C, bc) : cdiv(g->K, bk) * cdiv(g->C, bc) * g->R * g->S;
-  int splits = 512 / tiles;                              // one resident round: 2 workgroups per CU x 256 CUs
+  int splits = 512 / tiles;                              // one resident round: 2 workgroups per CU x 256 CUs (1 per CU for the
+                                                         // forked launches, to leave registers for the main stream: -1.5 %)
   const int max_by_rows = (int)((M + 255) / 256);      // at least 8 K-steps per block
   if (splits > max_by_rows) splits = max_by_rows;
   if (splits < 1) splits = 1;
@@ -400,7 +403,7 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   const int bk = pick_tile(g->K), bc = col_tile(g, ic);
   WgradArgs a{};
   a.im2col = ic ? 1 : 0;
-  { extern int g_rn_variant; a.xcd_remap = (g_rn_variant & 4) ? 0 : 1; }
+  a.xcd_remap = (g_rn_variant & 4) ? 0 : 1;
   {
     const unsigned long long pq = (unsigned long long)g->P * g->Q;
     a.magic_pq = pq <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / pq);
