@@ -140,7 +140,8 @@ __device__ inline void lds_barrier() {
   asm volatile("" ::: "memory");
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int TM, int TN, int NTH = WM * WN * 64>
+// SR: staged rows per pass (64 or 32, whatever fits the K-loop's LDS next to the reduction scratch)
+template <typename T, int BM, int BN, int WM, int WN, int TM, int TN, int NTH = WM * WN * 64, int SR = 64>
 __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int wave, int lane, float* lds_f,
                                       bool active = true) {
   if (a.probe_ep >= 2) {                       // keep every accumulator live (no dead-code elimination of the MFMAs)
@@ -153,15 +154,19 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
     if (a.probe_ep == 2) return;
   }
   constexpr int CE = Elem<T>::CE;
-  constexpr int HR = 64;                       // staged rows per half
   constexpr int LDC = BN + 4;                  // fp32 row stride of the staged tile
   constexpr int CCN = BN / CE;                 // output chunks per row
   constexpr int LANES = NTH / CCN;             // row lanes (threads beyond LANES*CCN idle in phase 2)
-  static_assert(BM == 2 * HR && 2 * HR == RN_CONV_STATS_ROWS && BN % CE == 0, "epilogue tile");
-  // A half takes 16 of the 32 rows of EVERY 32-row MFMA block (accumulator registers 8h .. 8h+7), so all waves park in
-  // both halves: staged row s = blk*16 + j  <->  tile row blk*32 + 16*half + j
-  float* ctile = lds_f;                        // [HR][LDC]
-  float* red = lds_f + HR * LDC;               // [row lanes][2][BN]
+  constexpr int NBLK = BM / 32;                // 32-row MFMA blocks of the tile
+  constexpr int NPASS = BM / SR;               // passes; each takes RPB rows of EVERY block, so all waves park in every pass
+  constexpr int RPB = 32 / NPASS;              // rows of a block per pass
+  constexpr int NR = 16 / NPASS;               // accumulator registers of a lane per pass (registers NR*pass .. NR*pass+NR-1)
+  constexpr int NGRP = BM / RN_CONV_STATS_ROWS;          // partial-sum rows this tile writes (one per 128 output rows)
+  static_assert(BM % RN_CONV_STATS_ROWS == 0 && BN % CE == 0 && (NPASS == 2 || NPASS == 4 || NPASS == 8) && RPB * NBLK == SR, "epilogue tile");
+  // staged row s = blk*RPB + lh*NR + j  <->  accumulator register r = NR*pass + j of lane half lh in block blk
+  //                                     <->  tile row blk*32 + (r&3) + 8*(r>>2) + 4*lh
+  float* ctile = lds_f;                        // [SR][LDC]
+  float* red = lds_f + SR * LDC;               // [row lanes][2][BN]
   const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 31, lh = lane >> 5;
   const int pq = a.Pc * a.Qc;
@@ -177,41 +182,46 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
   const bool res_same = a.res.mode == RN_RES_SAME;
   // the common forward case gets its own row loop: no residual / accumulate / BatchNorm-backward operands, no bias
   const bool simple = dense && a.res.mode == RN_RES_NONE && !a.accum && !bn_bwd && !a.bias;
-  float s0[CE], s1[CE], mean[CE], invstd[CE], bias[CE];
+  float s0[NGRP][CE], s1[NGRP][CE], mean[CE], invstd[CE], bias[CE];
 #pragma unroll
   for (int e = 0; e < CE; ++e) {
-    s0[e] = s1[e] = 0.f; mean[e] = 0.f; invstd[e] = 1.f; bias[e] = 0.f;
+#pragma unroll
+    for (int gi = 0; gi < NGRP; ++gi) s0[gi][e] = s1[gi][e] = 0.f;
+    mean[e] = 0.f; invstd[e] = 1.f; bias[e] = 0.f;
     if (colok && bn_bwd) { mean[e] = a.bn_coef[2 * a.Kd + k0 + e]; invstd[e] = a.bn_coef[3 * a.Kd + k0 + e]; }
     if (colok && a.bias) bias[e] = a.bias[k0 + e];
   }
+  auto tile_row = [&](int srow, int pass) {    // staged row -> row of the tile
+    const int blk = srow / RPB, rem = srow - blk * RPB;
+    const int hh = rem / NR, r = NR * pass + (rem - hh * NR);
+    return blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+  };
   __syncthreads();                             // every wave is done with the K-loop staging memory
   stamp(a.stamps, 2);
 #pragma unroll
-  for (int half = 0; half < 2; ++half) {
-    // ---- phase 1: every wave parks 8 of the 16 accumulator rows-groups of each of its MFMA blocks (fp32) ----
+  for (int pass = 0; pass < NPASS; ++pass) {
+    // ---- phase 1: every wave parks NR accumulator registers of each of its MFMA blocks (fp32) ----
     if (active && a.probe_ep != 3) {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int blk = wm * TM + i;
 #pragma unroll
-        for (int r8 = 0; r8 < 8; ++r8) {
-          const int srow = blk * 16 + (r8 & 3) + 8 * (r8 >> 2) + 4 * lh;
+        for (int jr = 0; jr < NR; ++jr) {
+          const int srow = blk * RPB + lh * NR + jr;
 #pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const float v = half == 0 ? acc[i][j][r8] : acc[i][j][8 + r8];
-            ctile[srow * LDC + wn * (BN / WN) + 32 * j + lr] = v;
-          }
+          for (int j = 0; j < TN; ++j) ctile[srow * LDC + wn * (BN / WN) + 32 * j + lr] = acc[i][j][NR * pass + jr];
         }
       }
     }
     lds_barrier();
-    stamp(a.stamps, 3 + 2 * half);
+    if (pass < 2) stamp(a.stamps, 3 + 2 * pass);
     // ---- phase 2: column-fixed threads, 16-byte chunks ----
     if (colok && a.probe_ep != 4) {
       if (simple) {
-        for (int srow = rl; srow < HR; srow += LANES) {
-          const int m = m0 + (srow >> 4) * 32 + 16 * half + (srow & 15);
-          if (m >= a.M) break;
+        for (int srow = rl; srow < SR; srow += LANES) {
+          const int trow = tile_row(srow, pass);
+          const int m = m0 + trow;
+          if (m >= a.M) continue;
           const float* cp = ctile + srow * LDC + cg * CE;
           Chunk<T> st;
 #pragma unroll
@@ -221,14 +231,20 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
           }
           if (a.probe_ep != 1 || st.u.x == 0x12345678u) store_chunk<T>(dst + (size_t)m * a.Kd + k0, st);
           if (want_stats) {
+            const int gi = NGRP > 1 ? trow / RN_CONV_STATS_ROWS : 0;
 #pragma unroll
-            for (int e = 0; e < CE; ++e) { const float vs = Elem<T>::to_f(st.e[e]); s0[e] += vs; s1[e] += vs * vs; }
+            for (int e = 0; e < CE; ++e) {
+              const float vs = Elem<T>::to_f(st.e[e]);
+#pragma unroll
+              for (int gg = 0; gg < NGRP; ++gg) if (gg == gi) { s0[gg][e] += vs; s1[gg][e] += vs * vs; }
+            }
           }
         }
       } else {
-        for (int srow = rl; srow < HR; srow += LANES) {
-          const int m = m0 + (srow >> 4) * 32 + 16 * half + (srow & 15);
-          if (m >= a.M) break;
+        for (int srow = rl; srow < SR; srow += LANES) {
+          const int trow = tile_row(srow, pass);
+          const int m = m0 + trow;
+          if (m >= a.M) continue;
           size_t pix;
           int n = 0, hd = 0, wd = 0;
           if (dense) {
@@ -265,9 +281,11 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
           for (int e = 0; e < CE; ++e) st.e[e] = Elem<T>::from_f(v[e]);
           if (a.probe_ep != 1 || st.u.x == 0x12345678u) store_chunk<T>(dst + off, st);
           if (want_stats) {
+            const int gi = NGRP > 1 ? trow / RN_CONV_STATS_ROWS : 0;
+            float d0[CE], d1[CE];
             if (!bn_bwd) {
 #pragma unroll
-              for (int e = 0; e < CE; ++e) { const float vs = Elem<T>::to_f(st.e[e]); s0[e] += vs; s1[e] += vs * vs; }
+              for (int e = 0; e < CE; ++e) { const float vs = Elem<T>::to_f(st.e[e]); d0[e] = vs; d1[e] = vs * vs; }
             } else {
               Chunk<T> cx = load_chunk<T>(reinterpret_cast<const T*>(a.bn_x) + off);
               Chunk<T> cm;
@@ -277,33 +295,41 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
                 float g = Elem<T>::to_f(st.e[e]) * a.gscale;
                 if (a.bn_mask && !(Elem<T>::to_f(cm.e[e]) > 0.f)) g = 0.f;
                 const float xh = (Elem<T>::to_f(cx.e[e]) - mean[e]) * invstd[e];
-                s0[e] += g; s1[e] += g * xh;
+                d0[e] = g; d1[e] = g * xh;
               }
             }
+#pragma unroll
+            for (int e = 0; e < CE; ++e)
+#pragma unroll
+              for (int gg = 0; gg < NGRP; ++gg) if (gg == gi) { s0[gg][e] += d0[e]; s1[gg][e] += d1[e]; }
           }
         }
       }
     }
-    if (want_stats && half == 1) {             // one partial row per RN_CONV_STATS_ROWS (= this tile's) output rows
-      if (p2) {
+    if (want_stats && pass == NPASS - 1) {     // one partial row per RN_CONV_STATS_ROWS output rows
 #pragma unroll
-        for (int e = 0; e < CE; ++e) { red[(rl * 2 + 0) * BN + cg * CE + e] = s0[e]; red[(rl * 2 + 1) * BN + cg * CE + e] = s1[e]; }
-      }
-      lds_barrier();
-      if (m0 < a.M) {
-        for (int col = tid; col < BN; col += NTH) {
-          const int k = n0 + col;
-          if (k >= a.Kd) continue;
-          float t0 = 0.f, t1 = 0.f;
-          for (int w = 0; w < LANES; ++w) { t0 += red[(w * 2 + 0) * BN + col]; t1 += red[(w * 2 + 1) * BN + col]; }
-          float* out = a.stats + ((size_t)(a.tile_base + m0 / (2 * HR)) * 2) * a.Kd;
-          out[k] = t0;
-          out[a.Kd + k] = t1;
+      for (int gg = 0; gg < NGRP; ++gg) {
+        if (p2) {
+#pragma unroll
+          for (int e = 0; e < CE; ++e) { red[(rl * 2 + 0) * BN + cg * CE + e] = s0[gg][e]; red[(rl * 2 + 1) * BN + cg * CE + e] = s1[gg][e]; }
         }
+        lds_barrier();
+        if (m0 + gg * RN_CONV_STATS_ROWS < a.M) {
+          for (int col = tid; col < BN; col += NTH) {
+            const int k = n0 + col;
+            if (k >= a.Kd) continue;
+            float t0 = 0.f, t1 = 0.f;
+            for (int w = 0; w < LANES; ++w) { t0 += red[(w * 2 + 0) * BN + col]; t1 += red[(w * 2 + 1) * BN + col]; }
+            float* out = a.stats + ((size_t)(a.tile_base + m0 / RN_CONV_STATS_ROWS + gg) * 2) * a.Kd;
+            out[k] = t0;
+            out[a.Kd + k] = t1;
+          }
+        }
+        if (gg + 1 < NGRP) lds_barrier();
       }
     }
-    lds_barrier();                             // ctile (and `red`) are reused by the next half
-    stamp(a.stamps, 4 + 2 * half);
+    lds_barrier();                             // ctile (and `red`) are reused by the next pass
+    if (pass < 2) stamp(a.stamps, 4 + 2 * pass);
   }
 }
 
