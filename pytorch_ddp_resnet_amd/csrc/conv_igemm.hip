@@ -621,7 +621,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
     if (++stg == NSTG) stg = 0;
   }
 
-  igemm_epilogue<T, BM, BN, WM, WN, TM, TN>(a, acc, m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
+  constexpr int SR = CPRT == 4 ? 32 : 64;              // 64-byte K rows: the ring is half as large, so is the staged slab
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN, NW * 64, SR>(a, acc, m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -804,8 +805,10 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   const int K = a.Kd;
-  // column tile: the widest of {160,128,96,64,32} that wastes no 32-column MFMA tile.  (256-row tiles -- 4 consumer waves of
-  // 64 x BN, or 8 homogeneous waves with a 3-stage ring -- were measured 5-12 % slower on the WRN-28-10 shapes and removed.)
+  // column tile: the widest of {160,128,96,64,32} that wastes no 32-column MFMA tile.  256-row tiles were measured and removed:
+  // 4 consumer + 4 loader waves of 64 x BN, or 8 homogeneous waves with a 3-stage ring (one workgroup per CU): 5-12 % slower on
+  // the WRN-28-10 shapes; 4 waves of 64 x BN with 64-byte K rows at two workgroups per CU (28 % fewer DMAs and 42 % fewer
+  // fragment reads per FLOP): +5 % in isolation, +-0 in the model.
   if (K % 160 == 0) return launch_cfg<T, 128, 160, 4, 1>(a, s);
   if (K % 128 == 0) return launch_cfg<T, 128, 128, 2, 2>(a, s);
   if (K % 96 == 0) return launch_cfg<T, 128, 96, 4, 1>(a, s);
