@@ -54,12 +54,26 @@ class GradReducer:
         self.model, self.world, self.group = model, world_size, group
         self.cap, self.first_cap, self.last_cap = int(bucket_cap_mb * 2 ** 20), int(first_bucket_mb * 2 ** 20), int(last_bucket_mb * 2 ** 20)
         self._plans = {}
+        self._ends = {}
         self._eng = None
         self._next = 0
         self._work = []
         self._comm_stream = None
         model._hook_fn = self._on_hook
         model.alias_grads = True          # finish() re-points p.grad at the reduced flat buffer every step
+
+    def wanted(self, eng, hook) -> bool:
+        """hook points this reducer acts on: SyncBN sums, and the gradients that complete a bucket."""
+        if self.world <= 1:
+            return False
+        if hook.action == 'allreduce_f32':
+            return True
+        if hook.action != 'grad_ready':
+            return False
+        ends = self._ends.get(id(eng))
+        if ends is None:
+            ends = self._ends[id(eng)] = {b[0] for b in self._bplan(eng).bounds}
+        return hook.arg in ends
 
     # ---- hook entry point: called by Engine.run between op ranges -------------------------------------------
     def _on_hook(self, eng, hook):
