@@ -235,9 +235,14 @@ class Lowering:
                 self.fwd.append(Op(ir.OP_BN_STATS, buf=dict(x=x.s, partial=part), dim=dict(M=x.M, C=C, nblk=nblk), note=pre))
             count = x.M
             if self.sync:
-                # SyncBN: the partial sums are summed slab-by-slab across ranks (a sum of partials is still a set of
-                # partials), then every rank finalizes over the global row count
-                self.fwd_hooks.append(Hook(len(self.fwd), 'allreduce_f32', slot=part))
+                # SyncBN: the [rows][2][C] partials are first summed locally to one [2][C] row (the backward-finalize kernel
+                # is exactly that reduction), THAT row is all-reduced (1.3 KB instead of 1.3 MB per layer), then every rank
+                # finalizes over the global row count
+                local = self.f32(pre + ':local', (2, C))
+                sg, sb = self.f32(pre + ':local_g', (C,)), self.f32(pre + ':local_b', (C,))      # by-products, unused
+                self.fwd.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=local, dgamma=sg, dbeta=sb), dim=dict(nblk=nblk, C=C), note=pre))
+                self.fwd_hooks.append(Hook(len(self.fwd), 'allreduce_f32', slot=local))
+                part, nblk = local, 1
                 count = x.M * self.world
             self.fwd.append(Op(ir.OP_BN_FINALIZE, buf=dict(partial=part, gamma=gamma, beta=beta, running_mean=rm,
                                                            running_var=rv, nbt=nbt, coef=coef),

@@ -31,6 +31,8 @@ CONV_GEOMS = [
     (1, 16, 16, 96, 96, 3, 1, 1),        # BN=96 tile
     (2, 7, 7, 128, 256, 3, 1, 1),        # ImageNet-like 7x7 map
     (2, 16, 16, 8, 64, 7, 2, 3),         # 7x7 stride-2 stem on the MFMA route (49 taps, channels padded to one chunk)
+    (32, 32, 32, 16, 64, 1, 1, 0),       # thin 1x1 layer on a large map: wgrad split 128 ways, wide slab reduction
+    (4, 32, 32, 8, 16, 3, 1, 1),         # 3x3 stem on the MFMA route (im2col wgrad, 72 columns in one 160-wide tile)
 ]
 
 
