@@ -185,7 +185,7 @@ def main():
                 traffic, traffic_src = int(tot_b / tot_n), f"profiles/{ks['tag']}_pmc_summary.json"
         roof = dict(bound='mfma', achieved=round(achieved, 1), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4), traffic=traffic,
                     traffic_unit='bytes per conv launch (HBM side)', traffic_source=traffic_src,
-                    kernel='igemm_kernel + wgrad_kernel (implicit-GEMM conv fwd/dgrad/wgrad launches)',
+                    kernel='igemm_dma_kernel / igemm_ws_kernel / wgrad_kernel (implicit-GEMM conv fwd, dgrad, wgrad launches)',
                     launches_per_step=nconv // nprof, avg_launch_ms=round(conv_t / max(nconv, 1), 4),
                     algorithmic_gflop_per_launch=round(conv_f / max(nconv, 1) / 1e9, 2),
                     conv_ms_per_step=round(conv_t / nprof, 3), all_ops_ms_per_step=round(sum(agg.values()), 3))
