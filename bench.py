@@ -98,10 +98,16 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
-    dev = torch.device('cuda', local_rank)
+    # rehearsal hook for a one-GPU box: RN_BENCH_REHEARSAL=1 puts every rank on cuda:0 and moves the collectives through
+    # gloo, so the multi-rank control flow of this file can be exercised without a second GPU (never set by the driver)
+    rehearsal = os.environ.get('RN_BENCH_REHEARSAL', '0') == '1'
+    dev = torch.device('cuda', 0 if rehearsal else local_rank)
     torch.cuda.set_device(dev)
     if world > 1:
-        torch.distributed.init_process_group('nccl', device_id=dev)        # RCCL over xGMI
+        if rehearsal:
+            torch.distributed.init_process_group('gloo')
+        else:
+            torch.distributed.init_process_group('nccl', device_id=dev)    # RCCL over xGMI
 
     from pytorch_ddp_resnet_amd import ResNet
     from pytorch_ddp_resnet_amd.engine import ir
@@ -147,26 +153,27 @@ def main():
     ms = dt / args.steps * 1e3
     value = world * cfg['batch'] * args.steps / dt
 
-    # ---- instrumented pass: per-launch HIP events on the launch stream (same steps, rank 0) ----
+    # ---- instrumented pass: per-launch HIP events on the launch stream (same steps).  EVERY rank runs it -- a step contains
+    # the gradient collectives, which all ranks must enter -- and rank 0 reports its own measurements ----
     roof = None
+    eng = next(e for k, e in model._engines.items() if k[1] and k[2])
+    nprof = max(3, min(10, args.steps))
+    agg, conv_t, conv_f, nconv = {}, 0.0, 0.0, 0
+    per_op = {}
+    for _ in range(nprof):
+        eng.profile(True)
+        step()
+        torch.cuda.synchronize()
+        for op, t_ms in eng.profile_read():
+            name = ir.OP_NAMES[op.kind]
+            agg[name] = agg.get(name, 0.0) + t_ms / nprof
+            per_op[id(op)] = (op, per_op.get(id(op), (op, 0.0))[1] + t_ms / nprof)
+            if op.kind in (ir.OP_CONV_FWD, ir.OP_CONV_DGRAD, ir.OP_CONV_WGRAD):
+                conv_t += t_ms
+                conv_f += conv_flops(op)
+                nconv += 1
+    eng.profile(False)
     if rank == 0:
-        eng = next(e for k, e in model._engines.items() if k[1] and k[2])
-        nprof = max(3, min(10, args.steps))
-        agg, conv_t, conv_f, nconv = {}, 0.0, 0.0, 0
-        per_op = {}
-        for _ in range(nprof):
-            eng.profile(True)
-            step()
-            torch.cuda.synchronize()
-            for op, t_ms in eng.profile_read():
-                name = ir.OP_NAMES[op.kind]
-                agg[name] = agg.get(name, 0.0) + t_ms / nprof
-                per_op[id(op)] = (op, per_op.get(id(op), (op, 0.0))[1] + t_ms / nprof)
-                if op.kind in (ir.OP_CONV_FWD, ir.OP_CONV_DGRAD, ir.OP_CONV_WGRAD):
-                    conv_t += t_ms
-                    conv_f += conv_flops(op)
-                    nconv += 1
-        eng.profile(False)
         achieved = conv_f / (conv_t * 1e-3) / 1e12 if conv_t > 0 else 0.0
         peak = PEAK_TFLOPS[args.dtype]
         # HBM-side bytes per conv launch: from the committed PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE, separate
