@@ -9,10 +9,13 @@
 // dgrad stride 2: one launch per output parity class (ds=2, (oh,ow) in {0,1}^2) with that class's tap subset, so no
 // MFMA work is spent on structural zeros.
 //
-// Tiling: BM x BN block tile, 4 waves (WM x WN), 32x32 MFMA tiles per wave; K streamed in 64-byte rows (32 bf16 / 16
-// f32) through a double-buffered, XOR-swizzled LDS image; global->register loads of tile i+1 are issued before the
-// MFMAs of tile i and written to LDS after them (one barrier per K tile).  f32 uses v_mfma_f32_32x32x2_f32 (exact
-// f32 FMA chain), bf16 v_mfma_f32_32x32x16_bf16, both fed by one 16-byte ds_read_b128 per operand per k-step.
+// Tiling: 128 x BN block tile (BN in {160,128,96,64,32}), 32x32 MFMA tiles per wave; K streamed in 128-byte rows (64 bf16 /
+// 32 f32) global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) into a ring of XOR-swizzled stages, counted s_waitcnt vmcnt
+// and raw s_barrier (one per K tile).  Two schedules: igemm_dma_kernel (4 waves load and multiply, 2 stages, two workgroups
+// per CU) and igemm_ws_kernel (4 consumer + 4 loader waves, 3 stages, one workgroup per CU); launch_cfg picks by tile count.
+// f32 uses v_mfma_f32_32x32x2_f32 (exact f32 FMA chain), bf16 v_mfma_f32_32x32x16_bf16, both fed by one 16-byte
+// ds_read_b128 per operand per k-step.  The epilogue (igemm_epilogue) stages the accumulators through LDS and fuses bias,
+// residual, accumulate and the BatchNorm sums.  DESIGN.md sections 4-6 hold the measurements behind each choice.
 #include "common.h"
 #include <type_traits>
 
