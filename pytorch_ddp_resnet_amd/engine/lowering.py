@@ -7,7 +7,9 @@ architectures/resnet.py:122-158) and the data flow of ``ResidualBlock.forward`` 
 ``BottleneckResidualBlock.forward`` (:173-215): v1 ``[drop] conv bn relu``, v2 ``bn relu [drop] conv``, shortcut from
 the raw block input (identity / subsample+zero-pad / subsample+1x1 projection), post-add ReLU only in v1.
 
-How it runs here: every BN+ReLU(+dropout) is one elementwise pass (BN_APPLY) fed by a statistics pass; the residual
+How it runs here: every BN+ReLU(+dropout) is one elementwise pass (BN_APPLY) fed by statistics that the producing
+convolution's epilogue already reduced (a statistics pass of its own only where no convolution produces the tensor), and
+the two reduction sums of its backward come out of the consuming convolution's dgrad epilogue; the residual
 add rides in the epilogue of the block's last convolution (v2) or of the last BN_APPLY (v1); the backward is written
 out explicitly (no autograd inside the engine) and merges gradient forks in kernel epilogues instead of separate adds.
 Weight gradients are produced in the order recorded in ``Plan.grad_order`` so the flat gradient buffer can be
