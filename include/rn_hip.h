@@ -162,6 +162,15 @@ int rn_unpack_stem_dw(const float* dw_padded, float* dw_krsc, int K, int RS, int
 
 /* fp32 KRSC master -> w_fwd [K][R*S][C] and w_dgrad [C][R*S][K] in dtype (either may be NULL) */
 int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, int dtype, int K, int RS, int C, rn_stream s);
+/* the same for up to RN_PACK_BATCH_MAX weights in ONE launch (descriptors are host memory, consumed before the call returns) */
+#define RN_PACK_BATCH_MAX 32
+typedef struct rn_pack_desc {
+  const float* w;   /* fp32 KRSC master */
+  void* w_fwd;      /* [K][R*S][C] in dtype, or NULL */
+  void* w_dgrad;    /* [C][R*S][K] in dtype, or NULL */
+  int32_t K, RS, C;
+} rn_pack_desc;
+int rn_pack_weights_batch(const rn_pack_desc* descs, int n, int dtype, rn_stream s);
 
 /* y = conv(x, w_fwd) [+ res];  MFMA implicit GEMM, M = N*P*Q, N = K, K = R*S*C.  C % 8 == 0, K % 16 == 0 */
 int rn_conv_fwd(const void* x, const void* w_fwd, void* y, const void* res, int res_mode, int res_C, int dtype,

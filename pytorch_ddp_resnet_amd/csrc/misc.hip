@@ -15,16 +15,13 @@ __global__ void pack_w_fwd_kernel(const float* __restrict__ w, T* __restrict__ w
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) wf[i] = Elem<T>::from_f(w[i]);
 }
 
-// w[k][rs][c] -> wd[c][rs][k]: one 32x32 (k, c) tile per workgroup and tap, transposed through LDS so both the read
-// (along c) and the write (along k) are coalesced
+// w[k][rs][c] -> wf[k][rs][c] and wd[c][rs][k] (either may be NULL): one 64(k) x 64(c) tile of one tap per workgroup, transposed
+// through LDS; 16-byte reads along c, 16-byte (bf16: 8 k) stores along k of the transposed copy.  K and C are multiples of
+// 8 (bf16) / 4 (fp32) (conv geometry check), so every 4-wide / 8-wide group is whole.
 template <typename T>
-__global__ __launch_bounds__(256) void pack_w_dgrad_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int K, int RS, int C) {
-  // one 64(k) x 64(c) tile of one tap: 16-byte reads along c, 16-byte (bf16: 8 k) stores along k of the transposed copy.
-  // K and C are multiples of 8 (bf16) / 4 (fp32) (conv geometry check), so every 4-wide / 8-wide group is whole.
+__device__ inline void pack_tile(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int K, int RS, int C, int b, float (*tile)[65]) {
   constexpr int CE = Elem<T>::CE;
-  __shared__ float tile[64][65];
   const int ct = (C + 63) / 64;
-  int b = blockIdx.x;
   const int rs = b % RS; b /= RS;
   const int c0 = (b % ct) * 64, k0 = (b / ct) * 64;
   const int t = threadIdx.x;
@@ -50,6 +47,7 @@ __global__ __launch_bounds__(256) void pack_w_dgrad_kernel(const float* __restri
       tile[r + 16 * j][c4] = v.x; tile[r + 16 * j][c4 + 1] = v.y; tile[r + 16 * j][c4 + 2] = v.z; tile[r + 16 * j][c4 + 3] = v.w;
     }
   }
+  if (!wd) return;                                 // uniform per workgroup
   __syncthreads();
   {
     const int k8 = (t & 7) * 8, cc = t >> 3;
@@ -72,6 +70,28 @@ __global__ __launch_bounds__(256) void pack_w_dgrad_kernel(const float* __restri
       }
     }
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_w_dgrad_kernel(const float* __restrict__ w, T* __restrict__ wf, T* __restrict__ wd, int K, int RS, int C) {
+  __shared__ float tile[64][65];
+  pack_tile<T>(w, wf, wd, K, RS, C, blockIdx.x, tile);
+}
+
+// every conv weight of a network in ONE launch (rn_pack_weights_batch): the descriptors travel as kernel arguments, a
+// workgroup finds its layer by a scan of the block prefix sums (26 launches of 3-14 us each were launch-latency bound)
+struct PackBatch {
+  rn_pack_desc d[RN_PACK_BATCH_MAX];
+  int first_block[RN_PACK_BATCH_MAX + 1];
+  int n;
+};
+template <typename T>
+__global__ __launch_bounds__(256) void pack_w_batch_kernel(const PackBatch pb) {
+  __shared__ float tile[64][65];
+  int l = 0;
+  while (l + 1 < pb.n && (int)blockIdx.x >= pb.first_block[l + 1]) ++l;
+  const rn_pack_desc& d = pb.d[l];
+  pack_tile<T>(d.w, reinterpret_cast<T*>(d.w_fwd), reinterpret_cast<T*>(d.w_dgrad), d.K, d.RS, d.C, (int)blockIdx.x - pb.first_block[l], tile);
 }
 
 // ---- MFMA stem route: image / weights / weight-gradient between the reference layouts and the padded NHWC operands ----
@@ -367,6 +387,28 @@ extern "C" int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, 
     else hipLaunchKernelGGL((pack_w_dgrad_kernel<bf16_t>), dim3(grid), dim3(256), 0, as_stream(s), w_krsc, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, K, RS, C);
   }
   RN_CHECK_LAUNCH("pack_weights");
+  return 0;
+}
+
+extern "C" int rn_pack_weights_batch(const rn_pack_desc* descs, int n, int dtype, rn_stream s) {
+  RN_CHECK_ARG(descs && n > 0 && n <= RN_PACK_BATCH_MAX, "rn_pack_weights_batch: n=%d out of range (1..%d)", n, RN_PACK_BATCH_MAX);
+  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "rn_pack_weights_batch: bad dtype");
+  const int ce = dtype == RN_F32 ? 4 : 8;
+  PackBatch pb;
+  pb.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const rn_pack_desc& d = descs[i];
+    RN_CHECK_ARG(d.w && (d.w_fwd || d.w_dgrad) && d.K > 0 && d.RS > 0 && d.C > 0, "rn_pack_weights_batch: bad descriptor %d", i);
+    RN_CHECK_ARG(d.C % ce == 0 && d.K % ce == 0, "rn_pack_weights: C=%d and K=%d must be multiples of %d for this dtype", d.C, d.K, ce);
+    pb.d[i] = d;
+    pb.first_block[i] = blocks;
+    blocks += cdiv(d.K, 64) * cdiv(d.C, 64) * d.RS;
+  }
+  pb.first_block[n] = blocks;
+  if (dtype == RN_F32) hipLaunchKernelGGL((pack_w_batch_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(s), pb);
+  else hipLaunchKernelGGL((pack_w_batch_kernel<bf16_t>), dim3(blocks), dim3(256), 0, as_stream(s), pb);
+  RN_CHECK_LAUNCH("pack_weights_batch");
   return 0;
 }
 

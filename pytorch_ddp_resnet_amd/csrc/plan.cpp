@@ -238,6 +238,25 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
   RN_CHECK_ARG(plan != nullptr, "rn_plan_run: null plan");
   RN_CHECK_ARG(first >= 0 && last <= (int)plan->ops.size() && first <= last, "rn_plan_run: bad range [%d, %d)", first, last);
   for (int i = first; i < last; ++i) {
+    if (!plan->profile && plan->ops[i].kind == RN_OP_PACK_W) {         // a run of weight packs becomes one launch
+      rn_pack_desc descs[RN_PACK_BATCH_MAX];
+      int n = 0;
+      while (i + n < last && n < RN_PACK_BATCH_MAX && plan->ops[i + n].kind == RN_OP_PACK_W && !(plan->ops[i + n].flags & RN_F_FORK)) {
+        const rn_op& o = plan->ops[i + n];
+        auto P = [&](int b) -> void* { return o.buf[b] >= 0 ? plan->bufs[o.buf[b]] : nullptr; };
+        descs[n] = rn_pack_desc{(const float*)P(0), P(1), P(2), o.dim[0], o.dim[1], o.dim[2]};
+        ++n;
+      }
+      if (n > 1) {
+        if (int e = rn_pack_weights_batch(descs, n, plan->dtype, stream)) {
+          std::string msg = g_err;
+          rn_set_error("op %d (kind %d): %s", i, plan->ops[i].kind, msg.c_str());
+          return e;
+        }
+        i += n - 1;
+        continue;
+      }
+    }
     const bool forked = plan->overlap && !plan->profile && (plan->ops[i].flags & RN_F_FORK);   // flagged ops own a workspace of their own
     rn_stream s = stream;
     if (forked) {

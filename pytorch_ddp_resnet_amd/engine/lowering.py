@@ -97,6 +97,7 @@ class Lowering:
         self._site = 0
         self._packed: Dict[str, Tuple[int, int]] = {}
         self._ws_need = []              # geometries of ops that share the workspace slot
+        self.fwd_packs: List[Op] = []   # weight-pack ops, emitted in front of the forward
         self._stats_of: Dict[int, Tuple[int, int]] = {}    # tensor slot -> (partial slot, rows) written by its producer's epilogue
         self._tail_bn: Dict[int, dict] = {}                # output slot of a BN(+add)+ReLU -> its record: the consumer's dgrad reduces its backward sums
         self._dpart_of: Dict[int, Tuple[int, int]] = {}    # gradient tensor slot -> BN-backward partial sums from the dgrad epilogue
@@ -176,8 +177,10 @@ class Lowering:
         wd = self.slot(key + ':dgrad', 'act', (C, k * k, K), 'T') if need_dgrad else -1
         if (not self.fp32) or need_dgrad:
             flags = (ir.F_SKIP_FWD_PACK if self.fp32 else 0) | (ir.F_NEED_DGRAD_PACK if need_dgrad else 0)
-            self.fwd.append(Op(ir.OP_PACK_W, buf=dict(w=w, w_fwd=-1 if self.fp32 else wf, w_dgrad=wd),
-                               dim=dict(K=K, RS=k * k, C=C), flags=flags, note=key))
+            # all weight packs sit at the head of the forward (they depend on parameters only): the executor turns the run
+            # into ONE launch (rn_pack_weights_batch)
+            self.fwd_packs.append(Op(ir.OP_PACK_W, buf=dict(w=w, w_fwd=-1 if self.fp32 else wf, w_dgrad=wd),
+                                     dim=dict(K=K, RS=k * k, C=C), flags=flags, note=key))
         self._packed[key] = (wf, wd)
         return wf, wd
 
@@ -563,8 +566,10 @@ class Lowering:
         elif self.with_loss:
             self.fwd.append(Op(ir.OP_SOFTMAX_CE, buf=dict(logits=named['logits'], labels=named['labels'], out3=named['loss3'], dlogits=-1),
                                dim=dict(N=n_logits[0], O=n_logits[1]), fp=dict(scale=1.0 / n_logits[0])))
+        npk = len(self.fwd_packs)
+        self.fwd = self.fwd_packs + self.fwd
         n_fwd = len(self.fwd)
-        hooks = list(self.fwd_hooks) + [Hook(h.at + n_fwd, h.action, h.slot, h.arg) for h in self.bwd_hooks]
+        hooks = [Hook(h.at + npk, h.action, h.slot, h.arg) for h in self.fwd_hooks] + [Hook(h.at + n_fwd, h.action, h.slot, h.arg) for h in self.bwd_hooks]
         if 'ws' in self._named:
             named['ws'] = self._named['ws']
         return Plan(self.slots, self.fwd + ops_b, n_fwd, hooks, self.grad_order, self.param_keys, named, self.train,
