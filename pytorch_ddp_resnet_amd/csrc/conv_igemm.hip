@@ -244,22 +244,42 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
           }
         }
       } else {
-        for (int srow = rl; srow < SR; srow += LANES) {
-          const int trow = tile_row(srow, pass);
-          const int m = m0 + trow;
-          if (m >= a.M) continue;
+        // general rows: the global operands (residual, accumulate, BatchNorm x / mask) of row i+1 are requested before row i
+        // is processed, so a thread pays their latency once per pass instead of once per row (the fused 1x1 data gradients of
+        // WRN-50-2 spend most of their time here)
+        struct Row { bool ok; size_t off; int trow, n, hd, wd; Chunk<T> cr, co, cx, cm; };
+        auto fetch = [&](int srow, Row& r) {
+          r.ok = false;
+          if (srow >= SR) return;
+          r.trow = tile_row(srow, pass);
+          const int m = m0 + r.trow;
+          if (m >= a.M) return;
+          r.ok = true;
+          r.n = r.hd = r.wd = 0;
           size_t pix;
-          int n = 0, hd = 0, wd = 0;
           if (dense) {
             pix = (size_t)m;
           } else {
             int pp, q;
-            decode_row(a, m, pq, n, pp, q);
-            hd = pp * a.ds + a.oh;
-            wd = q * a.ds + a.ow;
-            pix = ((size_t)n * a.Hd + hd) * a.Wd + wd;
+            decode_row(a, m, pq, r.n, pp, q);
+            r.hd = pp * a.ds + a.oh;
+            r.wd = q * a.ds + a.ow;
+            pix = ((size_t)r.n * a.Hd + r.hd) * a.Wd + r.wd;
           }
-          const size_t off = pix * a.Kd + k0;
+          r.off = pix * a.Kd + k0;
+          if (res_same) r.cr = load_chunk<T>(reinterpret_cast<const T*>(a.res.ptr) + r.off);
+          if (a.accum) r.co = load_chunk<T>(dst + r.off);
+          if (bn_bwd) {
+            r.cx = load_chunk<T>(reinterpret_cast<const T*>(a.bn_x) + r.off);
+            if (a.bn_mask) r.cm = load_chunk<T>(reinterpret_cast<const T*>(a.bn_mask) + r.off);
+          }
+        };
+        Row nxt;
+        fetch(rl, nxt);
+        for (int srow = rl; srow < SR; srow += LANES) {
+          const Row cur = nxt;
+          fetch(srow + LANES, nxt);
+          if (!cur.ok) continue;
           float v[CE];
           const float* cp = ctile + srow * LDC + cg * CE;
 #pragma unroll
@@ -268,36 +288,31 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
             v[e] = t.x + bias[e]; v[e + 1] = t.y + bias[e + 1]; v[e + 2] = t.z + bias[e + 2]; v[e + 3] = t.w + bias[e + 3];
           }
           if (res_same) {
-            Chunk<T> cr = load_chunk<T>(reinterpret_cast<const T*>(a.res.ptr) + off);
 #pragma unroll
-            for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cr.e[e]);
+            for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cur.cr.e[e]);
           } else if (a.res.mode != RN_RES_NONE) {
-            res_add_chunk<T>(a.res, n, hd, wd, k0, v);
+            res_add_chunk<T>(a.res, cur.n, cur.hd, cur.wd, k0, v);
           }
           if (a.accum) {
-            Chunk<T> co = load_chunk<T>(dst + off);
 #pragma unroll
-            for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(co.e[e]);
+            for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cur.co.e[e]);
           }
           Chunk<T> st;
 #pragma unroll
           for (int e = 0; e < CE; ++e) st.e[e] = Elem<T>::from_f(v[e]);
-          if (a.probe_ep != 1 || st.u.x == 0x12345678u) store_chunk<T>(dst + off, st);
+          if (a.probe_ep != 1 || st.u.x == 0x12345678u) store_chunk<T>(dst + cur.off, st);
           if (want_stats) {
-            const int gi = NGRP > 1 ? trow / RN_CONV_STATS_ROWS : 0;
+            const int gi = NGRP > 1 ? cur.trow / RN_CONV_STATS_ROWS : 0;
             float d0[CE], d1[CE];
             if (!bn_bwd) {
 #pragma unroll
               for (int e = 0; e < CE; ++e) { const float vs = Elem<T>::to_f(st.e[e]); d0[e] = vs; d1[e] = vs * vs; }
             } else {
-              Chunk<T> cx = load_chunk<T>(reinterpret_cast<const T*>(a.bn_x) + off);
-              Chunk<T> cm;
-              if (a.bn_mask) cm = load_chunk<T>(reinterpret_cast<const T*>(a.bn_mask) + off);
 #pragma unroll
               for (int e = 0; e < CE; ++e) {
                 float g = Elem<T>::to_f(st.e[e]) * a.gscale;
-                if (a.bn_mask && !(Elem<T>::to_f(cm.e[e]) > 0.f)) g = 0.f;
-                const float xh = (Elem<T>::to_f(cx.e[e]) - mean[e]) * invstd[e];
+                if (a.bn_mask && !(Elem<T>::to_f(cur.cm.e[e]) > 0.f)) g = 0.f;
+                const float xh = (Elem<T>::to_f(cur.cx.e[e]) - mean[e]) * invstd[e];
                 d0[e] = g; d1[e] = g * xh;
               }
             }
