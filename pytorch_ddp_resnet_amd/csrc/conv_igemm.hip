@@ -63,6 +63,7 @@ struct IgemmArgs {
   unsigned long long* stamps;   // diagnostic: per-workgroup s_memtime stamps [grid][16] (rn_set_stamp_buffer), NULL in production
   int probe_ep;            // timing probes: 1 = skip the global stores of the epilogue, 2 = skip the epilogue
   int xcd_remap;           // 1: blockIdx -> tile through the bijective XCD remap, column tiles fastest
+  int dense_src;           // 1: one tap at offset (0,0), unit stride, source grid == compute grid (1x1 convolutions): row m reads pixel m
   int dh[MAX_TAPS], dw[MAX_TAPS], widx[MAX_TAPS];
 };
 
@@ -75,7 +76,7 @@ __device__ inline void preload_args(const IgemmArgs& a) {
   RN_TOUCH(a.nt); RN_TOUCH(a.wrs); RN_TOUCH(a.cpt); RN_TOUCH(a.nk); RN_TOUCH(a.nth); RN_TOUCH(a.ntw);
   RN_TOUCH(a.magic_pq); RN_TOUCH(a.magic_q); RN_TOUCH(a.accum); RN_TOUCH(a.tile_base);
   RN_TOUCH(a.stats); RN_TOUCH(a.bn_x); RN_TOUCH(a.bn_mask); RN_TOUCH(a.bn_coef); RN_TOUCH(a.bias); RN_TOUCH(a.gscale);
-  RN_TOUCH(a.probe_mask); RN_TOUCH(a.stamps); RN_TOUCH(a.probe_ep); RN_TOUCH(a.xcd_remap);
+  RN_TOUCH(a.probe_mask); RN_TOUCH(a.stamps); RN_TOUCH(a.probe_ep); RN_TOUCH(a.xcd_remap); RN_TOUCH(a.dense_src);
 #undef RN_TOUCH
 }
 
@@ -534,11 +535,16 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
     const int m = m0 + RPI * (wave * AI + i) + lrow;
     amask[i] = 0; abase[i] = 0;
     if (m < a.M) {
-      int n, pp, q;
-      decode_row(a, m, pq, n, pp, q);
-      const int hb = pp * a.ss, wb = q * a.ss;
-      abase[i] = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES);
-      amask[i] = tap_mask(a, grid, hb, wb);
+      if (a.dense_src) {                                 // 1x1, stride 1: no decode, no padding
+        abase[i] = (unsigned)((size_t)(m - n_first * pq) * a.Cs * ES);
+        amask[i] = 1;
+      } else {
+        int n, pp, q;
+        decode_row(a, m, pq, n, pp, q);
+        const int hb = pp * a.ss, wb = q * a.ss;
+        abase[i] = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES);
+        amask[i] = tap_mask(a, grid, hb, wb);
+      }
     }
   }
   unsigned bbase[BI];
@@ -703,11 +709,16 @@ __global__ __launch_bounds__(512, BM >= 256 ? 1 : 2) void igemm_ws_kernel(const 
       const int m = m0 + RPI * (lw * AI + i) + lrow;
       amask[i] = 0; abase[i] = 0;
       if (m < a.M) {
-        int n, pp, q;
-        decode_row(a, m, pq, n, pp, q);
-        const int hb = pp * a.ss, wb = q * a.ss;
-        abase[i] = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES);
-        amask[i] = tap_mask(a, grid, hb, wb);
+        if (a.dense_src) {
+          abase[i] = (unsigned)((size_t)(m - n_first * pq) * a.Cs * ES);
+          amask[i] = 1;
+        } else {
+          int n, pp, q;
+          decode_row(a, m, pq, n, pp, q);
+          const int hb = pp * a.ss, wb = q * a.ss;
+          abase[i] = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES);
+          amask[i] = tap_mask(a, grid, hb, wb);
+        }
       }
     }
 #pragma unroll
@@ -862,6 +873,7 @@ void fill_res(ResDesc& r, const void* res, int mode, int res_C, int dN, int dH, 
 }  // namespace
 
 static void fill_magic(IgemmArgs& a) {
+  a.dense_src = (a.nt == 1 && a.dh[0] == 0 && a.dw[0] == 0 && a.ss == 1 && a.Hs == a.Pc && a.Ws == a.Qc) ? 1 : 0;
   const unsigned long long pq = (unsigned long long)a.Pc * a.Qc;
   a.magic_pq = pq <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / pq);
   a.magic_q = a.Qc <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned)a.Qc);
