@@ -84,6 +84,8 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print the per-op-kind time table to stderr')
     ap.add_argument('--sync-bn', action='store_true')
+    ap.add_argument('--optimizer', default='none', choices=['none', 'fused', 'torch'],
+                    help='also run the reference\'s SGD update (config.yaml:22-28) inside the timed step; the headline metric is fwd+bwd: none')
     ap.add_argument('--dropout', type=float, default=None, help='override the workload\'s dropout probability (diagnostics)')
     ap.add_argument('--per-op', type=int, default=0, help='with --breakdown: list the N slowest single ops with their geometry')
     args = ap.parse_args()
@@ -122,6 +124,14 @@ def main():
     model.alias_grads = True            # gradients are consumed (dropped) every step: no defensive copy of the flat buffer
 
     params = list(model.parameters())
+    opt = None
+    if args.optimizer != 'none':
+        sgd_args = dict(lr=0.1, momentum=0.9, dampening=0.0, nesterov=True, weight_decay=5e-4)        # the WRN-28-10 run's optimizer_args
+        if args.optimizer == 'fused':
+            from pytorch_ddp_resnet_amd.utils.fused_sgd import FusedSGD
+            opt = FusedSGD(model, **sgd_args)
+        else:
+            opt = torch.optim.SGD(model.parameters(), **sgd_args)
 
     def step():
         for p_ in params:
@@ -131,6 +141,8 @@ def main():
         loss.backward()
         if reducer is not None:
             reducer.finish()
+        if opt is not None:
+            opt.step()
         return loss
 
     def fence():
@@ -215,7 +227,7 @@ def main():
             'dtype': args.dtype, 'data': 'synthetic',
             'config': {'workload': f"{args.workload} CIFAR-10 32x32" if cfg['hw'] == 32 else f"{args.workload} 224x224", 'architecture_spec': cfg['spec'],
                        'preact': cfg['preact'], 'use_proj': cfg['use_proj'], 'dropout_prob': cfg['p'], 'batch_per_gpu': cfg['batch'],
-                       'global_batch': cfg['batch'] * world, 'parallelism': f'dp{world}', 'timed_region': 'fwd + CE loss + bwd + grad all-reduce (no optimizer step)',
+                       'global_batch': cfg['batch'] * world, 'parallelism': f'dp{world}', 'timed_region': 'fwd + CE loss + bwd + grad all-reduce' + (' (no optimizer step)' if opt is None else f' + SGD step ({args.optimizer})'),
                        'sync_bn': bool(args.sync_bn)},
             'roofline': roof,
         }
