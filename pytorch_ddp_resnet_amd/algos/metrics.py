@@ -30,3 +30,33 @@ def global_means(metrics, world_size):
         dist.all_reduce(packed, op=dist.ReduceOp.SUM)
     vals = (packed / world_size).tolist()
     return Counter(dict(zip(keys, vals)))
+
+
+class PendingMeans:
+    """world-averaged logging values of one microbatch whose device->host copy is still in flight.  ``result()`` blocks only
+    until THAT copy has landed, so a training loop that resolves step i-1 after it has enqueued step i never idles the GPU
+    (the reference reads three scalars with ``.item()`` right after every backward: metrics.py:32-36)."""
+
+    def __init__(self, keys, host, event):
+        self.keys, self._host, self._event = keys, host, event
+
+    def result(self):
+        if self._event is not None:
+            self._event.synchronize()
+        return Counter(dict(zip(self.keys, self._host.tolist())))
+
+
+def global_means_async(metrics, world_size):
+    """as global_means, but returns a PendingMeans: one 3-float all-reduce, then an asynchronous copy into pinned memory."""
+    keys = list(metrics)
+    packed = torch.stack([metrics[k].detach().float() for k in keys])
+    if world_size > 1 and dist.is_initialized():
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM)
+    packed = packed / world_size
+    if not packed.is_cuda:
+        return PendingMeans(keys, packed, None)
+    host = torch.empty(packed.shape, dtype=packed.dtype, pin_memory=True)
+    host.copy_(packed, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(packed.device))
+    return PendingMeans(keys, host, ev)

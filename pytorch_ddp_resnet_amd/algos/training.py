@@ -11,12 +11,13 @@ from typing import Optional
 
 import torch
 
-from .metrics import compute_losses_and_metrics, global_means
+from .metrics import compute_losses_and_metrics, global_means, global_means_async
 
 
-def train_step(classifier, x, y, optimizer=None, reducer=None, world_size=1, microbatch_id=1, num_microbatches=1, accum=None):
-    """one microbatch.  returns the world-averaged metrics (Counter of floats).  ``reducer``: ddp.GradReducer or None;
-    ``accum``: dict used to sum gradients across microbatches when num_microbatches > 1."""
+def train_step(classifier, x, y, optimizer=None, reducer=None, world_size=1, microbatch_id=1, num_microbatches=1, accum=None, lazy=False):
+    """one microbatch.  returns the world-averaged metrics (Counter of floats; with ``lazy`` a metrics.PendingMeans whose
+    host copy is still in flight).  ``reducer``: ddp.GradReducer or None; ``accum``: dict used to sum gradients across
+    microbatches when num_microbatches > 1."""
     logits = classifier(x)
     metrics = compute_losses_and_metrics(logits=logits, labels=y)
     metrics['loss'].backward()
@@ -31,7 +32,7 @@ def train_step(classifier, x, y, optimizer=None, reducer=None, world_size=1, mic
             else:
                 accum[k] = p.grad.clone()
             p.grad = None
-    out = global_means(metrics, world_size)
+    out = global_means_async(metrics, world_size) if lazy else global_means(metrics, world_size)
     if optimizer is not None and microbatch_id % num_microbatches == 0:
         if num_microbatches > 1 and accum is not None:
             for k, p in classifier.named_parameters():
@@ -50,19 +51,34 @@ def training_loop(rank, world_size, device, dl_train, dl_test, classifier, optim
             sampler_train.set_epoch(epoch)
         classifier.train()
         acc, running = {}, Counter()
+        # the logging values of a microbatch are read one microbatch LATE (after the next one has been enqueued), so the
+        # device never waits for the host; the printed lines and their order are those of the reference
+        pending = []                                       # [(PendingMeans, closes_a_step, global_step)]
+
+        def resolve(upto):
+            nonlocal running
+            while len(pending) > upto:
+                pm, closes, gs = pending.pop(0)
+                running += pm.result()
+                if closes:
+                    means = {k: v / num_microbatches for k, v in running.items()}
+                    if rank == 0:
+                        log(f"global step: {gs}... loss: {means.get('loss')}")
+                    running = Counter()
+
         for microbatch_id, (x, y) in enumerate(dl_train, 1):
             x, y = x.to(device), y.to(device)
-            running += train_step(classifier, x, y, optimizer, reducer, world_size, microbatch_id, num_microbatches, acc)
-            if microbatch_id % num_microbatches == 0:
-                means = {k: v / num_microbatches for k, v in running.items()}
+            pm = train_step(classifier, x, y, optimizer, reducer, world_size, microbatch_id, num_microbatches, acc, lazy=True)
+            closes = microbatch_id % num_microbatches == 0
+            pending.append((pm, closes, global_step))
+            resolve(1)                                     # everything but the microbatch just enqueued
+            if closes:
                 if scheduler is not None and scheduler_step_unit == 'batch':
                     scheduler.step()
-                if rank == 0:
-                    log(f"global step: {global_step}... loss: {means.get('loss')}")
-                running = Counter()
                 global_step += 1
                 if global_step >= max_steps:
                     break
+        resolve(0)
         if dl_test is not None:
             val = evaluation_loop(world_size, device, dl_test, classifier)
             if scheduler is not None and scheduler_step_unit == 'epoch':
