@@ -63,6 +63,13 @@ class FusedSGD(torch.optim.Optimizer):
         eng = self._engine_of(None)
         if eng is None:
             raise _lib.RnError("FusedSGD.step before any forward/backward of the model on the device")
+        if self._flat is not None:                    # parameters replaced since (module.to(...), load of new tensors): re-home them
+            lo, hi = self._flat.data_ptr(), self._flat.data_ptr() + self._flat.numel() * 4
+            if any(not (lo <= p.data_ptr() < hi) for _, p in self._named):
+                mom = self._mom
+                self._flatten(eng)
+                if mom is not None and mom.shape == self._mom.shape and mom.device == self._mom.device:
+                    self._mom.copy_(mom)
         if self._flat is None:
             self._flatten(eng)
         k0, p0 = self._named[0]
