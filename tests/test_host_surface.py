@@ -155,3 +155,32 @@ def test_fused_sgd_with_accumulated_microbatches():
         opt2.step()
         for (k, p), (_, q) in zip(m.named_parameters(), m2.named_parameters()):
             assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), (rnd, k)
+
+
+def test_training_loop_lagged_logging_is_complete_and_ordered():
+    """the logging values are read one microbatch late (metrics.global_means_async): every step is still logged once, in
+    order, with the values a blocking read gives (any module works on CPU here: the loop is host logic)."""
+    from pytorch_ddp_resnet_amd.algos.training import training_loop, train_step
+    from pytorch_ddp_resnet_amd.algos.metrics import global_means, global_means_async, compute_losses_and_metrics
+    torch.manual_seed(0)
+    xs = [(torch.randn(6, 12), torch.randint(0, 10, (6,))) for _ in range(3)]
+
+    def make():
+        torch.manual_seed(1)
+        m = torch.nn.Linear(12, 10)
+        return m, torch.optim.SGD(m.parameters(), lr=0.1)
+    m, opt = make()
+    lines = []
+    steps = training_loop(0, 1, torch.device('cpu'), xs, None, m, opt, num_microbatches=1, max_steps=7, log=lines.append)
+    assert steps == 7 and [ln.split('...')[0] for ln in lines] == [f'global step: {i}' for i in range(7)]
+    m2, opt2 = make()
+    ref = []
+    while len(ref) < 7:
+        for x, y in xs:
+            ref.append(train_step(m2, x, y, opt2)['loss'])
+            if len(ref) == 7:
+                break
+    got = [float(ln.split('loss: ')[1]) for ln in lines]
+    assert all(abs(a - b) < 1e-6 for a, b in zip(got, ref)), (got, ref)
+    met = compute_losses_and_metrics(torch.randn(5, 10), torch.randint(0, 10, (5,)))
+    assert global_means_async(met, 1).result() == global_means(met, 1)
