@@ -842,6 +842,13 @@ template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   if (K % 128 == 0) return launch_cfg<T, 128, 128, 2, 2>(a, s);
   if (K % 96 == 0) return launch_cfg<T, 128, 96, 4, 1>(a, s);
   if (K > 32) return launch_cfg<T, 128, 64, 2, 2>(a, s);
+  // thin layers (K <= 32) on large maps: a tile's fixed cost (row setup, first stage, epilogue: ~8 us) dominates its two or
+  // three K iterations, so 256-row tiles halve it per output row; still two workgroups per CU (74 KB of LDS each)
+  if (!(g_rn_variant & 32) && (long)cdiv(a.M, 256) >= 512) {
+    hipLaunchKernelGGL((igemm_dma_kernel<T, 256, 32, 4, 1, 8, 2>), dim3(cdiv(a.M, 256) * cdiv(K, 32)), dim3(256), 0, s, a);
+    RN_CHECK_LAUNCH("igemm_thin");
+    return 0;
+  }
   return launch_cfg<T, 128, 32, 4, 1>(a, s);
 }
 
