@@ -26,7 +26,7 @@ extern "C" {
 
 typedef void* rn_stream;                 /* a hipStream_t */
 
-enum { RN_F32 = 0, RN_BF16 = 1 };
+enum { RN_F32 = 0, RN_BF16 = 1, RN_F16 = 2 };   /* RN_F16: IEEE half storage + f16 MFMA, fp32 accumulate; needs loss scaling (rn_amp_*) */
 
 /* residual / merge operand addressing, shared by conv epilogues, bn_apply and bn_bwd_apply */
 enum {
@@ -98,6 +98,14 @@ const char* rn_last_error(void);
 int rn_version(void);
 /* kernel-variant switch for A/B measurements (tools/conv_bench.py; bits documented in csrc/conv_igemm.hip); 0 = shipped */
 void rn_set_variant(int v);
+/* which convolution kernel ran: rn_kernel_log(1) starts (and clears) a per-thread log of the instantiations the conv launchers
+ * pick ("igemm_dma<128x160>", "wgrad<160x160>", ...), rn_kernel_log_read() returns them comma-separated, rn_kernel_log(0) stops.
+ * rn_conv_kernel_names: the names a geometry WOULD select (pass 0 forward, 1 dgrad, 2 wgrad), without launching anything
+ * (host-only: works without a GPU) -- the tests use it to prove that every tile a BASELINE config selects is parity-tested */
+void rn_kernel_log(int enable);
+const char* rn_kernel_log_read(void);
+struct rn_conv_geom;
+int rn_conv_kernel_names(int pass, int dtype, const struct rn_conv_geom* g, int fused_epilogue, char* out, size_t n);
 /* diagnostic builds only: device buffer [grid][16] of u64 s_memtime stamps written by the implicit-GEMM kernels (NULL = off) */
 void rn_set_stamp_buffer(void* device_u64);
 
@@ -226,13 +234,20 @@ int rn_pool_fc_fwd(const void* x, const float* w, const float* b, float* feat, f
 int rn_pool_fc_bwd(const float* dlogits, const float* feat, const float* w, void* dx, float* dw, float* db, int dtype,
                    int N, int HW, int C, int O, int flags, rn_stream s);
 
-/* out3 = (sum nll, #top1 wrong, #top5 wrong) over the batch (fp32, overwritten); dlogits = (softmax - onehot) * scale */
+/* out3 = (sum nll, #top1 wrong, #top5 wrong) over the batch (fp32, overwritten); dlogits (may be NULL) = (softmax - onehot) *
+ * scale * (scale_dev ? *scale_dev : 1): scale_dev is a DEVICE scalar -- the upstream gradient of the loss, i.e. the AMP loss scale of
+ * scaler.scale(loss).backward() (training.py:100) -- so no host synchronisation is needed to apply it */
 int rn_softmax_ce(const float* logits, const int64_t* labels, float* out3, float* dlogits, int N, int O, float scale,
-                  rn_stream s);
+                  const float* scale_dev, rn_stream s);
 
 /* fused multi-tensor SGD over one flat fp32 buffer (torch.optim.SGD rule; optim_util.py:11-18, config.yaml:22-28) */
 int rn_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
                 float dampening, float weight_decay, int nesterov, int first_step, float grad_scale, rn_stream s);
+/* the same under AMP (GradScaler.step, training.py:104-110): gradients are divided by *loss_scale_dev and the whole step is skipped
+ * when *found_inf_dev != 0 (both device scalars, either may be NULL) */
+int rn_sgd_step_amp(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
+                    float weight_decay, int nesterov, int first_step, const float* loss_scale_dev, const float* found_inf_dev,
+                    rn_stream s);
 
 #ifdef __cplusplus
 }

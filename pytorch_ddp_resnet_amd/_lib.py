@@ -51,9 +51,14 @@ def lib():
     L.rn_conv_wgrad_ws_bytes.restype = sz
     L.rn_stem_wgrad_ws_bytes.argtypes = [C.POINTER(RnConvGeom)]
     L.rn_stem_wgrad_ws_bytes.restype = sz
-    L.rn_softmax_ce.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp]
+    L.rn_softmax_ce.argtypes = [vp, vp, vp, vp, i32, i32, f32, vp, vp]
     L.rn_sgd_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, f32, vp]
+    L.rn_sgd_step_amp.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, vp, vp, vp]
     L.rn_set_variant.argtypes = [i32]
+    L.rn_kernel_log.argtypes = [i32]
+    L.rn_kernel_log.restype = None
+    L.rn_kernel_log_read.restype = C.c_char_p
+    L.rn_conv_kernel_names.argtypes = [i32, i32, C.POINTER(RnConvGeom), i32, C.c_char_p, sz]
     if os.environ.get('RN_VARIANT'):          # kernel-variant switch for A/B runs (tools/conv_bench.py); unset = shipped configuration
         L.rn_set_variant(int(os.environ['RN_VARIANT']))
     _lib = L
@@ -63,6 +68,14 @@ def lib():
 def check(rc):
     if rc != 0:
         raise RnError(lib().rn_last_error().decode())
+
+
+def conv_kernel_names(pass_, dtype, g, fused_epilogue=False):
+    """names of the kernels a convolution geometry selects (pass_: 0 forward, 1 dgrad, 2 wgrad), without launching."""
+    buf = C.create_string_buffer(512)
+    gs = geom_struct(g)
+    check(lib().rn_conv_kernel_names(pass_, dtype, C.byref(gs), int(fused_epilogue), buf, 512))
+    return buf.value.decode().split(',') if buf.value else []
 
 
 def geom_struct(d):

@@ -19,6 +19,13 @@ def top_k_err(logits, labels, k):
 
 
 def compute_losses_and_metrics(logits, labels):
+    """metrics.py:21-29.  Logits that come straight out of a HIP-engine ``ResNet.forward`` take the fused path (one launch
+    forward, one backward: architectures/resnet.py:_LossFn); anything else (CPU tensors, detached logits, eval under
+    no_grad) goes through the reference's own torch ops below -- same values (tests/test_gpu_model.py)."""
+    from ..architectures.resnet import fused_loss_and_metrics
+    fused = fused_loss_and_metrics(logits, labels)
+    if fused is not None:
+        return {"loss": fused[0], "top1_err": fused[1], "top5_err": fused[2]}
     return {"loss": cross_entropy_loss(logits, labels), "top1_err": top_k_err(logits, labels, 1), "top5_err": top_k_err(logits, labels, 5)}
 
 

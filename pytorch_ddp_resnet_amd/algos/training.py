@@ -14,13 +14,32 @@ import torch
 from .metrics import compute_losses_and_metrics, global_means, global_means_async
 
 
-def train_step(classifier, x, y, optimizer=None, reducer=None, world_size=1, microbatch_id=1, num_microbatches=1, accum=None, lazy=False):
+def requires_loss(scheduler) -> bool:
+    """training.py:20-21"""
+    return isinstance(scheduler, torch.optim.lr_scheduler.ReduceLROnPlateau)
+
+
+def step_scheduler(scheduler, loss) -> None:
+    """training.py:24-28: a plateau scheduler is stepped with the loss, every other one without."""
+    if requires_loss(scheduler):
+        scheduler.step(loss)
+    else:
+        scheduler.step()
+
+
+def train_step(classifier, x, y, optimizer=None, reducer=None, world_size=1, microbatch_id=1, num_microbatches=1, accum=None, lazy=False,
+               scaler=None):
     """one microbatch.  returns the world-averaged metrics (Counter of floats; with ``lazy`` a metrics.PendingMeans whose
     host copy is still in flight).  ``reducer``: ddp.GradReducer or None; ``accum``: dict used to sum gradients across
-    microbatches when num_microbatches > 1."""
+    microbatches when num_microbatches > 1; ``scaler``: a torch GradScaler -- the reference's AMP branch (training.py:95-110:
+    scaled backward, ``scaler.step`` / ``scaler.update`` at the batch end); the fp16 engine needs it, there is no autocast
+    context because the engine's compute dtype is fixed at construction."""
     logits = classifier(x)
     metrics = compute_losses_and_metrics(logits=logits, labels=y)
-    metrics['loss'].backward()
+    if scaler is not None:
+        scaler.scale(metrics['loss']).backward()
+    else:
+        metrics['loss'].backward()
     if reducer is not None:
         reducer.finish()
     if num_microbatches > 1 and accum is not None:
@@ -37,13 +56,17 @@ def train_step(classifier, x, y, optimizer=None, reducer=None, world_size=1, mic
         if num_microbatches > 1 and accum is not None:
             for k, p in classifier.named_parameters():
                 p.grad = accum.pop(k, None)
-        optimizer.step()
+        if scaler is not None:
+            scaler.step(optimizer)
+            scaler.update()
+        else:
+            optimizer.step()
         optimizer.zero_grad(set_to_none=True)
     return out
 
 
 def training_loop(rank, world_size, device, dl_train, dl_test, classifier, optimizer, scheduler=None, scheduler_step_unit='none',
-                  num_microbatches=1, global_step=0, max_steps=1, reducer=None, sampler_train=None, log=print, **kwargs):
+                  num_microbatches=1, global_step=0, max_steps=1, reducer=None, sampler_train=None, log=print, scaler=None, **kwargs):
     from .evaluation import evaluation_loop
     epoch = 0
     while global_step < max_steps:
@@ -55,6 +78,8 @@ def training_loop(rank, world_size, device, dl_train, dl_test, classifier, optim
         # device never waits for the host; the printed lines and their order are those of the reference
         pending = []                                       # [(PendingMeans, closes_a_step, global_step)]
 
+        last_loss = [None]
+
         def resolve(upto):
             nonlocal running
             while len(pending) > upto:
@@ -62,19 +87,22 @@ def training_loop(rank, world_size, device, dl_train, dl_test, classifier, optim
                 running += pm.result()
                 if closes:
                     means = {k: v / num_microbatches for k, v in running.items()}
+                    last_loss[0] = means.get('loss')
                     if rank == 0:
                         log(f"global step: {gs}... loss: {means.get('loss')}")
                     running = Counter()
 
         for microbatch_id, (x, y) in enumerate(dl_train, 1):
             x, y = x.to(device), y.to(device)
-            pm = train_step(classifier, x, y, optimizer, reducer, world_size, microbatch_id, num_microbatches, acc, lazy=True)
+            pm = train_step(classifier, x, y, optimizer, reducer, world_size, microbatch_id, num_microbatches, acc, lazy=True, scaler=scaler)
             closes = microbatch_id % num_microbatches == 0
             pending.append((pm, closes, global_step))
             resolve(1)                                     # everything but the microbatch just enqueued
             if closes:
                 if scheduler is not None and scheduler_step_unit == 'batch':
-                    scheduler.step()
+                    if requires_loss(scheduler):
+                        resolve(0)                         # a plateau scheduler needs THIS step's mean loss now (training.py:119-120)
+                    step_scheduler(scheduler, last_loss[0])
                 global_step += 1
                 if global_step >= max_steps:
                     break
@@ -82,7 +110,7 @@ def training_loop(rank, world_size, device, dl_train, dl_test, classifier, optim
         if dl_test is not None:
             val = evaluation_loop(world_size, device, dl_test, classifier)
             if scheduler is not None and scheduler_step_unit == 'epoch':
-                scheduler.step()
+                step_scheduler(scheduler, val.get('loss'))
             if rank == 0:
                 log(f"epoch: {epoch}... validation loss: {val.get('loss')}")
         epoch += 1

@@ -19,7 +19,8 @@ from torch import nn
 from .residual_block import ResidualBlock, BottleneckResidualBlock, _conv_holder
 from .spec import parse_spec
 
-_DTYPES = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16}
+_DTYPES = {'fp32': torch.float32, 'float32': torch.float32, 'bf16': torch.bfloat16, 'bfloat16': torch.bfloat16,
+           'fp16': torch.float16, 'float16': torch.float16, 'half': torch.float16}
 
 
 class _EngineFn(torch.autograd.Function):
@@ -40,7 +41,8 @@ class _EngineFn(torch.autograd.Function):
                                "call backward before the next forward")
         if 'dlogits' not in eng.plan.slot_of:
             raise RuntimeError("forward ran without gradient support")
-        eng.t('dlogits').copy_(dlogits)
+        if dlogits.data_ptr() != eng.t('dlogits').data_ptr():      # the fused loss (_LossFn) has already written it in place
+            eng.t('dlogits').copy_(dlogits)
         eng.backward(step_seed=ctx.seed, hook_fn=ctx.model._hook_fn)
         # autograd's AccumulateGrad keeps (steals) the tensors returned here as p.grad.  Handing out views of the engine's
         # flat buffer is zero-copy but means the NEXT backward overwrites p.grad in place -- only safe when the caller
@@ -50,6 +52,56 @@ class _EngineFn(torch.autograd.Function):
                                "an existing .grad would alias the buffer the engine has just overwritten")
         flat = eng.flat_grad if ctx.model.alias_grads else eng.flat_grad.clone()
         return (None, None, None, None) + tuple(eng.grad_view(k, flat) for k in ctx.keys)
+
+
+class _LossFn(torch.autograd.Function):
+    """mean cross-entropy + top-1 / top-5 error (reference metrics.py:10-29) on the engine's logits as ONE launch
+    (rn_softmax_ce) instead of ATen's log_softmax / nll_loss / topk / eq / mean chains; the backward is one more launch that
+    writes dL/dlogits straight into the engine's buffer, multiplied by the upstream gradient of the loss ON THE DEVICE (a
+    GradScaler's loss scale under ``scaler.scale(loss).backward()``, training.py:100), so no copy and no host sync."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, eng, gen):
+        import ctypes as C
+        from .. import _lib
+        N, O = logits.shape
+        out3 = eng.loss_scratch(0)
+        st = C.c_void_p(torch.cuda.current_stream(logits.device).cuda_stream)
+        _lib.check(eng.L.rn_softmax_ce(C.c_void_p(eng.t('logits').data_ptr()), C.c_void_p(labels.data_ptr()), C.c_void_p(out3.data_ptr()), None,
+                                      N, O, 1.0 / N, None, st))
+        vals = out3[:3] * (1.0 / N)
+        ctx.eng, ctx.gen, ctx.labels, ctx.shape = eng, gen, labels, (N, O)
+        loss, t1, t5 = vals[0], vals[1], vals[2]
+        ctx.mark_non_differentiable(t1, t5)
+        return loss, t1, t5
+
+    @staticmethod
+    def backward(ctx, gloss, _g1, _g5):
+        import ctypes as C
+        from .. import _lib
+        eng = ctx.eng
+        if eng.generation != ctx.gen:
+            raise RuntimeError("the engine's logits were overwritten by a later forward; call backward before the next forward")
+        N, O = ctx.shape
+        gloss = gloss.detach().float().contiguous()
+        st = C.c_void_p(torch.cuda.current_stream(gloss.device).cuda_stream)
+        _lib.check(eng.L.rn_softmax_ce(C.c_void_p(eng.t('logits').data_ptr()), C.c_void_p(ctx.labels.data_ptr()), C.c_void_p(eng.loss_scratch(1).data_ptr()),
+                                      C.c_void_p(eng.t('dlogits').data_ptr()), N, O, 1.0 / N, C.c_void_p(gloss.data_ptr()), st))
+        return eng.t('dlogits'), None, None, None
+
+
+def fused_loss_and_metrics(logits, labels):
+    """-> (loss, top1_err, top5_err) through the engine's fused kernel when ``logits`` is the fresh output of a HIP-engine
+    ResNet.forward with gradients enabled; None when it is not (the caller then uses the reference's torch ops)."""
+    src = getattr(logits, '_rn_src', None)
+    if src is None:
+        return None
+    eng, gen = src
+    if eng.generation != gen or 'dlogits' not in eng.plan.slot_of or not logits.requires_grad:
+        return None
+    if labels.dtype != torch.int64 or labels.device != logits.device or not labels.is_contiguous() or logits.shape[1] < 5:
+        return None
+    return _LossFn.apply(logits, labels, eng, gen)
 
 
 class ResNet(nn.Module):
@@ -136,4 +188,7 @@ class ResNet(nn.Module):
         seed = (self._seed_base + self._step) & 0x7FFFFFFFFFFFFFFF
         params = [p for _, p in self.named_parameters()]
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)   # (grad mode is off inside Function.forward)
-        return _EngineFn.apply(self, x, seed, need_grad, *params)
+        out = _EngineFn.apply(self, x, seed, need_grad, *params)
+        eng = self._engine(x.shape, self.training, need_grad)
+        out._rn_src = (eng, eng.generation)        # lets algos.metrics.compute_losses_and_metrics take the fused loss path
+        return out

@@ -414,7 +414,7 @@ inline void make_res(ResDesc& r, const void* p, int mode, int res_C, int H, int 
 }
 
 inline int check_mc(int dtype, long M, int C, const char* who) {
-  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "%s: bad dtype %d", who, dtype);
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype), "%s: bad dtype %d", who, dtype);
   RN_CHECK_ARG(M > 0 && C > 0 && C % (dtype == RN_F32 ? 4 : 8) == 0, "%s: bad shape M=%ld C=%d", who, M, C);
   return 0;
 }
@@ -425,10 +425,7 @@ extern "C" int rn_bn_stats(const void* x, float* partial, int nblk, int dtype, i
   if (int e = check_mc(dtype, M, C, "rn_bn_stats")) return e;
   RN_CHECK_ARG(x && partial && nblk > 0 && M < (1L << 31), "rn_bn_stats: bad argument");
   const int rows = (int)((M + nblk - 1) / nblk);
-  if (dtype == RN_F32)
-    hipLaunchKernelGGL((bn_reduce_kernel<float, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const float*)x, nullptr, nullptr, nullptr, partial, (int)M, C, rows, 0, 1.f, 0u, 0u);
-  else
-    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const bf16_t*)x, nullptr, nullptr, nullptr, partial, (int)M, C, rows, 0, 1.f, 0u, 0u);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T_, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const T_*)x, nullptr, nullptr, nullptr, partial, (int)M, C, rows, 0, 1.f, 0u, 0u));
   RN_CHECK_LAUNCH("bn_stats");
   return 0;
 }
@@ -462,10 +459,7 @@ extern "C" int rn_bn_apply(const void* x, const float* coef, const void* res, vo
   (void)nchunks;
   const int rows = slab_rows(M, C, ce);
   const int grid = cdiv(M, rows);
-  if (dtype == RN_F32)
-    hipLaunchKernelGGL((bn_apply_kernel<float>), dim3(grid), dim3(NT), 0, as_stream(s), (const float*)x, coef, r, (float*)out, (int)M, H, W, C, rows, relu, inv_keep, key, thr);
-  else
-    hipLaunchKernelGGL((bn_apply_kernel<bf16_t>), dim3(grid), dim3(NT), 0, as_stream(s), (const bf16_t*)x, coef, r, (bf16_t*)out, (int)M, H, W, C, rows, relu, inv_keep, key, thr);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T_>), dim3(grid), dim3(NT), 0, as_stream(s), (const T_*)x, coef, r, (T_*)out, (int)M, H, W, C, rows, relu, inv_keep, key, thr));
   RN_CHECK_LAUNCH("bn_apply");
   return 0;
 }
@@ -480,10 +474,7 @@ extern "C" int rn_bn_bwd_reduce(const void* dout, const void* x, const void* mas
   RN_CHECK_ARG(drop_p == 0.f || (use_mask == 2 && M * C < (1L << 32)), "rn_bn_bwd_reduce: dropout recompute needs RN_F_MASK_RECOMPUTE and < 2^32 elements");
   const uint32_t thr = drop_p > 0.f ? rn_drop_threshold(drop_p) : 0u, key = rn_drop_key(site, step_seed);
   const int rows = (int)((M + nblk - 1) / nblk);
-  if (dtype == RN_F32)
-    hipLaunchKernelGGL((bn_reduce_kernel<float, 1>), dim3(nblk), dim3(NT), 0, as_stream(s), (const float*)x, (const float*)dout, (const float*)mask_src, coef, partial, (int)M, C, rows, use_mask, gscale, key, thr);
-  else
-    hipLaunchKernelGGL((bn_reduce_kernel<bf16_t, 1>), dim3(nblk), dim3(NT), 0, as_stream(s), (const bf16_t*)x, (const bf16_t*)dout, (const bf16_t*)mask_src, coef, partial, (int)M, C, rows, use_mask, gscale, key, thr);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T_, 1>), dim3(nblk), dim3(NT), 0, as_stream(s), (const T_*)x, (const T_*)dout, (const T_*)mask_src, coef, partial, (int)M, C, rows, use_mask, gscale, key, thr));
   RN_CHECK_LAUNCH("bn_bwd_reduce");
   return 0;
 }
@@ -516,8 +507,7 @@ extern "C" int rn_bn_bwd_apply(const void* dout, const void* x, const void* mask
   const int rows = slab_rows_stream(M, C, ce);
   const int grid = cdiv(M, rows);
   const int add_kind = r.mode == RN_RES_NONE ? 0 : (r.mode == RN_RES_SAME ? 1 : 2);
-  if (dtype == RN_F32) dispatch_bwd_apply_stream<float>(use_mask, add_kind, grid, as_stream(s), dout, x, mask_src, coef, dsum, r, dx, g, (int)M, H, W, C, rows, train, gscale, inv_count, key, thr);
-  else dispatch_bwd_apply_stream<bf16_t>(use_mask, add_kind, grid, as_stream(s), dout, x, mask_src, coef, dsum, r, dx, g, (int)M, H, W, C, rows, train, gscale, inv_count, key, thr);
+  RN_BY_DTYPE(dtype, dispatch_bwd_apply_stream<T_>(use_mask, add_kind, grid, as_stream(s), dout, x, mask_src, coef, dsum, r, dx, g, (int)M, H, W, C, rows, train, gscale, inv_count, key, thr));
   RN_CHECK_LAUNCH("bn_bwd_apply");
   return 0;
 }
@@ -528,10 +518,7 @@ extern "C" int rn_dropout_fwd(const void* x, void* out, int dtype, int64_t n, fl
   RN_CHECK_ARG(n % ce == 0, "rn_dropout_fwd: n must be a multiple of %d", ce);
   const long nchunks = n / ce;
   const uint32_t thr = rn_drop_threshold(p), key = rn_drop_key(site, step_seed);
-  if (dtype == RN_F32)
-    hipLaunchKernelGGL((dropout_fwd_kernel<float>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const float*)x, (float*)out, nchunks, 1.f / (1.f - p), key, thr);
-  else
-    hipLaunchKernelGGL((dropout_fwd_kernel<bf16_t>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const bf16_t*)x, (bf16_t*)out, nchunks, 1.f / (1.f - p), key, thr);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((dropout_fwd_kernel<T_>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const T_*)x, (T_*)out, nchunks, 1.f / (1.f - p), key, thr));
   RN_CHECK_LAUNCH("dropout_fwd");
   return 0;
 }
@@ -541,10 +528,7 @@ extern "C" int rn_dropout_bwd(const void* dout, const void* out, void* din, int 
   const int ce = dtype == RN_F32 ? 4 : 8;
   RN_CHECK_ARG(n % ce == 0, "rn_dropout_bwd: n must be a multiple of %d", ce);
   const long nchunks = n / ce;
-  if (dtype == RN_F32)
-    hipLaunchKernelGGL((dropout_bwd_kernel<float>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const float*)dout, (const float*)out, (float*)din, nchunks, 1.f / (1.f - p));
-  else
-    hipLaunchKernelGGL((dropout_bwd_kernel<bf16_t>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const bf16_t*)dout, (const bf16_t*)out, (bf16_t*)din, nchunks, 1.f / (1.f - p));
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((dropout_bwd_kernel<T_>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const T_*)dout, (const T_*)out, (T_*)din, nchunks, 1.f / (1.f - p)));
   RN_CHECK_LAUNCH("dropout_bwd");
   return 0;
 }
@@ -557,10 +541,7 @@ extern "C" int rn_add_res(void* dst, const void* res, int dtype, int N, int H, i
   make_res(r, res, res_mode, res_C, H, W, C);
   const int ce = dtype == RN_F32 ? 4 : 8;
   const long nchunks = M * (C / ce);
-  if (dtype == RN_F32)
-    hipLaunchKernelGGL((add_res_kernel<float>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (float*)dst, r, H, W, C, nchunks);
-  else
-    hipLaunchKernelGGL((add_res_kernel<bf16_t>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (bf16_t*)dst, r, H, W, C, nchunks);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((add_res_kernel<T_>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (T_*)dst, r, H, W, C, nchunks));
   RN_CHECK_LAUNCH("add_res");
   return 0;
 }

@@ -9,10 +9,17 @@
 typedef __bf16 bf16_t;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef _Float16 f16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
 void rn_set_error(const char* fmt, ...);
+// kernel log (rn_kernel_log / rn_conv_kernel_names): every convolution launcher reports the instantiation it picks; in a
+// dry run (rn_dry_run() true) it reports and returns without launching, so tests can ask which kernel a geometry selects
+void rn_note_kernel(const char* fmt, ...);
+bool rn_dry_run();
 
 #define RN_CHECK_ARG(cond, ...)              \
   do {                                       \
@@ -43,6 +50,24 @@ template <> struct Elem<bf16_t> {
   __device__ static inline float to_f(bf16_t v) { return (float)v; }
   __device__ static inline bf16_t from_f(float v) { return (bf16_t)v; }  // v_cvt_pk_bf16_f32: RNE, NaN-preserving
 };
+
+// fp16 storage (the reference's own GPU arithmetic: autocast + GradScaler, script.py:63, training.py:95-110): 11 significant bits
+// instead of bf16's 8, same MFMA rate; the narrow exponent is handled by dynamic loss scaling (rn_softmax_ce / rn_amp_*).
+// Conversions are v_cvt_f16_f32 (RNE); overflow becomes inf, which the unscale pass detects.
+template <> struct Elem<f16_t> {
+  static constexpr int CE = 8;
+  __device__ static inline float to_f(f16_t v) { return (float)v; }
+  __device__ static inline f16_t from_f(float v) { return (f16_t)v; }
+};
+
+#define RN_DTYPE_OK(d) ((d) == RN_F32 || (d) == RN_BF16 || (d) == RN_F16)
+// runs the statement(s) once with T_ bound to the element type of `dtype`
+#define RN_BY_DTYPE(dtype, ...)                                  \
+  do {                                                           \
+    if ((dtype) == RN_F32) { typedef float T_; __VA_ARGS__; }    \
+    else if ((dtype) == RN_BF16) { typedef bf16_t T_; __VA_ARGS__; } \
+    else { typedef f16_t T_; __VA_ARGS__; }                      \
+  } while (0)
 
 // a 16-byte chunk viewed as CE elements of T
 template <typename T> struct Chunk {

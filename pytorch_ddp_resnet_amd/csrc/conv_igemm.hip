@@ -19,10 +19,7 @@
 #include "common.h"
 #include <type_traits>
 
-int rn_conv3x3_patch(const void* src, const void* wt, void* dst, const ResDesc& res, int accum, int dtype, int N, int H, int W, int C, int K,
-                     bool flip, rn_stream s);
-
-int g_rn_variant = 0;   // tuning switch (tools/conv_bench.py): 1 LDS-patch 3x3 kernel (conv3x3.hip), 64 DMA source-window timing probe,
+int g_rn_variant = 0;   // tuning switch (tools/conv_bench.py): 64 DMA source-window timing probe,
                         // 128 force / 512 forbid the wave-specialised kernel, 8192.. epilogue timing probes (fill_ep)
 extern "C" void rn_set_variant(int v) { g_rn_variant = v; }
 static void* g_rn_stamps = nullptr;
@@ -97,6 +94,11 @@ template <> struct Mfma<float> {
 template <> struct Mfma<bf16_t> {
   __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<f16_t> {     // same cycles as the bf16 form (MI355X_MICROARCH.md, matrix cores)
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&a), *reinterpret_cast<const f16x8*>(&b), c, 0, 0, 0);
   }
 };
 
@@ -823,7 +825,10 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   // CU the homogeneous 4-wave DMA kernel at two workgroups per CU is faster (measured).  rn_set_variant: 128 forces the
   // wave-specialised kernel, 512 forbids it (A/B in tools/conv_bench.py).
   const bool one_per_cu = nmt * nnt <= 256;
-  if ((g_rn_variant & 128) || (one_per_cu && !(g_rn_variant & 512)))
+  const bool ws = (g_rn_variant & 128) || (one_per_cu && !(g_rn_variant & 512));
+  rn_note_kernel("igemm_%s<%dx%d>", ws ? "ws" : "dma", BM, BN);
+  if (rn_dry_run()) return 0;
+  if (ws)
     hipLaunchKernelGGL((igemm_ws_kernel<T, BM, BN, WM, WN, 8, 3>), dim3(nmt * nnt), dim3(512), 0, s, a);
   else
     hipLaunchKernelGGL((igemm_dma_kernel<T, BM, BN, WM, WN, 8, 2>), dim3(nmt * nnt), dim3(256), 0, s, a);
@@ -845,6 +850,8 @@ template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   // thin layers (K <= 32) on large maps: a tile's fixed cost (row setup, first stage, epilogue: ~8 us) dominates its two or
   // three K iterations, so 256-row tiles halve it per output row; still two workgroups per CU (74 KB of LDS each)
   if (!(g_rn_variant & 32) && (long)cdiv(a.M, 256) >= 512) {
+    rn_note_kernel("igemm_dma<256x32>");
+    if (rn_dry_run()) return 0;
     hipLaunchKernelGGL((igemm_dma_kernel<T, 256, 32, 4, 1, 8, 2>), dim3(cdiv(a.M, 256) * cdiv(K, 32)), dim3(256), 0, s, a);
     RN_CHECK_LAUNCH("igemm_thin");
     return 0;
@@ -854,7 +861,7 @@ template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
 
 int check_geom(const rn_conv_geom* g, int dtype, const char* who) {
   RN_CHECK_ARG(g != nullptr, "%s: null geometry", who);
-  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "%s: bad dtype %d", who, dtype);
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype), "%s: bad dtype %d", who, dtype);
   const int ce = dtype == RN_F32 ? 4 : 8;
   RN_CHECK_ARG(g->N > 0 && g->H > 0 && g->W > 0 && g->C > 0 && g->K > 0, "%s: non-positive shape", who);
   RN_CHECK_ARG(g->C % ce == 0 && g->K % ce == 0, "%s: C=%d and K=%d must be multiples of %d for this dtype", who, g->C, g->K, ce);
@@ -921,10 +928,6 @@ extern "C" int rn_conv_fwd(const void* x, const void* w_fwd, void* y, const void
   fill_res(a.res, res, res_mode, res_C, g->N, g->P, g->Q, g->K);
   RN_CONV_CHECK_EP
   fill_ep(a, ep, 0);
-  if ((g_rn_variant & 1) && !ep && g->R == 3 && g->S == 3 && g->stride == 1 && g->pad == 1) {      // LDS-resident patch kernel (opt-in) for CIFAR-sized maps
-    const int e = rn_conv3x3_patch(x, w_fwd, y, a.res, 0, dtype, g->N, g->H, g->W, g->C, g->K, false, s);
-    if (e >= 0) return e;
-  }
   a.N = g->N; a.Hs = g->H; a.Ws = g->W; a.Cs = g->C;
   a.Pc = g->P; a.Qc = g->Q; a.M = g->N * g->P * g->Q;
   a.Hd = g->P; a.Wd = g->Q; a.Kd = g->K;
@@ -941,7 +944,8 @@ extern "C" int rn_conv_fwd(const void* x, const void* w_fwd, void* y, const void
   a.nk = cdiv((long)a.nt * a.cpt, CPR);
   a.accum = 0;
   fill_magic(a);
-  return dtype == RN_F32 ? launch_igemm<float>(a, as_stream(s)) : launch_igemm<bf16_t>(a, as_stream(s));
+  RN_BY_DTYPE(dtype, return launch_igemm<T_>(a, as_stream(s)));
+  return 1;
 }
 
 extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* res, int res_mode, int res_C, int flags,
@@ -952,12 +956,6 @@ extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, cons
   const int ce = dtype == RN_F32 ? 4 : 8;
   RN_CHECK_ARG(!ep || (ep->partial && ep->bn_x && ep->bn_coef && !ep->bias), "rn_conv_dgrad: incomplete epilogue descriptor");
   int tile_base = 0;
-  if ((g_rn_variant & 1) && !ep && g->R == 3 && g->S == 3 && st == 1 && g->pad == 1) {
-    ResDesc rd;
-    fill_res(rd, res, res_mode, res_C, g->N, g->H, g->W, g->C);
-    const int e = rn_conv3x3_patch(dy, w_dgrad, dx, rd, (flags & RN_F_ACCUM) ? 1 : 0, dtype, g->N, g->H, g->W, g->K, g->C, true, s);
-    if (e >= 0) return e;
-  }
   // one launch per parity class (a, b) of the input grid: h = st*p' + a, w = st*q' + b
   for (int pa = 0; pa < st; ++pa)
     for (int pb = 0; pb < st; ++pb) {
@@ -992,7 +990,8 @@ extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, cons
       fill_magic(a);
       tile_base += cdiv(a.M, RN_CONV_STATS_ROWS);
       if (nt == 0 && a.accum && a.res.mode == RN_RES_NONE && !ep) continue;   // nothing to add to this class (a fused reduction still has to see it)
-      int e = dtype == RN_F32 ? launch_igemm<float>(a, as_stream(s)) : launch_igemm<bf16_t>(a, as_stream(s));
+      int e = 0;
+      RN_BY_DTYPE(dtype, e = launch_igemm<T_>(a, as_stream(s)));
       if (e) return e;
     }
   return 0;

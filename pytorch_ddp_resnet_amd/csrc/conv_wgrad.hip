@@ -33,32 +33,49 @@ struct WgradArgs {
   int dh[MAX_TAPS], dw[MAX_TAPS];
 };
 
-template <typename T, int TI, int TJ> struct WTile;  // per-wave MFMA work on one 32-pixel tile
+// 16-bit element types: the transposed LDS read and the MFMA of each
+template <typename T> struct H16;
+template <> struct H16<bf16_t> {
+  typedef bf16x8 v8; typedef bf16x4 v4;
+  __device__ static inline v4 tr(const char* p) { typedef __attribute__((address_space(3))) bf16x4* lp; return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(p)); }
+  __device__ static inline f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct H16<f16_t> {
+  typedef f16x8 v8; typedef f16x4 v4;
+  __device__ static inline v4 tr(const char* p) {          // the builtin is declared on __fp16 vectors: same bits as _Float16
+    typedef __fp16 h4 __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) h4* lp;
+    const h4 r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(p));
+    return __builtin_bit_cast(v4, r);
+  }
+  __device__ static inline f32x4 mfma(v8 a, v8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+};
 
-// bf16: A fragment of a 16-channel group = 8 pixels per lane via two transposed 4x16 block reads
-template <int TI, int TJ> struct WTile<bf16_t, TI, TJ> {
-  __device__ static inline bf16x8 frag(const char* tile, int rowb, int ch0, int lane) {
+// bf16 / fp16: A fragment of a 16-channel group = 8 pixels per lane via two transposed 4x16 block reads
+template <typename T, int TI, int TJ> struct WTile {
+  typedef typename H16<T>::v8 v8;
+  typedef typename H16<T>::v4 v4;
+  __device__ static inline v8 frag(const char* tile, int rowb, int ch0, int lane) {
     // One transposed read serves, per 32-lane half, pixels {a..a+3} and {a+8..a+11}; 8 row strides are a multiple of 64 banks
     // for every 32-byte-aligned stride, so those two pixel groups would hit the same banks (measured: a third of all LDS
     // cycles were conflict cycles).  The 32-byte channel octets of a row are therefore swapped pairwise in rows whose pixel
     // index has bit 3 set (store_tile writes them that way): the two groups land on octets of different parity.
     const int g = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
     const char* a0 = tile + (size_t)(8 * g + q) * rowb + ((ch0 ^ ((g & 1) << 4)) + 4 * p) * 2;
-    typedef __attribute__((address_space(3))) bf16x4* lp;
-    bf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(a0));
-    bf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lp)(a0 + 4 * rowb));
-    bf16x8 r;
+    v4 lo = H16<T>::tr(a0);
+    v4 hi = H16<T>::tr(a0 + 4 * rowb);
+    v8 r;
     r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
     r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
     return r;
   }
   __device__ static inline void run(const char* ta, int rowa, int cha, const char* tb, int rowbb, int chb, int lane, f32x4 (&acc)[TI][TJ]) {
-    bf16x8 fa[2][TI], fb[2][TJ];
+    v8 fa[2][TI], fb[2][TJ];
 #pragma unroll
     for (int i = 0; i < TI; ++i) fa[0][i] = frag(ta, rowa, cha + 16 * i, lane);
 #pragma unroll
     for (int j = 0; j < TJ; ++j) fb[0][j] = frag(tb, rowbb, chb + 16 * j, lane);
-    constexpr int NS = Bp<bf16_t>::v / 32;
+    constexpr int NS = Bp<T>::v / 32;
 #pragma unroll
     for (int s = 0; s < NS; ++s) {
       const int cur = s & 1, nxt = cur ^ 1;
@@ -72,7 +89,7 @@ template <int TI, int TJ> struct WTile<bf16_t, TI, TJ> {
 #pragma unroll
       for (int i = 0; i < TI; ++i)
 #pragma unroll
-        for (int j = 0; j < TJ; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[cur][i], fb[cur][j], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < TJ; ++j) acc[i][j] = H16<T>::mfma(fa[cur][i], fb[cur][j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -355,6 +372,8 @@ int wgrad_splits(const rn_conv_geom* g, int bk, int bc, bool im2col = false) {
 template <typename T, int TI, int TJ, bool IC = false>
 int launch_w(const WgradArgs& a, hipStream_t s) {
   int grid = a.kt * a.ct * a.nt * a.splits;
+  rn_note_kernel("wgrad%s<%dx%d>", IC ? "_im2col" : "", 2 * TI * 16, 2 * TJ * 16);
+  if (rn_dry_run()) return 0;
   hipLaunchKernelGGL((wgrad_kernel<T, TI, TJ, IC>), dim3(grid), dim3(256), 0, s, a);
   RN_CHECK_LAUNCH("wgrad");
   return 0;
@@ -394,7 +413,7 @@ extern "C" size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g) {
 extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void* ws, size_t ws_bytes, int flags, int dtype,
                              const rn_conv_geom* g, rn_stream s) {
   RN_CHECK_ARG(g && x && dy && dw_krsc, "rn_conv_wgrad: null pointer");
-  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "rn_conv_wgrad: bad dtype");
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype), "rn_conv_wgrad: bad dtype");
   const int ce = dtype == RN_F32 ? 4 : 8;
   RN_CHECK_ARG(g->C % ce == 0 && g->K % ce == 0, "rn_conv_wgrad: C=%d, K=%d must be multiples of %d", g->C, g->K, ce);
   RN_CHECK_ARG(g->R == g->S && g->R * g->S <= MAX_TAPS, "rn_conv_wgrad: kernel %dx%d unsupported", g->R, g->S);
@@ -425,10 +444,13 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
                  ws_bytes, (size_t)a.splits * n * sizeof(float));
   }
   a.out = direct ? dw_krsc : reinterpret_cast<float*>(ws);
-  int e = dtype == RN_F32 ? dispatch_w<float>(a, bk, bc, as_stream(s)) : dispatch_w<bf16_t>(a, bk, bc, as_stream(s));
+  int e = 0;
+  RN_BY_DTYPE(dtype, e = dispatch_w<T_>(a, bk, bc, as_stream(s)));
   if (e) return e;
   if (!direct) {
     const long n4 = (long)(n / 4);
+    rn_note_kernel((a.splits >= 32 && n4 < 65536) ? "wgrad_reduce_wide" : "wgrad_reduce");
+    if (rn_dry_run()) return 0;
     if (a.splits >= 32 && n4 < 65536) {                  // few outputs, many slabs: split the slab walk over 16 threads
       int blocks = (int)((n4 + 15) / 16);
       if (blocks > 4096) blocks = 4096;

@@ -37,8 +37,9 @@ __device__ inline void pack_tile(const float* __restrict__ w, T* __restrict__ wf
         v = *reinterpret_cast<const float4*>(w + off);
         if (wf) {                                  // forward copy from the same read
           if constexpr (CE == 8) {
-            bf16x4 o = {(bf16_t)v.x, (bf16_t)v.y, (bf16_t)v.z, (bf16_t)v.w};
-            *reinterpret_cast<bf16x4*>(wf + off) = o;
+            typedef T t4 __attribute__((ext_vector_type(4)));
+            t4 o = {(T)v.x, (T)v.y, (T)v.z, (T)v.w};
+            *reinterpret_cast<t4*>(wf + off) = o;
           } else {
             *reinterpret_cast<float4*>(wf + off) = v;
           }
@@ -318,8 +319,9 @@ __global__ __launch_bounds__(NT) void fc_dgrad_kernel(const float* __restrict__ 
 // rank rule for ties (torch.topk leaves it implementation-defined): an entry outranks the label iff it is strictly
 // greater, or equal with a lower index.
 __global__ __launch_bounds__(NT) void softmax_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, float* __restrict__ out3,
-                                                        float* __restrict__ dlogits, int N, int O, float scale) {
+                                                        float* __restrict__ dlogits, int N, int O, float scale, const float* __restrict__ scale_dev) {
   __shared__ float red[3][NT];
+  if (scale_dev) scale *= scale_dev[0];          // loss scale (AMP) / upstream gradient of the loss, a device scalar: no host sync
   float nll = 0.f, e1 = 0.f, e5 = 0.f;
   for (int n = threadIdx.x; n < N; n += NT) {
     const float* row = logits + (size_t)n * O;
@@ -350,7 +352,12 @@ __global__ __launch_bounds__(NT) void softmax_ce_kernel(const float* __restrict_
 }
 
 __global__ __launch_bounds__(NT) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n, float lr, float momentum,
-                                                 float dampening, float wd, int nesterov, int first, float gscale) {
+                                                 float dampening, float wd, int nesterov, int first, float gscale, const float* __restrict__ loss_scale_dev,
+                                                 const float* __restrict__ found_inf_dev) {
+  // AMP (training.py:104-110 scaler.step): gradients carry the loss scale, a device scalar; a step with non-finite gradients
+  // is skipped entirely (parameters and momentum untouched) -- decided on the device, no host sync
+  if (found_inf_dev && found_inf_dev[0] != 0.f) return;
+  if (loss_scale_dev) gscale /= loss_scale_dev[0];
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
     float d = g[i] * gscale + wd * p[i];
     if (momentum != 0.f) {
@@ -373,18 +380,16 @@ inline int ew_grid(long n) {
 
 extern "C" int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, int dtype, int K, int RS, int C, rn_stream s) {
   RN_CHECK_ARG(w_krsc && (w_fwd || w_dgrad) && K > 0 && RS > 0 && C > 0, "rn_pack_weights: bad argument");
-  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "rn_pack_weights: bad dtype");
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype), "rn_pack_weights: bad dtype");
   RN_CHECK_ARG(!w_dgrad || (C % (dtype == RN_F32 ? 4 : 8) == 0 && K % (dtype == RN_F32 ? 4 : 8) == 0), "rn_pack_weights: C=%d and K=%d must be multiples of %d for this dtype", C, K, dtype == RN_F32 ? 4 : 8);
   const long n = (long)K * RS * C;
   if (w_fwd && !w_dgrad) {
-    if (dtype == RN_F32) hipLaunchKernelGGL((pack_w_fwd_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), w_krsc, (float*)w_fwd, n);
-    else hipLaunchKernelGGL((pack_w_fwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), w_krsc, (bf16_t*)w_fwd, n);
+    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((pack_w_fwd_kernel<T_>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), w_krsc, (T_*)w_fwd, n));
     RN_CHECK_LAUNCH("pack_weights_fwd");
   }
   if (w_dgrad) {
     const int grid = cdiv(K, 64) * cdiv(C, 64) * RS;
-    if (dtype == RN_F32) hipLaunchKernelGGL((pack_w_dgrad_kernel<float>), dim3(grid), dim3(256), 0, as_stream(s), w_krsc, (float*)w_fwd, (float*)w_dgrad, K, RS, C);
-    else hipLaunchKernelGGL((pack_w_dgrad_kernel<bf16_t>), dim3(grid), dim3(256), 0, as_stream(s), w_krsc, (bf16_t*)w_fwd, (bf16_t*)w_dgrad, K, RS, C);
+    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((pack_w_dgrad_kernel<T_>), dim3(grid), dim3(256), 0, as_stream(s), w_krsc, (T_*)w_fwd, (T_*)w_dgrad, K, RS, C));
   }
   RN_CHECK_LAUNCH("pack_weights");
   return 0;
@@ -392,7 +397,7 @@ extern "C" int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, 
 
 extern "C" int rn_pack_weights_batch(const rn_pack_desc* descs, int n, int dtype, rn_stream s) {
   RN_CHECK_ARG(descs && n > 0 && n <= RN_PACK_BATCH_MAX, "rn_pack_weights_batch: n=%d out of range (1..%d)", n, RN_PACK_BATCH_MAX);
-  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "rn_pack_weights_batch: bad dtype");
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype), "rn_pack_weights_batch: bad dtype");
   const int ce = dtype == RN_F32 ? 4 : 8;
   PackBatch pb;
   pb.n = n;
@@ -406,27 +411,24 @@ extern "C" int rn_pack_weights_batch(const rn_pack_desc* descs, int n, int dtype
     blocks += cdiv(d.K, 64) * cdiv(d.C, 64) * d.RS;
   }
   pb.first_block[n] = blocks;
-  if (dtype == RN_F32) hipLaunchKernelGGL((pack_w_batch_kernel<float>), dim3(blocks), dim3(256), 0, as_stream(s), pb);
-  else hipLaunchKernelGGL((pack_w_batch_kernel<bf16_t>), dim3(blocks), dim3(256), 0, as_stream(s), pb);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((pack_w_batch_kernel<T_>), dim3(blocks), dim3(256), 0, as_stream(s), pb));
   RN_CHECK_LAUNCH("pack_weights_batch");
   return 0;
 }
 
 extern "C" int rn_img_to_nhwc(const float* x_nchw, void* out, int dtype, int N, int C, int H, int W, int CP, rn_stream s) {
-  RN_CHECK_ARG(x_nchw && out && N > 0 && C > 0 && C <= CP && (dtype == RN_F32 || dtype == RN_BF16) && CP == (dtype == RN_F32 ? 4 : 8),
+  RN_CHECK_ARG(x_nchw && out && N > 0 && C > 0 && C <= CP && RN_DTYPE_OK(dtype) && CP == (dtype == RN_F32 ? 4 : 8),
                "rn_img_to_nhwc: bad argument (C=%d CP=%d)", C, CP);
   const long n = (long)N * H * W;
-  if (dtype == RN_F32) hipLaunchKernelGGL((img_to_nhwc_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), x_nchw, (float*)out, N, C, H, W, CP);
-  else hipLaunchKernelGGL((img_to_nhwc_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), x_nchw, (bf16_t*)out, N, C, H, W, CP);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((img_to_nhwc_kernel<T_>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), x_nchw, (T_*)out, N, C, H, W, CP));
   RN_CHECK_LAUNCH("img_to_nhwc");
   return 0;
 }
 
 extern "C" int rn_pack_stem_w(const float* w_krsc, void* w_padded, int dtype, int K, int RS, int C, int CP, rn_stream s) {
-  RN_CHECK_ARG(w_krsc && w_padded && K > 0 && RS > 0 && C > 0 && C <= CP && (dtype == RN_F32 || dtype == RN_BF16), "rn_pack_stem_w: bad argument");
+  RN_CHECK_ARG(w_krsc && w_padded && K > 0 && RS > 0 && C > 0 && C <= CP && RN_DTYPE_OK(dtype), "rn_pack_stem_w: bad argument");
   const long rows = (long)K * RS;
-  if (dtype == RN_F32) hipLaunchKernelGGL((pack_stem_w_kernel<float>), dim3(ew_grid(rows * CP)), dim3(NT), 0, as_stream(s), w_krsc, (float*)w_padded, rows, C, CP);
-  else hipLaunchKernelGGL((pack_stem_w_kernel<bf16_t>), dim3(ew_grid(rows * CP)), dim3(NT), 0, as_stream(s), w_krsc, (bf16_t*)w_padded, rows, C, CP);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((pack_stem_w_kernel<T_>), dim3(ew_grid(rows * CP)), dim3(NT), 0, as_stream(s), w_krsc, (T_*)w_padded, rows, C, CP));
   RN_CHECK_LAUNCH("pack_stem_w");
   return 0;
 }
@@ -440,7 +442,7 @@ extern "C" int rn_unpack_stem_dw(const float* dw_padded, float* dw_krsc, int K, 
 }
 
 static int check_pool(int dtype, int N, int H, int W, int C, int k, int stride, int pad, const char* who) {
-  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "%s: bad dtype", who);
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype), "%s: bad dtype", who);
   RN_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % (dtype == RN_F32 ? 4 : 8) == 0 && k > 0 && stride > 0 && pad >= 0 && 2 * pad <= k,
                "%s: bad shape", who);
   return 0;
@@ -451,8 +453,7 @@ extern "C" int rn_maxpool_fwd(const void* x, void* y, unsigned char* argmax, int
   RN_CHECK_ARG(x && y && k * k < 255, "rn_maxpool_fwd: bad argument");
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
   const long n = (long)N * P * Q * (C / (dtype == RN_F32 ? 4 : 8));
-  if (dtype == RN_F32) hipLaunchKernelGGL((maxpool_fwd_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const float*)x, (float*)y, argmax, N, H, W, C, P, Q, k, stride, pad);
-  else hipLaunchKernelGGL((maxpool_fwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const bf16_t*)x, (bf16_t*)y, argmax, N, H, W, C, P, Q, k, stride, pad);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((maxpool_fwd_kernel<T_>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const T_*)x, (T_*)y, argmax, N, H, W, C, P, Q, k, stride, pad));
   RN_CHECK_LAUNCH("maxpool_fwd");
   return 0;
 }
@@ -462,17 +463,15 @@ extern "C" int rn_maxpool_bwd(const void* dy, const unsigned char* argmax, void*
   RN_CHECK_ARG(dy && argmax && dx, "rn_maxpool_bwd: null pointer");
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
   const int rows_grid = (int)std::min<long>((long)N * H, 8192);
-  if (dtype == RN_F32) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(rows_grid), dim3(NT), 0, as_stream(s), (const float*)dy, argmax, (float*)dx, N, H, W, C, P, Q, k, stride, pad);
-  else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(rows_grid), dim3(NT), 0, as_stream(s), (const bf16_t*)dy, argmax, (bf16_t*)dx, N, H, W, C, P, Q, k, stride, pad);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T_>), dim3(rows_grid), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (T_*)dx, N, H, W, C, P, Q, k, stride, pad));
   RN_CHECK_LAUNCH("maxpool_bwd");
   return 0;
 }
 
 extern "C" int rn_pool_fc_fwd(const void* x, const float* w, const float* b, float* feat, float* logits, int dtype, int N, int HW, int C, int O, rn_stream s) {
   RN_CHECK_ARG(x && w && b && feat && logits && N > 0 && HW > 0 && O > 0, "rn_pool_fc_fwd: bad argument");
-  RN_CHECK_ARG((dtype == RN_F32 || dtype == RN_BF16) && C % (dtype == RN_F32 ? 4 : 8) == 0, "rn_pool_fc_fwd: bad dtype / C=%d", C);
-  if (dtype == RN_F32) hipLaunchKernelGGL((gap_kernel<float>), dim3(N), dim3(NT), 0, as_stream(s), (const float*)x, feat, HW, C);
-  else hipLaunchKernelGGL((gap_kernel<bf16_t>), dim3(N), dim3(NT), 0, as_stream(s), (const bf16_t*)x, feat, HW, C);
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype) && C % (dtype == RN_F32 ? 4 : 8) == 0, "rn_pool_fc_fwd: bad dtype / C=%d", C);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((gap_kernel<T_>), dim3(N), dim3(NT), 0, as_stream(s), (const T_*)x, feat, HW, C));
   RN_CHECK_LAUNCH("gap");
   hipLaunchKernelGGL(fc_fwd_kernel, dim3(cdiv((long)N * O * 64, NT)), dim3(NT), 0, as_stream(s), feat, w, b, logits, N, C, O);
   RN_CHECK_LAUNCH("fc_fwd");
@@ -482,21 +481,21 @@ extern "C" int rn_pool_fc_fwd(const void* x, const float* w, const float* b, flo
 extern "C" int rn_pool_fc_bwd(const float* dlogits, const float* feat, const float* w, void* dx, float* dw, float* db, int dtype, int N, int HW, int C,
                               int O, int flags, rn_stream s) {
   RN_CHECK_ARG(dlogits && feat && w && dw && db && N > 0 && HW > 0 && O > 0, "rn_pool_fc_bwd: bad argument");
-  RN_CHECK_ARG((dtype == RN_F32 || dtype == RN_BF16) && C % (dtype == RN_F32 ? 4 : 8) == 0, "rn_pool_fc_bwd: bad dtype / C=%d", C);
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype) && C % (dtype == RN_F32 ? 4 : 8) == 0, "rn_pool_fc_bwd: bad dtype / C=%d", C);
   hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv((long)O * C, NT)), dim3(NT), 0, as_stream(s), dlogits, feat, dw, db, N, C, O, (flags & RN_F_ACCUM) ? 1 : 0);
   RN_CHECK_LAUNCH("fc_wgrad");
   if (!(flags & RN_F_NO_DX)) {
     RN_CHECK_ARG(dx != nullptr, "rn_pool_fc_bwd: dx is null");
-    if (dtype == RN_F32) hipLaunchKernelGGL((fc_dgrad_kernel<float>), dim3(N), dim3(NT), 0, as_stream(s), dlogits, w, (float*)dx, HW, C, O);
-    else hipLaunchKernelGGL((fc_dgrad_kernel<bf16_t>), dim3(N), dim3(NT), 0, as_stream(s), dlogits, w, (bf16_t*)dx, HW, C, O);
+    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((fc_dgrad_kernel<T_>), dim3(N), dim3(NT), 0, as_stream(s), dlogits, w, (T_*)dx, HW, C, O));
     RN_CHECK_LAUNCH("fc_dgrad");
   }
   return 0;
 }
 
-extern "C" int rn_softmax_ce(const float* logits, const int64_t* labels, float* out3, float* dlogits, int N, int O, float scale, rn_stream s) {
+extern "C" int rn_softmax_ce(const float* logits, const int64_t* labels, float* out3, float* dlogits, int N, int O, float scale, const float* scale_dev,
+                             rn_stream s) {
   RN_CHECK_ARG(logits && labels && out3 && N > 0 && O > 0, "rn_softmax_ce: bad argument");
-  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(NT), 0, as_stream(s), logits, (const long long*)labels, out3, dlogits, N, O, scale);
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(NT), 0, as_stream(s), logits, (const long long*)labels, out3, dlogits, N, O, scale, scale_dev);
   RN_CHECK_LAUNCH("softmax_ce");
   return 0;
 }
@@ -505,7 +504,16 @@ extern "C" int rn_sgd_step(float* param, const float* grad, float* momentum_buf,
                            float weight_decay, int nesterov, int first_step, float grad_scale, rn_stream s) {
   RN_CHECK_ARG(param && grad && n > 0 && (momentum == 0.f || momentum_buf), "rn_sgd_step: bad argument");
   hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), param, grad, momentum_buf, (long)n, lr, momentum, dampening, weight_decay,
-                     nesterov, first_step, grad_scale);
+                     nesterov, first_step, grad_scale, (const float*)nullptr, (const float*)nullptr);
   RN_CHECK_LAUNCH("sgd");
+  return 0;
+}
+
+extern "C" int rn_sgd_step_amp(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,
+                               float weight_decay, int nesterov, int first_step, const float* loss_scale_dev, const float* found_inf_dev, rn_stream s) {
+  RN_CHECK_ARG(param && grad && n > 0 && (momentum == 0.f || momentum_buf), "rn_sgd_step_amp: bad argument");
+  hipLaunchKernelGGL(sgd_kernel, dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), param, grad, momentum_buf, (long)n, lr, momentum, dampening, weight_decay,
+                     nesterov, first_step, 1.f, loss_scale_dev, found_inf_dev);
+  RN_CHECK_LAUNCH("sgd_amp");
   return 0;
 }

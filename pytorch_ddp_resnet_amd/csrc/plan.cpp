@@ -23,6 +23,41 @@ void rn_set_error(const char* fmt, ...) {
 }
 
 extern "C" const char* rn_last_error(void) { return g_err; }
+
+// ---- kernel log: names of the convolution kernels picked since rn_kernel_log(1) (tests assert which tile ran) ----
+static thread_local bool g_log_on = false, g_dry = false;
+static thread_local std::string g_log;
+void rn_note_kernel(const char* fmt, ...) {
+  if (!g_log_on) return;
+  char b[96];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(b, sizeof(b), fmt, ap);
+  va_end(ap);
+  if (!g_log.empty()) g_log += ',';
+  g_log += b;
+}
+bool rn_dry_run() { return g_dry; }
+extern "C" void rn_kernel_log(int enable) { g_log_on = enable != 0; g_log.clear(); }
+extern "C" const char* rn_kernel_log_read(void) { return g_log.c_str(); }
+extern "C" int rn_conv_kernel_names(int pass, int dtype, const rn_conv_geom* g, int fused_epilogue, char* out, size_t n) {
+  RN_CHECK_ARG(g && out && n > 0 && pass >= 0 && pass <= 2, "rn_conv_kernel_names: bad argument");
+  const bool was_on = g_log_on;
+  const std::string keep = g_log;
+  g_log_on = true; g_dry = true; g_log.clear();
+  static float dummy[8];
+  void* p = dummy;                              // never dereferenced: the launchers return before launching
+  rn_conv_epilogue ep{(float*)p, nullptr, nullptr, nullptr, 1.f, nullptr};
+  int e;
+  if (pass == 0) e = rn_conv_fwd(p, p, p, nullptr, RN_RES_NONE, 0, dtype, g, fused_epilogue ? &ep : nullptr, nullptr);
+  else if (pass == 1) {
+    ep.bn_x = p; ep.bn_coef = (const float*)p;
+    e = rn_conv_dgrad(p, p, p, nullptr, RN_RES_NONE, 0, 0, dtype, g, fused_epilogue ? &ep : nullptr, nullptr);
+  } else e = rn_conv_wgrad(p, p, (float*)p, p, (size_t)-1, 0, dtype, g, nullptr);
+  snprintf(out, n, "%s", g_log.c_str());
+  g_dry = false; g_log_on = was_on; g_log = keep;
+  return e;
+}
 extern "C" int rn_version(void) { return 1; }
 
 struct rn_plan {
@@ -50,7 +85,7 @@ struct rn_plan {
 
 extern "C" int rn_plan_create(const rn_op* ops, int n_ops, int n_bufs, int dtype, rn_plan** out) {
   RN_CHECK_ARG(ops && out && n_ops > 0 && n_bufs > 0, "rn_plan_create: bad argument");
-  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "rn_plan_create: bad dtype %d", dtype);
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype), "rn_plan_create: bad dtype %d", dtype);
   for (int i = 0; i < n_ops; ++i) {
     RN_CHECK_ARG(ops[i].kind >= RN_OP_STEM_FWD && ops[i].kind <= RN_OP_UNPACK_STEM_DW, "rn_plan_create: op %d has unknown kind %d", i, ops[i].kind);
     for (int j = 0; j < RN_OP_NBUF; ++j)
@@ -213,7 +248,7 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
     case RN_OP_DROPOUT_BWD:
       return rn_dropout_bwd(B(0), B(1), B(2), dt, ((int64_t)d[1] << 31) | (int64_t)d[0], o.fp[0], s);
     case RN_OP_SOFTMAX_CE:
-      return rn_softmax_ce((const float*)B(0), (const int64_t*)B(1), (float*)B(2), (float*)B(3), d[0], d[1], o.fp[0], s);
+      return rn_softmax_ce((const float*)B(0), (const int64_t*)B(1), (float*)B(2), (float*)B(3), d[0], d[1], o.fp[0], (const float*)B(4), s);
     case RN_OP_ZERO: {
       size_t bytes = ((size_t)(uint32_t)d[1] << 31) | (size_t)(uint32_t)d[0];
       hipError_t e = hipMemsetAsync(B(0), 0, bytes, as_stream(s));

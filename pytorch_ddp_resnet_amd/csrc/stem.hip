@@ -197,7 +197,7 @@ inline int stem_wgrad_kt(const rn_conv_geom* g) {
 
 int check_stem(const rn_conv_geom* g, int dtype, const char* who) {
   RN_CHECK_ARG(g != nullptr, "%s: null geometry", who);
-  RN_CHECK_ARG(dtype == RN_F32 || dtype == RN_BF16, "%s: bad dtype", who);
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype), "%s: bad dtype", who);
   RN_CHECK_ARG(g->C > 0 && g->C <= 4 && g->S * g->C <= 24, "%s: stem path needs C_in <= 4 and S*C <= %d (got C=%d S=%d)", who, 24, g->C, g->S);
   RN_CHECK_ARG(g->K % 8 == 0, "%s: K=%d must be a multiple of 8", who, g->K);
   RN_CHECK_ARG(g->P == (g->H + 2 * g->pad - g->R) / g->stride + 1 && g->Q == (g->W + 2 * g->pad - g->S) / g->stride + 1, "%s: inconsistent output size", who);
@@ -225,8 +225,7 @@ extern "C" int rn_stem_conv_fwd(const float* x_nchw, const float* w_krsc, const 
   if (gx > 8192) gx = 8192;
   const size_t smem = (size_t)g->R * g->S * g->C * a.KT * sizeof(float);
   dim3 grid(gx, cdiv(g->K, a.KT));
-  if (dtype == RN_F32) hipLaunchKernelGGL((stem_fwd_kernel<float>), grid, dim3(NT), smem, as_stream(s), a);
-  else hipLaunchKernelGGL((stem_fwd_kernel<bf16_t>), grid, dim3(NT), smem, as_stream(s), a);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((stem_fwd_kernel<T_>), grid, dim3(NT), smem, as_stream(s), a));
   RN_CHECK_LAUNCH("stem_fwd");
   return 0;
 }
@@ -249,8 +248,7 @@ extern "C" int rn_stem_conv_wgrad(const float* x_nchw, const void* dy, int dtype
   const int nblk = stem_wgrad_blocks(g);
   dim3 grid(nblk, cdiv(g->K, a.KT));
   const size_t smem = (size_t)WPIX * (((ncol + 3) / 4 * 4) + a.KT) * sizeof(float);
-  if (dtype == RN_F32) hipLaunchKernelGGL((stem_wgrad_kernel<float>), grid, dim3(NT), smem, as_stream(s), a);
-  else hipLaunchKernelGGL((stem_wgrad_kernel<bf16_t>), grid, dim3(NT), smem, as_stream(s), a);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((stem_wgrad_kernel<T_>), grid, dim3(NT), smem, as_stream(s), a));
   RN_CHECK_LAUNCH("stem_wgrad");
   const int n = g->K * (g->R * g->S * g->C + 1);
   hipLaunchKernelGGL(stem_wgrad_reduce_kernel, dim3(cdiv(n, 16)), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), nblk, dw_krsc, dbias,

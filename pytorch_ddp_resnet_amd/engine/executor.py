@@ -36,7 +36,7 @@ class Engine:
         self.L = _lib.lib()
         self.plan, self.device = plan, device
         self.T = compute_dtype
-        self.rn_dtype = ir.RN_F32 if compute_dtype == torch.float32 else ir.RN_BF16
+        self.rn_dtype = {torch.float32: ir.RN_F32, torch.bfloat16: ir.RN_BF16, torch.float16: ir.RN_F16}[compute_dtype]
         assert plan.meta['fp32'] == (compute_dtype == torch.float32)
         self.generation = 0
         # ---- flat gradient buffer, laid out in the order the backward produces the gradients ----
@@ -98,6 +98,13 @@ class Engine:
         _lib.check(self.L.rn_plan_set_overlap(self._h, 0 if os.environ.get('RN_NO_OVERLAP', '0') == '1' else 1))
         self._graphs = {}
         self._profiling = False
+        self._loss_scratch = None
+
+    def loss_scratch(self, i):
+        """two 4-float device scratch rows for the fused loss kernel (forward sums / backward by-product)."""
+        if self._loss_scratch is None:
+            self._loss_scratch = torch.zeros(2, 4, dtype=torch.float32, device=self.device)
+        return self._loss_scratch[i]
 
     def __del__(self):
         try:

@@ -8,7 +8,7 @@ plan's slot table, ``dim``/``fp`` are per-kind scalars, documented in OP_FIELDS 
 from dataclasses import dataclass, field
 from typing import List, Optional, Tuple
 
-RN_F32, RN_BF16 = 0, 1
+RN_F32, RN_BF16, RN_F16 = 0, 1, 2
 
 RES_NONE, RES_SAME, RES_DOWN2PAD, RES_UP2 = 0, 1, 2, 3
 
@@ -44,7 +44,7 @@ OP_FIELDS = {
     OP_CONV_WGRAD:      ('x dy dw ws', 'geom', ''),
     OP_STEM_WGRAD:      ('x dy dw db ws', 'geom', ''),
     OP_DROPOUT_BWD:     ('dout out din', 'n_lo n_hi', 'p'),
-    OP_SOFTMAX_CE:      ('logits labels out3 dlogits', 'N O', 'scale'),
+    OP_SOFTMAX_CE:      ('logits labels out3 dlogits gscale', 'N O', 'scale'),
     OP_ZERO:            ('dst', 'bytes_lo bytes_hi', ''),
     OP_ADD_RES:         ('dst res', 'N H W C res_mode res_C', ''),
     OP_IMG_TO_NHWC:     ('x out', 'N C H W CP', ''),

@@ -73,15 +73,21 @@ def setup(rank, config):
     steps = config.get('num_microbatches') * 4
     dl_train = SyntheticLoader(local_batch, hw, classes, steps, device, 1234 + rank)
     dl_test = SyntheticLoader(local_batch, hw, classes, 2, device, 4321 + rank)
+    # the reference turns AMP (fp16 autocast + GradScaler) on whenever a GPU is present (script.py:63, training.py:95-110): the
+    # engine's counterpart is fp16 storage / f16 MFMA with fp32 accumulation, statistics and master weights, under the same
+    # GradScaler.  `compute_dtype: fp32 | bf16 | fp16` in the YAML overrides it (neither fp32 nor bf16 needs a scaler).
+    compute_dtype = dict(config).get('compute_dtype', 'fp16')
+    scaler = torch.amp.GradScaler('cuda') if (on_gpu and compute_dtype == 'fp16') else None
     classifier = ResNet(architecture_spec=config.get('architecture_spec'), preact=config.get('preact'), use_proj=config.get('use_proj'),
-                        dropout_prob=config.get('dropout_prob'), sync_bn=bool(dict(config).get('sync_bn', False))).to(device)
+                        dropout_prob=config.get('dropout_prob'), sync_bn=bool(dict(config).get('sync_bn', False)),
+                        compute_dtype=compute_dtype).to(device)
     if world > 1:
         broadcast_parameters(classifier)                       # ranks draw different initial weights (no seeding): rank 0 defines the model
     reducer = GradReducer(classifier, world) if world > 1 else None
     optimizer = get_optimizer(config.get('optimizer_cls_name'), classifier, config.get('optimizer_args'))
     scheduler = get_scheduler(config.get('scheduler_cls_name'), optimizer, config.get('scheduler_args'))
     return dict(device=device, dl_train=dl_train, dl_test=dl_test, classifier=classifier, optimizer=optimizer, scheduler=scheduler,
-                reducer=reducer, global_step=0)
+                reducer=reducer, global_step=0, scaler=scaler)
 
 
 def train(rank, config):

@@ -45,7 +45,7 @@ def test_constants_match_header():
         assert header_enum('RN_' + k) == getattr(ir, k)
     for k in ('F_RELU', 'F_TRAIN', 'F_ACCUM', 'F_WRITE_G', 'F_NEED_DGRAD_PACK', 'F_SKIP_FWD_PACK', 'F_NO_DX'):
         assert header_enum('RN_' + k) == getattr(ir, k)
-    assert header_enum('RN_F32') == ir.RN_F32 and header_enum('RN_BF16') == ir.RN_BF16
+    assert header_enum('RN_F32') == ir.RN_F32 and header_enum('RN_BF16') == ir.RN_BF16 and header_enum('RN_F16') == ir.RN_F16
     assert int(re.search(r'#define RN_OP_NBUF (\d+)', HEADER).group(1)) == ir.OP_NBUF
     assert int(re.search(r'#define RN_OP_NDIM (\d+)', HEADER).group(1)) == ir.OP_NDIM
 

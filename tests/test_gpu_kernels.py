@@ -86,46 +86,6 @@ def test_conv_epilogue_residual_and_accum(mode, fp32):
     assert h.max_rel(hip['dx'], ref['dx']) < TOL[fp32]
 
 
-PATCH_GEOMS = [
-    # N, H, W, C, K   (3x3 s1 p1): every tile geometry of the LDS-resident patch kernel
-    (64, 32, 32, 32, 160),     # BM=256, W=32 (8-row tiles)
-    (128, 16, 16, 32, 320),    # BM=256, W=16 (whole image per tile), two column tiles
-    (256, 8, 8, 32, 640),      # BM=256, W=8 (4 images per tile)
-    (2, 32, 32, 64, 64),       # BM=128, W=32 (4-row tiles), BN=64
-    (2, 16, 16, 32, 128),      # BM=128, W=16, BN=128
-    (4, 8, 8, 64, 32),         # BM=128, W=8 (2 images per tile), BN=32
-]
-
-
-@pytest.mark.parametrize('fp32', DT)
-@pytest.mark.parametrize('g', PATCH_GEOMS)
-def test_conv3x3_patch_kernel(g, fp32):
-    """forward + dgrad (accumulating, with a residual epilogue) through the opt-in LDS-patch kernel vs the oracle."""
-    h = H()
-    from pytorch_ddp_resnet_amd import _lib
-    _lib.lib().rn_set_variant(1)
-    try:
-        _patch_case(h, g, fp32)
-    finally:
-        _lib.lib().rn_set_variant(0)
-
-
-def _patch_case(h, g, fp32):
-    N, Hh, W, C, K = g
-    gm = h.geom(N, Hh, W, C, K, 3, 1, 1)
-    b = h.PlanBuilder()
-    x = b.slot('x', (N, Hh, W, C)); wf = b.slot('wf', (K, 9, C)); wd = b.slot('wd', (C, 9, K))
-    y = b.slot('y', (N, Hh, W, K)); r = b.slot('r', (N, Hh, W, K)); dy = b.slot('dy', (N, Hh, W, K)); dx = b.slot('dx', (N, Hh, W, C))
-    b.op(ir.OP_CONV_FWD, buf=dict(x=x, w_fwd=wf, y=y, res=r), dim=dict(gm, res_mode=ir.RES_SAME, res_C=K))
-    b.op(ir.OP_CONV_DGRAD, buf=dict(dy=dy, w_dgrad=wd, dx=dx, res=-1), dim=dict(gm, res_mode=0, res_C=0), flags=ir.F_ACCUM)
-    plan = b.plan(fp32)
-    sc = (3.0 / (9 * C)) ** 0.5
-    hip, ref = h.run_both(plan, dict(x=fill((N, Hh, W, C), 61), wf=fill((K, 9, C), 62, sc), wd=fill((C, 9, K), 63, sc), r=fill((N, Hh, W, K), 64),
-                                     dy=fill((N, Hh, W, K), 65), dx=fill((N, Hh, W, C), 66)), fp32)
-    assert h.max_rel(hip['y'], ref['y']) < TOL[fp32]
-    assert h.max_rel(hip['dx'], ref['dx']) < TOL[fp32]
-
-
 @pytest.mark.parametrize('fp32', DT)
 @pytest.mark.parametrize('g', [(3, 8, 8, 160, 160, 3, 1, 1), (2, 9, 7, 24, 16, 3, 1, 1), (2, 8, 8, 16, 32, 3, 2, 1), (5, 16, 16, 32, 64, 3, 1, 1)])
 def test_conv_fused_epilogues(g, fp32):

@@ -1,0 +1,156 @@
+"""GPU parity of the PRODUCTION convolution tiles: the real layer shapes of the BASELINE configurations (tests/prod_geoms.py),
+which select the igemm_dma<128xBN> / igemm_ws / igemm_dma<256x32> / wgrad<BKxBC> instantiations that dominate bench.py
+(round-1 review: those ran in the bench only).  Forward with residual + fused BatchNorm statistics, data gradient with the
+fused BatchNorm-backward sums (mask, gscale, xhat) and every parity class of a stride-2 layer, weight gradient at production
+split counts -- through the C ABI (one-op plans), against torch-CPU convolutions (numpy is too slow at these sizes).
+
+The kernel that ran is ASSERTED (rn_kernel_log): a geometry that silently re-routes to another tile fails the test.
+Small geometries are additionally run with the wave-specialised schedule forced (rn_set_variant 128) and forbidden (512)
+so both schedules see every tile shape.
+
+Tolerances: as tests/test_gpu_kernels.py (fp32 2e-5 of the tensor's max; 16-bit engines: operands pre-rounded on both
+sides, one output rounding: bf16 6e-3, fp16 8e-4)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from filler import fill
+from pytorch_ddp_resnet_amd import _lib
+from pytorch_ddp_resnet_amd.engine import ir
+from pytorch_ddp_resnet_amd.engine.lowering import conv_stats_rows
+from prod_geoms import PROD_GEOMS, geom, resolve
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = ['fp32', 'bf16', 'fp16']
+TOL = {'fp32': 2e-5, 'bf16': 6e-3, 'fp16': 8e-4}
+TORCH_DT = {'fp32': torch.float32, 'bf16': torch.bfloat16, 'fp16': torch.float16}
+RN_DT = {'fp32': ir.RN_F32, 'bf16': ir.RN_BF16, 'fp16': ir.RN_F16}
+
+
+def _round(a, dtype):
+    t = torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32))
+    return t.to(TORCH_DT[dtype]).to(torch.float32)
+
+
+def _nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def run_conv_case(g, dtype, variant=0, expect_same_names=True):
+    """one convolution layer: pack -> forward(+residual, +stats) -> dgrad(+BN-backward sums) -> wgrad, HIP vs torch-CPU."""
+    import gpu_harness as h
+    from pytorch_ddp_resnet_amd.engine.executor import Engine
+    L = _lib.lib()
+    fp32 = dtype == 'fp32'
+    g = resolve(g, fp32)
+    N, Hh, W, C, K, k, s, p = g
+    gm = geom(*g)
+    P, Q = gm['P'], gm['Q']
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, Hh, W, C)); w = b.slot('w', (K, k, k, C), 'f32')
+    wf = b.slot('wf', (K, k * k, C)); wd = b.slot('wd', (C, k * k, K))
+    y = b.slot('y', (N, P, Q, K)); res = b.slot('res', (N, P, Q, K)); dy = b.slot('dy', (N, P, Q, K)); dx = b.slot('dx', (N, Hh, W, C))
+    st = b.slot('st', (conv_stats_rows(gm), 2, K), 'f32'); dp = b.slot('dp', (conv_stats_rows(gm, True), 2, C), 'f32')
+    bx = b.slot('bx', (N, Hh, W, C)); bm = b.slot('bm', (N, Hh, W, C)); coef = b.slot('coef', (4, C), 'f32')
+    dw = b.slot('dw', (K, k, k, C), 'f32'); ws = b.slot('workspace', (0,), 'u8')
+    b.op(ir.OP_PACK_W, buf=dict(w=w, w_fwd=wf, w_dgrad=wd), dim=dict(K=K, RS=k * k, C=C))
+    b.op(ir.OP_CONV_FWD, buf=dict(x=x, w_fwd=wf, y=y, res=res, stats=st), dim=dict(gm, res_mode=ir.RES_SAME, res_C=K))
+    b.op(ir.OP_CONV_DGRAD, buf=dict(dy=dy, w_dgrad=wd, dx=dx, res=-1, bn_x=bx, bn_mask=bm, bn_coef=coef, bn_partial=dp),
+         dim=dict(gm, res_mode=0, res_C=0), fp=dict(gscale=1 / 0.7))
+    b.op(ir.OP_CONV_WGRAD, buf=dict(x=x, dy=dy, dw=dw, ws=ws), dim=dict(gm))
+    b.ws_need.append(('wgrad', gm))
+    plan = b.plan(fp32)
+    plan.meta['dtype'] = dtype
+    plan.slot_of['ws'] = ws
+
+    sc = (3.0 / (C * k * k)) ** 0.5
+    xv = _round(fill((N, Hh, W, C), 2), dtype)
+    wv = _round(fill((K, k, k, C), 1, sc), dtype)            # the master is fp32; rounded so both sides multiply the same values
+    dyv = _round(fill((N, P, Q, K), 3), dtype)
+    resv = _round(fill((N, P, Q, K), 4), dtype)
+    bxv = _round(fill((N, Hh, W, C), 5), dtype)
+    bmv = _round(fill((N, Hh, W, C), 6), dtype)
+    cf = torch.from_numpy(np.stack([fill((C,), 71, 0.2, 1.0), fill((C,), 72, 0.1), fill((C,), 73, 0.3), fill((C,), 74, 0.2, 1.0)]))
+
+    eng = Engine(plan, h.DEV, TORCH_DT[dtype])
+    for name, v in dict(x=xv, w=wv, dy=dyv, res=resv, bx=bxv, bm=bmv, coef=cf).items():
+        t = eng.tensors[plan.slot_of[name]]
+        t.copy_(v.reshape(t.shape).to(t.dtype))
+    eng.bind({})
+    L.rn_set_variant(variant)
+    try:
+        L.rn_kernel_log(1)
+        eng.run(0, len(plan.ops), 0)
+        torch.cuda.synchronize()
+        ran = L.rn_kernel_log_read().decode().split(',')
+        L.rn_kernel_log(0)
+        if expect_same_names:
+            want = []
+            for ps in range(3):
+                want += _lib.conv_kernel_names(ps, RN_DT[dtype], gm, fused_epilogue=True)
+            assert ran == want, (ran, want)
+    finally:
+        L.rn_set_variant(0)
+        L.rn_kernel_log(0)
+    out = {n: eng.tensors[plan.slot_of[n]].detach().float().cpu() for n in ('y', 'dx', 'dw', 'st', 'dp')}
+
+    # ---- torch-CPU reference on the same (pre-rounded) operands, fp32 ----
+    xn, wn, dyn = _nchw(xv), wv.permute(0, 3, 1, 2).contiguous(), _nchw(dyv)
+    y_ref = _nhwc(F.conv2d(xn, wn, None, s, p)) + resv
+    dx_ref = _nhwc(torch.nn.grad.conv2d_input(xn.shape, wn, dyn, s, p))
+    dw_ref = torch.nn.grad.conv2d_weight(xn, wn.shape, dyn, s, p).permute(0, 2, 3, 1)
+    tol = TOL[dtype]
+
+    def close(a, r, name, t=tol):
+        err = float((a - r).abs().max() / r.abs().max().clamp_min(1e-30))
+        assert err < t, (name, err, g, dtype, ran)
+    close(out['y'], y_ref, 'y')
+    close(out['dx'], dx_ref, 'dx')
+    close(out['dw'].reshape(dw_ref.shape), dw_ref, 'dw', max(tol, 2e-5) if fp32 else 2e-4)     # dw is fp32 on every engine
+    # fused sums are taken over the STORED (rounded) tensors; only the total over partial rows is specified
+    ys = out['y'].double().reshape(-1, K)
+    s0, s1 = out['st'].double().sum(0)
+    assert float((s0 - ys.sum(0)).abs().max()) < 2e-5 * float(ys.abs().sum(0).max()), 'stats sum'
+    assert float((s1 - (ys * ys).sum(0)).abs().max()) < 2e-5 * float((ys * ys).sum(0).max()), 'stats sumsq'
+    gd = out['dx'].double() * (1 / 0.7) * (bmv.double() > 0)
+    xh = (bxv.double() - cf[2].double()) * cf[3].double()
+    d0, d1 = out['dp'].double().sum(0)
+    scale = float(gd.abs().reshape(-1, C).sum(0).max())
+    assert float((d0 - gd.reshape(-1, C).sum(0)).abs().max()) < 3e-5 * scale, 'bn-backward sum g'
+    assert float((d1 - (gd * xh).reshape(-1, C).sum(0)).abs().max()) < 3e-5 * scale * float(xh.abs().max()), 'bn-backward sum g*xhat'
+    return ran
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('g', PROD_GEOMS)
+def test_production_tiles(g, dtype):
+    run_conv_case(g, dtype)
+
+
+SMALL = [(3, 8, 8, 160, 160, 3, 1, 1), (2, 8, 8, 64, 128, 1, 1, 0), (1, 16, 16, 96, 96, 3, 1, 1), (2, 8, 8, 32, 64, 3, 2, 1), (4, 16, 16, 16, 32, 3, 1, 1)]
+
+
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('variant', [128, 512])
+@pytest.mark.parametrize('g', SMALL)
+def test_both_schedules_on_small_tiles(g, variant, dtype):
+    """variant 128 forces the wave-specialised kernel, 512 forbids it: every tile shape under both schedules."""
+    ran = run_conv_case(g, dtype, variant=variant, expect_same_names=False)
+    assert all(('igemm_ws' in n) == (variant == 128) for n in ran if n.startswith('igemm_') and '256x32' not in n), ran
+
+
+def test_production_set_reaches_every_instantiation():
+    """sanity of the list itself: the names it selects include both schedules and the wide tiles."""
+    names = set()
+    for g in PROD_GEOMS:
+        for ps in range(3):
+            names.update(_lib.conv_kernel_names(ps, ir.RN_BF16, geom(*resolve(g, False)), True))
+    for need in ('igemm_dma<128x160>', 'igemm_ws<128x160>', 'igemm_dma<128x128>', 'igemm_dma<256x32>', 'wgrad<160x160>', 'wgrad<128x128>',
+                 'wgrad_reduce', 'wgrad_reduce_wide'):
+        assert need in names, (need, sorted(names))

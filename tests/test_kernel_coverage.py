@@ -1,0 +1,70 @@
+"""CPU proof that the GPU parity tests reach every convolution kernel instantiation the BASELINE configurations launch.
+
+The library answers "which kernel would this geometry select" without a GPU (rn_conv_kernel_names runs the launchers'
+own selection code in a dry run).  For every convolution of the five full-batch configurations (forward, data gradient,
+weight gradient; bf16/fp16 and fp32 engines) the selected names must also be selected by a geometry of
+tests/prod_geoms.py or of tests/test_gpu_kernels.py -- i.e. no production tile runs only in bench.py."""
+import os
+
+import pytest
+
+from pytorch_ddp_resnet_amd import _lib
+from pytorch_ddp_resnet_amd.engine import ir
+from pytorch_ddp_resnet_amd.engine.lowering import lower
+from prod_geoms import PROD_GEOMS, CONFIGS, geom, resolve
+
+pytestmark = pytest.mark.skipif(not os.path.exists(_lib.LIB_PATH), reason='librn_hip.so not built')
+
+PASS_OF = {ir.OP_CONV_FWD: 0, ir.OP_CONV_DGRAD: 1, ir.OP_CONV_WGRAD: 2}
+
+
+def _small_geoms():
+    import importlib
+    src = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'test_gpu_kernels.py')).read()
+    ns = {}
+    start = src.index('CONV_GEOMS = [')
+    exec(src[start:src.index(']\n', start) + 2], ns)
+    return ns['CONV_GEOMS']
+
+
+def _tested_names(dtype):
+    names = set()
+    for g in list(PROD_GEOMS) + list(_small_geoms()):
+        ce = 4 if dtype == ir.RN_F32 else 8
+        g = resolve(g, dtype == ir.RN_F32)
+        if g[3] % ce or g[4] % ce:
+            continue
+        for p in range(3):
+            names.update(_lib.conv_kernel_names(p, dtype, geom(*g), fused_epilogue=True))
+    return names
+
+
+@pytest.mark.parametrize('dtype', [ir.RN_F32, ir.RN_BF16])
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_every_production_tile_is_parity_tested(name, dtype):
+    cfg = CONFIGS[name]
+    plan = lower(cfg['spec'], cfg['preact'], cfg['use_proj'], 0.0, cfg['batch'], cfg['hw'], cfg['hw'], train=True,
+                 fp32=dtype == ir.RN_F32)
+    tested = _tested_names(dtype)
+    missing = {}
+    n_conv = 0
+    for op in plan.ops:
+        if op.kind not in PASS_OF:
+            continue
+        n_conv += 1
+        g = {k: op.dim[k] for k in 'N H W C P Q K R S stride pad'.split()}
+        for nm in _lib.conv_kernel_names(PASS_OF[op.kind], dtype, g, fused_epilogue=True):
+            if nm not in tested:
+                missing.setdefault(nm, []).append((ir.OP_NAMES[op.kind], tuple(g.values())))
+    assert n_conv > 10
+    assert not missing, f'{name}: kernels launched by the configuration but by no parity-test geometry: ' + \
+        '; '.join(f'{k} e.g. {v[0]}' for k, v in missing.items())
+
+
+def test_dry_run_launches_nothing_and_restores_the_log():
+    L = _lib.lib()
+    L.rn_kernel_log(1)
+    names = _lib.conv_kernel_names(0, ir.RN_BF16, geom(128, 32, 32, 160, 160, 3, 1, 1))
+    assert names == ['igemm_dma<128x160>'] or len(names) == 1
+    assert L.rn_kernel_log_read() == b''          # a query does not leak into a running log
+    L.rn_kernel_log(0)
