@@ -32,7 +32,7 @@ WORKLOADS = {
     'wrn-50-2b': dict(spec='c3,512,7,2,3 n a mp3,2,1 b3 b4 b6 b3 ap7,1,0 fc4096,1000', preact=False, use_proj=True, p=0.0, classes=1000, hw=224, batch=256, cpu_batch=2),
 }
 
-PEAK_TFLOPS = {'bf16': 2500.0, 'fp32': 157.3}      # MI355X dense MFMA peaks (guides/MI355X_MICROARCH.md)
+PEAK_TFLOPS = {'bf16': 2500.0, 'fp16': 2500.0, 'fp32': 157.3}      # MI355X dense MFMA peaks (guides/MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -62,6 +62,31 @@ def cpu_baseline(cfg, steps=3):
                 cpu=_cpu_model(), torch=torch.__version__)
 
 
+def parity(cfg, dtype, dev):
+    """logits / loss of the TIMED engine (same dtype, same kernels) against the torch-CPU port of the reference on a reduced batch
+    of the same workload, same weights, BatchNorm in training mode, dropout off (torch's CPU masks cannot be reproduced on the
+    device).  The north star asks: logits within 1e-3 relative, identical argmax."""
+    from oracle import torch_model as tm
+    from pytorch_ddp_resnet_amd import ResNet
+    b = cfg['cpu_batch']
+    st = tm.init_state(cfg['spec'], cfg['preact'], cfg['use_proj'], seed=0)
+    gen = torch.Generator().manual_seed(4321)
+    x = torch.randn(b, 3, cfg['hw'], cfg['hw'], generator=gen)
+    y = torch.randint(0, cfg['classes'], (b,), generator=gen)
+    with torch.no_grad():
+        lg = tm.TorchResNet(cfg['spec'], cfg['preact'], cfg['use_proj']).forward({k: v.clone() for k, v in st.items()}, x, train=True)
+        ref_loss = float(torch.nn.functional.cross_entropy(lg, y))
+    m = ResNet(cfg['spec'], cfg['preact'], cfg['use_proj'], 0.0, compute_dtype=dtype)
+    m.load_state_dict({k: v.clone() for k, v in st.items()})
+    m = m.to(dev).train()
+    with torch.no_grad():
+        logits = m(x.to(dev)).float().cpu()
+    loss = float(torch.nn.functional.cross_entropy(logits, y))
+    return dict(logits_rel_err=float((logits - lg).abs().max() / lg.abs().max()), loss_abs_err=abs(loss - ref_loss),
+                argmax_equal=bool((logits.argmax(1) == lg.argmax(1)).all()), batch=b,
+                against='torch-CPU fp32 port of the reference forward (oracle/torch_model.py), train-mode BN, dropout 0')
+
+
 def _cpu_model():
     try:
         with open('/proc/cpuinfo') as f:
@@ -79,7 +104,10 @@ def main():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--workload', default='wrn-28-10', choices=list(WORKLOADS))
-    ap.add_argument('--dtype', default='bf16', choices=['bf16', 'fp32'])
+    ap.add_argument('--dtype', default='fp16', choices=['fp16', 'bf16', 'fp32'],
+                    help='engine arithmetic: fp16 = the reference\'s own GPU arithmetic (autocast + GradScaler, script.py:63), fp32 = exact-f32 MFMA parity mode')
+    ap.add_argument('--also', default='fp32', help='comma-separated dtypes measured in short side runs and reported under "other_dtypes" (N=1 only; "" = none)')
+    ap.add_argument('--no-parity', action='store_true')
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: the workload\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--breakdown', action='store_true', help='print the per-op-kind time table to stderr')
@@ -111,12 +139,51 @@ def main():
         else:
             torch.distributed.init_process_group('nccl', device_id=dev)    # RCCL over xGMI
 
+    res = measure(args, cfg, args.dtype, dev, world, rank, args.steps, args.warmup, main_run=True)
+
+    if rank == 0:
+        out = {
+            'metric': 'images/sec fwd+bwd (whole node)', 'value': round(res['value'], 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(res['ms'], 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.dtype, 'data': 'synthetic',
+            'config': {'workload': f"{args.workload} CIFAR-10 32x32" if cfg['hw'] == 32 else f"{args.workload} 224x224", 'architecture_spec': cfg['spec'],
+                       'preact': cfg['preact'], 'use_proj': cfg['use_proj'], 'dropout_prob': cfg['p'], 'batch_per_gpu': cfg['batch'],
+                       'global_batch': cfg['batch'] * world, 'parallelism': f'dp{world}',
+                       'timed_region': 'fwd + CE loss/top-k + bwd + grad all-reduce' + (' (no optimizer step)' if args.optimizer == 'none' else f' + SGD step ({args.optimizer})'),
+                       'sync_bn': bool(args.sync_bn), 'loss_scale': res['loss_scale']},
+            'step_ms_spread': res['spread'],
+            'roofline': res['roof'],
+        }
+    if world == 1:
+        # the same workload on the other engines, short runs: the fp32 engine (exact-f32 MFMA) is the parity engine, so the record
+        # always carries a figure at the reference's own CPU precision next to the headline
+        others = {}
+        for dt_ in [d for d in args.also.split(',') if d and d != args.dtype]:
+            r = measure(args, cfg, dt_, dev, world, rank, max(3, min(args.steps, 8)), 2, main_run=False)
+            others[dt_] = {'value': round(r['value'], 1), 'unit': 'images/sec', 'ms_per_step': round(r['ms'], 3), 'roofline': r['roof']}
+            if not args.no_parity:
+                others[dt_]['parity'] = parity(cfg, dt_, dev)
+        if others:
+            out['other_dtypes'] = others
+        if not args.no_parity:
+            out['parity'] = parity(cfg, args.dtype, dev)
+        if not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(cfg)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
+    """W untimed + K timed steps of the workload on the `dtype` engine, then the instrumented pass for the roofline record."""
     from pytorch_ddp_resnet_amd import ResNet
     from pytorch_ddp_resnet_amd.engine import ir
     from pytorch_ddp_resnet_amd.ddp import GradReducer
+    from pytorch_ddp_resnet_amd.algos.metrics import compute_losses_and_metrics
 
     torch.manual_seed(0)                                                       # identical replicas on every rank
-    model = ResNet(cfg['spec'], cfg['preact'], cfg['use_proj'], cfg['p'], compute_dtype=args.dtype, sync_bn=args.sync_bn).to(dev).train()
+    model = ResNet(cfg['spec'], cfg['preact'], cfg['use_proj'], cfg['p'], compute_dtype=dtype, sync_bn=args.sync_bn).to(dev).train()
     gen = torch.Generator().manual_seed(1234 + rank)
     x = torch.randn(cfg['batch'], 3, cfg['hw'], cfg['hw'], generator=gen).to(dev)
     y = torch.randint(0, cfg['classes'], (cfg['batch'],), generator=gen).to(dev)
@@ -124,8 +191,11 @@ def main():
     model.alias_grads = True            # gradients are consumed (dropped) every step: no defensive copy of the flat buffer
 
     params = list(model.parameters())
+    # fp16: the loss is scaled on the device as torch's GradScaler does (training.py:100 scaler.scale(loss).backward()); the scale
+    # is found during warm-up by GradScaler's own backoff rule (halve while any gradient is non-finite) and then held fixed
+    loss_scale = torch.tensor(65536.0 if dtype == 'fp16' else 1.0, device=dev)
     opt = None
-    if args.optimizer != 'none':
+    if args.optimizer != 'none' and main_run:
         sgd_args = dict(lr=0.1, momentum=0.9, dampening=0.0, nesterov=True, weight_decay=5e-4)        # the WRN-28-10 run's optimizer_args
         if args.optimizer == 'fused':
             from pytorch_ddp_resnet_amd.utils.fused_sgd import FusedSGD
@@ -137,8 +207,11 @@ def main():
         for p_ in params:
             p_.grad = None                                   # optimizer.zero_grad() of training.py:113 (set_to_none)
         logits = model(x)
-        loss = torch.nn.functional.cross_entropy(logits, y)
-        loss.backward()
+        loss = compute_losses_and_metrics(logits, y)['loss']          # CE + top-1/top-5 as one launch (metrics.py:10-29)
+        if dtype == 'fp16':
+            (loss * loss_scale).backward()
+        else:
+            loss.backward()
         if reducer is not None:
             reducer.finish()
         if opt is not None:
@@ -150,28 +223,43 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for i in range(max(warmup, 1)):
         step()
+        if dtype == 'fp16' and i < 8:                        # loss-scale backoff, outside the timed region
+            eng0 = next(e for k, e in model._engines.items() if k[1] and k[2])
+            bad = torch.logical_not(torch.isfinite(eng0.flat_grad).all()).float()
+            if world > 1:
+                torch.distributed.all_reduce(bad)
+            if bad.item() > 0:
+                loss_scale.mul_(0.5)
     fence()
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(steps):
         step()
+        evs[i + 1].record()                                  # per-step spread only; nothing synchronises inside the region
     fence()
     dt = time.perf_counter() - t0
+    per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = t.item()
-    ms = dt / args.steps * 1e3
-    value = world * cfg['batch'] * args.steps / dt
+    ms = dt / steps * 1e3
+    value = world * cfg['batch'] * steps / dt
+    spread = dict(median=round(per_step[len(per_step) // 2], 3), p10=round(per_step[int(0.1 * (len(per_step) - 1))], 3),
+                  p90=round(per_step[int(round(0.9 * (len(per_step) - 1)))], 3), source='HIP events between steps on the launch stream (rank 0)')
 
     # ---- instrumented pass: per-launch HIP events on the launch stream (same steps).  EVERY rank runs it -- a step contains
     # the gradient collectives, which all ranks must enter -- and rank 0 reports its own measurements ----
     roof = None
     eng = next(e for k, e in model._engines.items() if k[1] and k[2])
-    nprof = max(3, min(10, args.steps))
+    nprof = max(3, min(10, steps))
     agg, conv_t, conv_f, nconv = {}, 0.0, 0.0, 0
     per_op = {}
+    from pytorch_ddp_resnet_amd import _lib
+    _lib.lib().rn_kernel_log(1)
     for _ in range(nprof):
         eng.profile(True)
         step()
@@ -185,30 +273,33 @@ def main():
                 conv_f += conv_flops(op)
                 nconv += 1
     eng.profile(False)
+    kernels = sorted(set(n for n in _lib.lib().rn_kernel_log_read().decode().split(',') if n and 'reduce' not in n))
+    _lib.lib().rn_kernel_log(0)
     if rank == 0:
         achieved = conv_f / (conv_t * 1e-3) / 1e12 if conv_t > 0 else 0.0
-        peak = PEAK_TFLOPS[args.dtype]
+        peak = PEAK_TFLOPS[dtype]
         # HBM-side bytes per conv launch: from the committed PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE, separate
         # rocprofv3 --pmc runs, tools/summarize_profiles.py); a PMC pass cannot run inside the timed process
         traffic, traffic_src = None, None
         pmc = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'profiles', 'latest_pmc_summary.json')
-        if args.workload == 'wrn-28-10' and args.dtype == 'bf16' and os.path.exists(pmc):
+        if os.path.exists(pmc):
             ks = json.load(open(pmc))
-            tot_b = tot_n = 0.0
-            for name, e in ks['kernels'].items():
-                if name.startswith(('igemm_', 'wgrad_kernel')) and 'hbm_read_MB_per_launch' in e:
-                    n_l = e['launches_in_trace']
-                    tot_b += n_l * (e['hbm_read_MB_per_launch'] + e.get('hbm_write_MB_per_launch', 0.0)) * 1e6
-                    tot_n += n_l
-            if tot_n:
-                traffic, traffic_src = int(tot_b / tot_n), f"profiles/{ks['tag']}_pmc_summary.json"
+            if ks.get('workload', 'wrn-28-10') == args.workload and ks.get('dtype', 'bf16') == dtype:
+                tot_b = tot_n = 0.0
+                for name, e in ks['kernels'].items():
+                    if name.startswith(('igemm_', 'wgrad_kernel')) and 'hbm_read_MB_per_launch' in e:
+                        n_l = e['launches_in_trace']
+                        tot_b += n_l * (e['hbm_read_MB_per_launch'] + e.get('hbm_write_MB_per_launch', 0.0)) * 1e6
+                        tot_n += n_l
+                if tot_n:
+                    traffic, traffic_src = int(tot_b / tot_n), f"profiles/{ks['tag']}_pmc_summary.json"
         roof = dict(bound='mfma', achieved=round(achieved, 1), peak=peak, unit='TFLOP/s', frac=round(achieved / peak, 4), traffic=traffic,
                     traffic_unit='bytes per conv launch (HBM side)', traffic_source=traffic_src,
-                    kernel='igemm_dma_kernel / igemm_ws_kernel / wgrad_kernel (implicit-GEMM conv fwd, dgrad, wgrad launches)',
+                    kernel='implicit-GEMM convolution launches (forward, dgrad, wgrad): ' + ' '.join(kernels),
                     launches_per_step=nconv // nprof, avg_launch_ms=round(conv_t / max(nconv, 1), 4),
                     algorithmic_gflop_per_launch=round(conv_f / max(nconv, 1) / 1e9, 2),
                     conv_ms_per_step=round(conv_t / nprof, 3), all_ops_ms_per_step=round(sum(agg.values()), 3))
-        if args.breakdown:
+        if args.breakdown and main_run:
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
                 print(f'  {k:22s} {v:9.3f} ms/step', file=sys.stderr)
             for op, t in sorted(per_op.values(), key=lambda ot: -ot[1])[:args.per_op]:
@@ -219,23 +310,10 @@ def main():
                 print(f'    {ir.OP_NAMES[op.kind]:18s} {t * 1e3:9.1f} us  {geo}{extra}  [{op.note}]', file=sys.stderr)
     if world > 1:
         torch.distributed.barrier()
-
-    if rank == 0:
-        out = {
-            'metric': 'images/sec fwd+bwd (whole node)', 'value': round(value, 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
-            'warmup': args.warmup, 'ms_per_step': round(ms, 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f"{args.workload} CIFAR-10 32x32" if cfg['hw'] == 32 else f"{args.workload} 224x224", 'architecture_spec': cfg['spec'],
-                       'preact': cfg['preact'], 'use_proj': cfg['use_proj'], 'dropout_prob': cfg['p'], 'batch_per_gpu': cfg['batch'],
-                       'global_batch': cfg['batch'] * world, 'parallelism': f'dp{world}', 'timed_region': 'fwd + CE loss + bwd + grad all-reduce' + (' (no optimizer step)' if opt is None else f' + SGD step ({args.optimizer})'),
-                       'sync_bn': bool(args.sync_bn)},
-            'roofline': roof,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(cfg)
-        print(json.dumps(out))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    ls = float(loss_scale.item())
+    del model, x, y
+    torch.cuda.empty_cache()
+    return dict(ms=ms, value=value, spread=spread, roof=roof, loss_scale=ls)
 
 
 if __name__ == '__main__':

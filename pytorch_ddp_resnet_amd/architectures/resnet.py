@@ -106,9 +106,11 @@ def fused_loss_and_metrics(logits, labels):
 
 class ResNet(nn.Module):
     def __init__(self, architecture_spec: str, preact: bool, use_proj: bool, dropout_prob: float,
-                 compute_dtype: str = 'bf16', sync_bn: bool = False):
-        """:param compute_dtype: 'bf16' (bf16 MFMA, fp32 accumulate/statistics/master weights) or 'fp32' (exact-f32 MFMA:
-        the parity mode).  :param sync_bn: all-reduce BatchNorm statistics over the default process group."""
+                 compute_dtype: str = 'fp16', sync_bn: bool = False):
+        """:param compute_dtype: 'fp16' (default: the reference's own GPU arithmetic -- fp16 storage and MFMA operands under a
+        GradScaler, script.py:63 / training.py:95-110 -- with fp32 accumulation, statistics and master weights; meets the 1e-3 logit
+        bound), 'bf16' (no loss scaling needed, 8 significant bits: logits ~4e-3) or 'fp32' (exact-f32 MFMA: the parity mode).
+        :param sync_bn: all-reduce BatchNorm statistics over the default process group."""
         super().__init__()
         self._architecture_spec = architecture_spec
         self._preact, self._use_proj, self._dropout_prob = preact, use_proj, dropout_prob

@@ -59,6 +59,7 @@ struct IgemmArgs {
   unsigned probe_mask;     // timing probe (rn_set_variant bit6): AND-mask on DMA source offsets, 0xFFFFFFFF in production
   unsigned long long* stamps;   // diagnostic: per-workgroup s_memtime stamps [grid][16] (rn_set_stamp_buffer), NULL in production
   int probe_ep;            // timing probes: 1 = skip the global stores of the epilogue, 2 = skip the epilogue
+  int probe_k;             // K-loop timing probes (igemm_dma_kernel): 1 = DMA only (no fragment reads / MFMA), 2 = no DMA, 3 = every DMA out of range
   int xcd_remap;           // 1: blockIdx -> tile through the bijective XCD remap, column tiles fastest
   int dense_src;           // 1: one tap at offset (0,0), unit stride, source grid == compute grid (1x1 convolutions): row m reads pixel m
   int dh[MAX_TAPS], dw[MAX_TAPS], widx[MAX_TAPS];
@@ -73,7 +74,7 @@ __device__ inline void preload_args(const IgemmArgs& a) {
   RN_TOUCH(a.nt); RN_TOUCH(a.wrs); RN_TOUCH(a.cpt); RN_TOUCH(a.nk); RN_TOUCH(a.nth); RN_TOUCH(a.ntw);
   RN_TOUCH(a.magic_pq); RN_TOUCH(a.magic_q); RN_TOUCH(a.accum); RN_TOUCH(a.tile_base);
   RN_TOUCH(a.stats); RN_TOUCH(a.bn_x); RN_TOUCH(a.bn_mask); RN_TOUCH(a.bn_coef); RN_TOUCH(a.bias); RN_TOUCH(a.gscale);
-  RN_TOUCH(a.probe_mask); RN_TOUCH(a.stamps); RN_TOUCH(a.probe_ep); RN_TOUCH(a.xcd_remap); RN_TOUCH(a.dense_src);
+  RN_TOUCH(a.probe_mask); RN_TOUCH(a.stamps); RN_TOUCH(a.probe_ep); RN_TOUCH(a.xcd_remap); RN_TOUCH(a.dense_src); RN_TOUCH(a.probe_k);
 #undef RN_TOUCH
 }
 
@@ -565,6 +566,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
   stamp(a.stamps, 7);
 
   auto dma_tile = [&](int stg) {
+    if (a.probe_k == 2) return;
     const unsigned base = lds0 + (unsigned)(stg * STAGE * 16);
     const unsigned keep = m0_save();
 #pragma unroll
@@ -572,7 +574,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
       const int j = wave * AI + i;
       bool kv; int tp; unsigned so, wo;
       pick_walk<CPRT, NST>(walk, j, kv, tp, so, wo);
-      const unsigned off = (kv && ((amask[i] >> tp) & 1)) ? ((abase[i] + so) & a.probe_mask) : OOB;
+      const unsigned off = (kv && ((amask[i] >> tp) & 1) && a.probe_k != 3) ? ((abase[i] + so) & a.probe_mask) : OOB;
       dma16(ra_desc, off, base + j * 1024);
     }
 #pragma unroll
@@ -580,7 +582,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
       const int j = wave * BI + i;
       bool kv; int tp; unsigned so, wo;
       pick_walk<CPRT, NST>(walk, j, kv, tp, so, wo);
-      const unsigned off = (kv && bbase[i] != OOB) ? ((bbase[i] + wo) & a.probe_mask) : OOB;
+      const unsigned off = (kv && bbase[i] != OOB && a.probe_k != 3) ? ((bbase[i] + wo) & a.probe_mask) : OOB;
       dma16(rb_desc, off, base + (j < BIT ? BM * CPRT * 16 + j * 1024 : (BM + BN) * CPRT * 16));
     }
     m0_restore(keep);
@@ -616,6 +618,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
     const uint4* cur_s = &smem[stg * STAGE];
     int nstg = stg + (NSTG - 1); if (nstg >= NSTG) nstg -= NSTG;
     if (it + NSTG - 1 < a.nk) dma_tile(nstg);          // ring slot read last in iteration it-1: free since the barrier
+    if (a.probe_k != 1) {
     uint4 fa[2][TM], fb[2][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[0][i] = cur_s[swz_t<CPRT>(arow0 + 32 * i, lh)];
@@ -637,6 +640,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
 #pragma unroll
         for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur][i], fb[cur][j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
+    }
     }
     // (spreading a tile's DMAs over the k-steps instead of issuing them at the head of the iteration was measured 2-6 % slower
   // with two ring stages: the late ones have no time to land)
@@ -904,6 +908,7 @@ static void fill_ep(IgemmArgs& a, const rn_conv_epilogue* ep, int tile_base) {
   a.probe_mask = (g_rn_variant & 64) ? 0x0000FFF0u : 0xFFFFFFFFu;
   a.stamps = reinterpret_cast<unsigned long long*>(g_rn_stamps);
   a.xcd_remap = (g_rn_variant & 8) ? 0 : 1;
+  a.probe_k = (g_rn_variant & 1024) ? 1 : ((g_rn_variant & 2048) ? 2 : ((g_rn_variant & 4096) ? 3 : 0));
   a.probe_ep = (g_rn_variant & 8192) ? 1 : ((g_rn_variant & 16384) ? 2 : ((g_rn_variant & 32768) ? 3 : ((g_rn_variant & 65536) ? 4 : 0)));
 }
 

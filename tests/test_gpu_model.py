@@ -28,7 +28,7 @@ def rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
 
 
-@pytest.mark.parametrize('dtype', ['fp32', 'bf16'])
+@pytest.mark.parametrize('dtype', ['fp32', 'bf16', 'fp16'])
 @pytest.mark.parametrize('name', list(MODELS))
 def test_models_match_golden(golden, name, dtype):
     cfg = MODELS[name]
@@ -36,13 +36,16 @@ def test_models_match_golden(golden, name, dtype):
     shapes, st, x, y, nesterov = model_inputs(g, cfg)
     m = build(cfg, st, dtype)
     xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
-    if dtype == 'bf16' and name in ('v2b_small', 'inet_small'):
+    if dtype != 'fp32' and name in ('v2b_small', 'inet_small'):
         # bottleneck width 4: bf16 moves 16-byte chunks of 8 channels -> rejected loudly, never silently re-routed
         from pytorch_ddp_resnet_amd._lib import RnError
         with pytest.raises(RnError, match='multiples of 8'):
             m(xt)
         return
-    tl, tg = (1e-4, 1e-3) if dtype == 'fp32' else (5e-2, 3.5e-1)
+    # fp16 is the 16-bit engine that has to meet the north-star bound (logits 1e-3); bf16 (8 significant bits) cannot and is
+    # bounded at what bf16 storage costs
+    tl, tg = {'fp32': (1e-4, 1e-3), 'bf16': (5e-2, 3.5e-1), 'fp16': (1e-3, 6e-2)}[dtype]
+    S = 256.0 if dtype == 'fp16' else 1.0            # loss scale (fp16 gradients; a GradScaler's job in training)
     m.eval()
     with torch.no_grad():
         le = m(xt)
@@ -53,9 +56,9 @@ def test_models_match_golden(golden, name, dtype):
     assert rel(logits, g['train.logits']) < tl
     assert (logits.argmax(1).cpu().numpy() == g['train.logits'].argmax(1)).all()
     loss = torch.nn.functional.cross_entropy(logits, yt)
-    assert abs(loss.item() - float(g['train.loss'])) < (1e-5 if dtype == 'fp32' else 3e-2) * max(1.0, abs(float(g['train.loss'])))
-    loss.backward()
-    grads = {k: p.grad for k, p in m.named_parameters()}
+    assert abs(loss.item() - float(g['train.loss'])) < {'fp32': 1e-5, 'bf16': 3e-2, 'fp16': 2e-3}[dtype] * max(1.0, abs(float(g['train.loss'])))
+    (loss * S).backward()
+    grads = {k: p.grad / S for k, p in m.named_parameters()}
     pkeys = [k for k, _ in shapes if k.endswith('weight') or k.endswith('bias')]
     norms = np.array([grads[k].double().norm().item() for k in pkeys])
     assert np.abs(norms - g['grad.norms']).max() < min(tg, 0.15) * g['grad.norms'].max()
@@ -74,12 +77,12 @@ def test_models_match_golden(golden, name, dtype):
                 d2, r2 = float(np.sqrt((diff ** 2).sum())), float(np.sqrt((g['grad.' + k].astype(np.float64) ** 2).sum()))
                 worst = max(worst, d2 / (r2 + 0.01 * gnorm))
                 assert d2 < tg * r2 + 0.01 * gnorm, (k, d2, r2, gnorm)
-    if dtype == 'bf16':
-        print(f'{name} bf16: logits rel err {rel(logits, g["train.logits"]):.3e}; worst per-parameter gradient L2 error (rel. to own norm + 1% global) {worst:.3f}')
+    if dtype != 'fp32':
+        print(f'{name} {dtype}: logits rel err {rel(logits, g["train.logits"]):.3e}; worst per-parameter gradient L2 error (rel. to own norm + 1% global) {worst:.3f}')
     sd = m.state_dict()
     for k in sd:
         if 'step1.buf.' + k in g:
-            assert rel(sd[k], g['step1.buf.' + k]) < (1e-4 if dtype == 'fp32' else 2e-2), k
+            assert rel(sd[k], g['step1.buf.' + k]) < {'fp32': 1e-4, 'bf16': 2e-2, 'fp16': 2e-3}[dtype], k
 
 
 @pytest.mark.parametrize('name', ['rn20', 'wrn_small'])
