@@ -120,6 +120,9 @@ int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_seed, rn_strea
  * caller joins before it consumes weight gradients (end of the backward, or before reducing a gradient bucket) */
 int rn_plan_set_overlap(rn_plan* plan, int enable);
 int rn_plan_join(rn_plan* plan, rn_stream stream);
+/* `stream` (e.g. the gradient all-reduce stream) waits for the weight-gradient ops forked so far; nothing is joined into the launch
+ * stream (rn_plan_join at the end of the range still does that) */
+int rn_plan_side_wait(rn_plan* plan, rn_stream stream);
 int rn_plan_num_ops(const rn_plan* plan);
 /* per-op hipEvent pairs on the launch stream; rn_plan_profile_read blocks and returns ms per op (0 = not run) */
 int rn_plan_profile(rn_plan* plan, int enable);

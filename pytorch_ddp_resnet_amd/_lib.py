@@ -46,6 +46,7 @@ def lib():
     L.rn_plan_destroy.argtypes = [vp]
     L.rn_plan_set_overlap.argtypes = [vp, i32]
     L.rn_plan_join.argtypes = [vp, vp]
+    L.rn_plan_side_wait.argtypes = [vp, vp]
     L.rn_plan_destroy.restype = None
     L.rn_conv_wgrad_ws_bytes.argtypes = [C.POINTER(RnConvGeom)]
     L.rn_conv_wgrad_ws_bytes.restype = sz

@@ -74,11 +74,12 @@ struct rn_plan {
   // path of the backward and leaves matrix-pipe and HBM idle time in every kernel's prologue, epilogue and tail round.
   bool overlap = false, side_pending = false;
   hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_peek = nullptr;
   ~rn_plan() {
     for (auto e : ev) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
+    if (ev_peek) (void)hipEventDestroy(ev_peek);
     if (side) (void)hipStreamDestroy(side);
   }
 };
@@ -146,7 +147,8 @@ extern "C" int rn_plan_set_overlap(rn_plan* plan, int enable) {
     (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (hipStreamCreateWithPriority(&plan->side, hipStreamNonBlocking, least) != hipSuccess ||
         hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&plan->ev_peek, hipEventDisableTiming) != hipSuccess) {
       rn_set_error("rn_plan_set_overlap: could not create the side stream / events");
       return 2;
     }
@@ -164,6 +166,18 @@ extern "C" int rn_plan_join(rn_plan* plan, rn_stream stream) {
     return 2;
   }
   plan->side_pending = false;
+  return 0;
+}
+
+// makes `stream` (a communication stream) wait for the weight-gradient ops forked so far WITHOUT joining them into the launch stream:
+// the launch stream keeps issuing the data-gradient chain; rn_plan_join still joins everything at the end of the range
+extern "C" int rn_plan_side_wait(rn_plan* plan, rn_stream stream) {
+  RN_CHECK_ARG(plan != nullptr, "rn_plan_side_wait: null plan");
+  if (!plan->side_pending) return 0;
+  if (hipEventRecord(plan->ev_peek, plan->side) != hipSuccess || hipStreamWaitEvent(as_stream(stream), plan->ev_peek, 0) != hipSuccess) {
+    rn_set_error("rn_plan_side_wait: event record / wait failed");
+    return 2;
+  }
   return 0;
 }
 

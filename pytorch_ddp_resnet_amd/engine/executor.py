@@ -144,46 +144,64 @@ class Engine:
             self._graphs = {}
 
     # ---- execution ------------------------------------------------------------------------------------------
-    def run(self, first: int, last: int, step_seed: int, hook_fn: Optional[Callable] = None):
-        if self.use_graphs and hook_fn is None and not self._profiling:
-            key = (first, last)
-            g = self._graphs.get(key)
-            if g is None:                                  # first call runs eagerly (warm-up), second call captures
-                self._graphs[key] = 'warm'
-            elif g == 'warm':
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._run_eager(first, last, step_seed, None)
-                self._graphs[key] = g
-                g.replay()
-                return
-            else:
-                g.replay()
-                return
-        self._run_eager(first, last, step_seed, hook_fn)
+    MIN_GRAPH_OPS = 8        # a captured range costs ~10-16 us of replay overhead: shorter hook-to-hook ranges run eagerly
 
-    def _run_eager(self, first: int, last: int, step_seed: int, hook_fn: Optional[Callable] = None):
-        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        pos = first
-        # the hook consumer may declare which hook points it acts on (GradReducer.wanted: bucket ends only): the op stream is
-        # cut there and nowhere else (80 gradient hooks per WRN-28-10 backward, 6 buckets)
+    def _cuts(self, first, last, hook_fn):
+        """hook points inside [first, last) the consumer acts on -> [(position, [hooks])].  The consumer may declare which
+        ones (GradReducer.wanted: bucket ends and SyncBN sums only): 80 gradient hooks per WRN-28-10 backward, 6 buckets."""
+        if hook_fn is None:
+            return []
         wanted = getattr(getattr(hook_fn, '__self__', None), 'wanted', None)
+        cuts = []
         for at in self._hook_points:
             if at < first or at >= last:
                 continue
-            if hook_fn is None:
-                continue
             hooks = [h for h in self._hooks[at] if wanted is None or wanted(self, h)]
-            if not hooks:
-                continue
+            if hooks:
+                cuts.append((at, hooks))
+        return cuts
+
+    def run(self, first: int, last: int, step_seed: int, hook_fn: Optional[Callable] = None):
+        """ops [first, last) in order; `hook_fn(engine, hook)` is called between ops at the plan's hook points.  With hipGraph
+        replay enabled every hook-free range is a captured graph: the host-side actions (collective launches) sit BETWEEN graphs,
+        so a reducer no longer turns replay off for launch-bound networks (round 1: any hook consumer forced eager launches)."""
+        stream = None
+        pos = first
+        graphs = self.use_graphs and not self._profiling
+        for at, hooks in self._cuts(first, last, hook_fn) + [(last, [])]:
             if at > pos:
-                _lib.check(self.L.rn_plan_run(self._h, pos, at, step_seed, stream))
+                if graphs and at - pos >= self.MIN_GRAPH_OPS:
+                    self._replay(pos, at, step_seed)
+                else:
+                    if stream is None:
+                        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+                    _lib.check(self.L.rn_plan_run(self._h, pos, at, step_seed, stream))
                 pos = at
             for h in hooks:
                 hook_fn(self, h)
-        if last > pos:
-            _lib.check(self.L.rn_plan_run(self._h, pos, last, step_seed, stream))
+        if stream is None:
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         _lib.check(self.L.rn_plan_join(self._h, stream))       # forked weight-gradient ops: joined at the end of every range
+
+    def _replay(self, a, b, step_seed):
+        key = (a, b)
+        g = self._graphs.get(key)
+        if g is None:                                      # first call runs eagerly (warm-up), second call captures
+            self._graphs[key] = 'warm'
+            stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+            _lib.check(self.L.rn_plan_run(self._h, a, b, step_seed, stream))
+            return
+        if g == 'warm':
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+                _lib.check(self.L.rn_plan_run(self._h, a, b, step_seed, stream))
+            self._graphs[key] = g
+        g.replay()
+
+    def side_wait(self, stream):
+        """`stream` (a torch.cuda.Stream) waits for the weight-gradient ops forked so far; the compute stream is not joined."""
+        _lib.check(self.L.rn_plan_side_wait(self._h, C.c_void_p(stream.cuda_stream)))
 
     def join(self):
         """the current stream waits for the weight-gradient ops forked so far (before their results are read)."""

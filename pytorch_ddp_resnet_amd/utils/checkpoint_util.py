@@ -1,0 +1,92 @@
+"""
+Checkpoint files in the reference's format, so that a run of either code base resumes from the other's files.
+
+Format (from /root/reference/resnet/utils/checkpoint_util.py): one file per checkpointable, ``{kind}_{steps}.pth`` (:16-18),
+holding ``torch.save(obj.state_dict())`` (:74-85); on resume the newest step is picked per kind (:21-41), every kind must
+agree on it or ``RuntimeError("Checkpoint steps not aligned.")`` (:112-114); only the newest five files of a kind are kept
+(:44-49, 85).  The reference's classifier is wrapped in DistributedDataParallel (script.py:64), so its keys carry a
+``module.`` prefix (``module._architecture.1.0._conv1.weight``); the product's classifier is the bare ``ResNet`` (the gradient
+reduction lives in ddp.GradReducer), so ``ddp_keys(classifier)`` adds / strips that prefix at the file boundary.  Optimizer
+files are ``torch.optim.SGD.state_dict()``; ``utils.fused_sgd.FusedSGD`` loads and writes the same structure (parameter
+order == ``model.parameters()`` order == the reference's).  Tensors are read by shape: the product keeps convolution weights
+channels_last in memory, which ``load_state_dict``'s ``copy_`` and ``state_dict()``'s logical [K,C,R,S] view make invisible.
+"""
+import os
+import re
+from typing import Dict, Optional
+
+import torch
+
+
+def _format_name(kind: str, steps: int, suffix: str = 'pth') -> str:
+    return f"{kind}_{steps}.{suffix}"
+
+
+def _parse_name(filename: str) -> Optional[dict]:
+    m = re.fullmatch(r"(\w+)_([0-9]+)\.([a-z]+)", filename)
+    return dict(kind=m.group(1), steps=int(m.group(2)), suffix=m.group(3)) if m else None
+
+
+def _steps_of(base_path: str, kind: str):
+    out = set()
+    for f in os.listdir(base_path):
+        p = _parse_name(f)
+        if p is not None and p['kind'] == kind:
+            out.add(p['steps'])
+    return sorted(out)
+
+
+def latest_step(base_path: str, kind: str) -> Optional[int]:
+    s = _steps_of(base_path, kind)
+    return s[-1] if s else None
+
+
+class ddp_keys:
+    """views a module through DistributedDataParallel's key scheme: ``state_dict()`` keys gain ``module.``, ``load_state_dict``
+    accepts them with or without it."""
+
+    def __init__(self, module, prefix: str = 'module.'):
+        self.module, self.prefix = module, prefix
+
+    def state_dict(self):
+        return {self.prefix + k: v for k, v in self.module.state_dict().items()}
+
+    def load_state_dict(self, sd):
+        if sd and all(k.startswith(self.prefix) for k in sd):
+            sd = {k[len(self.prefix):]: v for k, v in sd.items()}
+        return self.module.load_state_dict(sd)
+
+
+def maybe_load_checkpoint(checkpoint_dir: str, kind_name: str, checkpointable, map_location, steps: Optional[int]) -> int:
+    os.makedirs(checkpoint_dir, exist_ok=True)
+    steps_ = latest_step(checkpoint_dir, kind_name) if steps is None else steps
+    path = os.path.join(checkpoint_dir, _format_name(kind_name, steps_)) if steps_ is not None else None
+    if path is None or not os.path.exists(path):
+        print(f"Bad {kind_name} checkpoint or none at {checkpoint_dir} with step {steps}.")
+        print("Running from scratch.")
+        return 0
+    checkpointable.load_state_dict(torch.load(path, map_location=map_location))
+    print(f"Loaded {kind_name} checkpoint from {checkpoint_dir}, with step {steps_}.")
+    return steps_
+
+
+def save_checkpoint(checkpoint_dir: str, kind_name: str, checkpointable, steps: int, keep: int = 5) -> None:
+    os.makedirs(checkpoint_dir, exist_ok=True)
+    torch.save(checkpointable.state_dict(), os.path.join(checkpoint_dir, _format_name(kind_name, steps)))
+    for old in _steps_of(checkpoint_dir, kind_name)[:-keep]:
+        os.remove(os.path.join(checkpoint_dir, _format_name(kind_name, old)))
+
+
+def maybe_load_checkpoints(checkpoint_dir: str, checkpointables: Dict[str, object], map_location, steps: Optional[int] = None) -> int:
+    """-> the step of the loaded checkpoints (0: none found, running from scratch).  Every non-None checkpointable must be at the
+    same step."""
+    found = [maybe_load_checkpoint(checkpoint_dir, k, c, map_location, steps) for k, c in checkpointables.items() if c is not None]
+    if len(set(found)) > 1:
+        raise RuntimeError("Checkpoint steps not aligned.")
+    return found[0] if found else 0
+
+
+def save_checkpoints(checkpoint_dir: str, checkpointables: Dict[str, object], steps: int) -> None:
+    for k, c in checkpointables.items():
+        if c is not None:
+            save_checkpoint(checkpoint_dir, k, c, steps)

@@ -7,7 +7,7 @@ Only data is written (inputs are the closed-form filler of filler.py; outputs co
 modules: resnet.architectures.{resnet,residual_block}, resnet.algos.{metrics,evaluation}, and the torch.nn ops
 those files call).  /root/reference does not exist on the GPU box: tests read the .npz files, never this script.
 Fixture groups follow SURVEY.md section 8(c): G1 conv kernels, G2 BatchNorm, G3 blocks, G4 models (+SGD steps),
-G5 grammar/state_dict keys, G6 metrics, G7 SyncBN oracle, G8 evaluation loop.
+G5 grammar/state_dict keys, G6 metrics, G7 SyncBN oracle, G8 evaluation loop, G9 a reference-written checkpoint.
 """
 
 import os
@@ -263,5 +263,51 @@ def g8_eval_loop():
     save('g8_eval', loss=np.array(m['loss']), top1_err=np.array(m['top1_err']), top5_err=np.array(m['top5_err']))
 
 
+# ------------------------------------------------------------------------------------------- G9
+def g9_checkpoint():
+    """a checkpoint written by the REFERENCE's own code path: DistributedDataParallel-wrapped classifier (script.py:64, gloo,
+    world_size 1) + torch.optim.SGD, three training steps (training.py:92-113), then resnet.utils.checkpoint_util.save_checkpoints
+    -> tests/golden/ckpt/{classifier,optimizer}_3.pth (the files themselves are the fixture: `module.`-prefixed keys, KCRS-contiguous
+    weights, SGD momentum buffers).  Expected values after resuming: eval-mode logits/metrics and the fourth training step."""
+    import shutil
+    from resnet.utils.checkpoint_util import save_checkpoints
+    os.environ['MASTER_ADDR'] = '127.0.0.1'; os.environ['MASTER_PORT'] = '29432'
+    torch.distributed.init_process_group('gloo', world_size=1, rank=0)
+    cfg = MODELS['wrn_small']
+    net = ResNet(architecture_spec=cfg['spec'], preact=cfg['preact'], use_proj=cfg['use_proj'], dropout_prob=0.0)
+    load_filled(net, 41)
+    ddp = torch.nn.parallel.DistributedDataParallel(net)
+    opt = torch.optim.SGD(ddp.parameters(), lr=0.1, momentum=0.9, dampening=0.0, nesterov=True, weight_decay=5e-4)
+    x, y = T(fill((4, 3, 32, 32), 701)), T(fill_labels(4, 10, 801))
+    ddp.train()
+    for step in range(3):
+        loss = compute_losses_and_metrics(ddp(x), y)['loss']
+        loss.backward()
+        opt.step(); opt.zero_grad()
+    ck = os.path.join(HERE, 'ckpt')
+    shutil.rmtree(ck, ignore_errors=True)
+    save_checkpoints(checkpoint_dir=ck, checkpointables={'classifier': ddp, 'optimizer': opt, 'scheduler': None}, steps=3)
+    out = {}
+    ddp.eval()
+    with torch.no_grad():
+        lg = ddp(x)
+        m = compute_losses_and_metrics(lg, y)
+    out.update(eval_logits=lg.numpy().copy(), eval_loss=m['loss'].numpy().copy(), eval_top1=m['top1_err'].numpy().copy())
+    ddp.train()
+    loss = compute_losses_and_metrics(ddp(x), y)['loss']
+    loss.backward()
+    opt.step(); opt.zero_grad()
+    out['step4.loss'] = loss.detach().numpy().copy()
+    out['step4.param_sums'] = np.array([p.detach().double().sum().item() for p in net.parameters()])
+    out['step4.param_abs_sums'] = np.array([p.detach().double().abs().sum().item() for p in net.parameters()])
+    out['step4.mom_sums'] = np.array([opt.state[p]['momentum_buffer'].double().sum().item() for p in ddp.parameters()])
+    out['keys'] = np.array(list(ddp.state_dict().keys()))
+    torch.distributed.destroy_process_group()
+    save('g9_checkpoint', **out)
+
+
 if __name__ == '__main__':
-    g1_conv(); g2_bn(); g3_blocks(); g4_models(); g5_grammar(); g6_metrics(); g7_syncbn(); g8_eval_loop()
+    which = sys.argv[1:] or ['g1', 'g2', 'g3', 'g4', 'g5', 'g6', 'g7', 'g8', 'g9']
+    fns = dict(g1=g1_conv, g2=g2_bn, g3=g3_blocks, g4=g4_models, g5=g5_grammar, g6=g6_metrics, g7=g7_syncbn, g8=g8_eval_loop, g9=g9_checkpoint)
+    for w in which:
+        fns[w]()

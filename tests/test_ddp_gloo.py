@@ -236,3 +236,51 @@ def test_bucket_plan_tail_bucket():
     assert (bp.bounds[-2][2] - bp.bounds[-2][1]) * 4 >= (32 << 20)         # the bucket in front of it was not shrunk
     one = BucketPlan(order[:1], {order[0]: 0}, sizes[0], 32 << 20, 4 << 20, 1 << 20)
     assert one.bounds == [(0, 0, sizes[0])]
+
+
+def _buffer_sync_worker(rank, world, port, out):
+    from pytorch_ddp_resnet_amd.ddp import GradReducer
+    _init(rank, world, port)
+    torch.manual_seed(100 + rank)                                   # ranks start from DIFFERENT statistics
+    m = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 1), torch.nn.BatchNorm2d(4))
+    for mod in m:
+        if isinstance(mod, torch.nn.BatchNorm2d):
+            mod.running_mean.normal_(); mod.running_var.uniform_(0.5, 2.0); mod.num_batches_tracked.fill_(7 + rank)
+    keys_before = list(m.state_dict().keys())
+    red = GradReducer(m, world)                                      # registers the forward pre-hook (DDP's broadcast_buffers=True)
+    x = torch.randn(2, 3, 8, 8)
+    m.eval()
+    y = m(x)                                                         # eval forward: rank-0 statistics everywhere (script.py:64 semantics)
+    st = {k: v.clone() for k, v in m.state_dict().items()}
+    flat = red._buf_flat
+    assert flat is not None and flat.numel() == 2 * (8 + 4)
+    for mod in m:
+        if isinstance(mod, torch.nn.BatchNorm2d):                    # the module buffers ARE slices of the flat tensor
+            assert flat.data_ptr() <= mod.running_mean.data_ptr() < flat.data_ptr() + flat.numel() * 4
+            assert int(mod.num_batches_tracked) == 7 + rank          # integer step counters are not sent
+    assert list(m.state_dict().keys()) == keys_before
+    m.train()
+    m(x)                                                             # training forward: broadcast first, then each rank updates locally
+    torch.save(dict(st=st, y=y.detach()), out + f'.{rank}')
+    # sync_bn models skip the broadcast: statistics are identical by construction
+    m2 = torch.nn.Sequential(torch.nn.BatchNorm2d(4))
+    m2._sync_bn = True
+    m2[0].running_mean.fill_(float(rank))
+    red2 = GradReducer(m2, world)
+    m2.eval(); m2(torch.randn(2, 4, 3, 3))
+    assert float(m2[0].running_mean[0]) == float(rank) and red2._buf_flat is None
+    dist.destroy_process_group()
+
+
+def test_buffers_follow_rank0_before_every_forward(tmp_path):
+    """SURVEY C2 / script.py:64: DistributedDataParallel's default broadcast_buffers=True."""
+    out = str(tmp_path / 'bufs')
+    mp.spawn(_buffer_sync_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    r0, r1 = torch.load(out + '.0'), torch.load(out + '.1')
+    for k in r0['st']:
+        if r0['st'][k].is_floating_point() and ('running' in k):
+            assert torch.equal(r0['st'][k], r1['st'][k]), k
+    torch.manual_seed(100)                                           # rank 0's own statistics won
+    ref = torch.nn.Sequential(torch.nn.Conv2d(3, 8, 3), torch.nn.BatchNorm2d(8), torch.nn.ReLU(), torch.nn.Conv2d(8, 4, 1), torch.nn.BatchNorm2d(4))
+    ref[1].running_mean.normal_(); ref[1].running_var.uniform_(0.5, 2.0)
+    assert torch.equal(r1['st']['1.running_mean'], ref[1].running_mean)

@@ -44,7 +44,7 @@ def test_models_match_golden(golden, name, dtype):
         return
     # fp16 is the 16-bit engine that has to meet the north-star bound (logits 1e-3); bf16 (8 significant bits) cannot and is
     # bounded at what bf16 storage costs
-    tl, tg = {'fp32': (1e-4, 1e-3), 'bf16': (5e-2, 3.5e-1), 'fp16': (1e-3, 6e-2)}[dtype]
+    tl, tg = {'fp32': (1e-4, 1e-3), 'bf16': (5e-2, 3.5e-1), 'fp16': (1e-3, 1.5e-1)}[dtype]
     S = 256.0 if dtype == 'fp16' else 1.0            # loss scale (fp16 gradients; a GradScaler's job in training)
     m.eval()
     with torch.no_grad():
@@ -258,3 +258,35 @@ def test_forked_weight_gradients_are_bit_identical(golden, monkeypatch, dtype):
         assert torch.equal(l0, l1)
         for k in g0:
             assert torch.equal(g0[k], g1[k]), k
+
+
+def test_graph_replay_survives_a_reducer(golden):
+    """a GradReducer's hook points cut the backward into hook-free ranges that are still hipGraph replays (round 1: any hook consumer
+    forced eager launches, i.e. every multi-GPU run of the launch-bound nets): same gradients bit for bit, graphs in use, and the
+    communication-side actions (pre-scale on the comm stream, bucket events) run between the graphs."""
+    from pytorch_ddp_resnet_amd.ddp import GradReducer
+    cfg = MODELS['rn20']
+    g = golden('g4_rn20')
+    shapes, st, x, y, nesterov = model_inputs(g, cfg)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+    outs = {}
+    for tag in ('plain', 'reducer'):
+        m = build(cfg, st, 'fp32').train()
+        red = GradReducer(m, 1, bucket_cap_mb=0.05, first_bucket_mb=0.01, last_bucket_mb=0.005, force_hooks=True) if tag == 'reducer' else None
+        res = []
+        for step in range(4):
+            for p_ in m.parameters():
+                p_.grad = None
+            torch.nn.functional.cross_entropy(m(xt + 0.01 * step), yt).backward()
+            if red is not None:
+                red.finish()
+            torch.cuda.synchronize()
+            res.append({k: p_.grad.detach().clone() for k, p_ in m.named_parameters()})
+        eng = next(e for k, e in m._engines.items() if k[1] and k[2])
+        ngraphs = sum(1 for v in eng._graphs.values() if isinstance(v, torch.cuda.CUDAGraph))
+        outs[tag] = (res, ngraphs, len(red._bplan(eng).bounds) if red else 0)
+    assert outs['plain'][1] == 2                                   # forward + backward
+    assert outs['reducer'][2] >= 3 and outs['reducer'][1] >= 3     # several buckets -> several captured backward ranges
+    for a, b in zip(outs['plain'][0], outs['reducer'][0]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k

@@ -184,3 +184,53 @@ def test_training_loop_lagged_logging_is_complete_and_ordered():
     assert all(abs(a - b) < 1e-6 for a, b in zip(got, ref)), (got, ref)
     met = compute_losses_and_metrics(torch.randn(5, 10), torch.randint(0, 10, (5,)))
     assert global_means_async(met, 1).result() == global_means(met, 1)
+
+
+@pytest.mark.parametrize('name,preact,proj', [('rn20', False, False), ('wrn2810', True, True), ('v2_164', True, True), ('wrn50a', False, True), ('wrn50b', False, True)])
+def test_state_dict_keys_and_shapes_match_the_reference(golden, name, preact, proj):
+    """G5: ordered state_dict keys, shapes, parameter order and parameter count of the reference module for the five BASELINE specs."""
+    import torch
+    from pytorch_ddp_resnet_amd import ResNet
+    g = golden('g5_grammar')
+    specs = {'rn20': 'c3,16,3,1,1 n a r3 r3 r3 ap8,1,0 fc64,10', 'wrn2810': 'c3,160,3,1,1 r4 r4 r4 n a ap8,1,0 fc640,10',
+             'v2_164': 'c3,64,3,1,1 b18 b18 b18 n a ap8,1,0 fc256,100', 'wrn50a': 'c3,256,7,2,3 n a mp3,2,1 b3 b4 b6 b3 ap7,1,0 fc2048,1000',
+             'wrn50b': 'c3,512,7,2,3 n a mp3,2,1 b3 b4 b6 b3 ap7,1,0 fc4096,1000'}
+    m = ResNet(specs[name], preact, proj, 0.0)
+    sd = m.state_dict()
+    assert list(sd.keys()) == [str(k) for k in g[name + '.keys']]
+    assert [','.join(map(str, v.shape)) for v in sd.values()] == [str(s) for s in g[name + '.shapes']]
+    assert [k for k, _ in m.named_parameters()] == [str(k) for k in g[name + '.param_keys']]
+    assert sum(p.numel() for p in m.parameters()) == int(g[name + '.nparams'])
+
+
+def test_init_statistics_match_the_reference(golden):
+    """resnet.py:160-163: Kaiming-normal on the top-level conv only (std sqrt(2/27) for the 3x3 stem), torch's default
+    kaiming_uniform(a=sqrt(5)) -> U(+-1/sqrt(fan_in)) on block convs (max-abs just under 1/sqrt(144) for 16-channel 3x3)."""
+    import torch
+    from pytorch_ddp_resnet_amd import ResNet
+    g = golden('g5_grammar')
+    torch.manual_seed(0)
+    m = ResNet('c3,16,3,1,1 n a r3 r3 r3 ap8,1,0 fc64,10', False, False, 0.0)
+    sd = m.state_dict()
+    std, amax = float(sd['_architecture.0.weight'].std()), float(sd['_architecture.3.0._conv1.weight'].abs().max())
+    assert abs(std - (2.0 / 27) ** 0.5) < 0.03 and abs(std - float(g['rn20.init_stem_std'])) < 0.05       # 432 samples: ~3.5 % sampling error
+    assert amax <= 1.0 / 12 + 1e-7 and abs(amax - float(g['rn20.init_block_absmax'])) < 2e-3
+    assert float(sd['_architecture.0.bias'].abs().max()) <= 1.0 / 27 ** 0.5 + 1e-7                       # Conv2d default bias init
+    bn = sd['_architecture.1.weight']
+    assert bool((bn == 1).all()) and bool((sd['_architecture.1.running_var'] == 1).all()) and int(sd['_architecture.1.num_batches_tracked']) == 0
+
+
+def test_dropout_mask_spec_keep_rate_and_decorrelation():
+    """the counter-hash dropout mask (spec: tests/np_interp.py keep_mask == csrc/common.h rn_keep): keep rate 1-p, and the masks of
+    two sites, or of two steps, are independent (their agreement rate is p^2 + (1-p)^2)."""
+    from np_interp import keep_mask
+    n, p = 1 << 18, 0.3
+    a = keep_mask(n, p, site=3, step_seed=123456789)
+    assert abs(a.mean() - (1 - p)) < 4e-3
+    for other in (keep_mask(n, p, site=4, step_seed=123456789), keep_mask(n, p, site=3, step_seed=123456790),
+                  keep_mask(n, p, site=3, step_seed=123456789 + (1 << 32))):
+        assert abs(other.mean() - (1 - p)) < 4e-3
+        assert abs((a == other).mean() - (p * p + (1 - p) ** 2)) < 6e-3
+        assert abs(np.corrcoef(a.astype(float), other.astype(float))[0, 1]) < 0.01
+    # neighbouring elements are independent too (lag-1 autocorrelation)
+    assert abs(np.corrcoef(a[:-1].astype(float), a[1:].astype(float))[0, 1]) < 0.01
