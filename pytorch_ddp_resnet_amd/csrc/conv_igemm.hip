@@ -821,6 +821,200 @@ __global__ __launch_bounds__(512, BM >= 256 ? 1 : 2) void igemm_ws_kernel(const 
   igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 512>(a, acc, m0, n0, loader ? 0 : wave, lane, reinterpret_cast<float*>(&smem[0]), !loader);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// LDS-resident input patch for 3x3 stride-1 convolutions (forward and the stride-1 data gradient), 16-bit element types.
+//
+// Why: the implicit-GEMM kernels above are bound by the rate at which a CU can issue LDS-DMA instructions, not by the matrix
+// pipe (round-2 timing probes, WRN-28-10 stage 1: K loop with the DMAs alone 72 us, with the MFMAs alone 54 us, both 84 us;
+// a DMA whose 64 lanes are all out of range costs the same, so it is instruction issue, ~40 cycles per 1 KiB instruction and
+// CU, not memory).  An im2col tile loads every input pixel once per tap: (BM + BN) * 128 B per 64-deep K step.  Here the
+// input pixels a 256-pixel output tile needs (its rows plus a one-pixel halo, explicit zero pad columns) are loaded ONCE per
+// 64-channel chunk into LDS and read by all nine taps through a per-tap pixel offset; only the 20 KiB weight tile of the
+// (tap, chunk) step is streamed.  DMA instructions per FLOP: 13.7 -> 4.7 per MFLOP at 160 output channels.
+//
+// Tile: BM = 256 consecutive output pixels = whole image rows (H*W >= 256) or whole images (H*W < 256), BN output channels;
+// 8 waves, wave w owns tile rows 32w..32w+31 (one 32x32 MFMA row block, BN/32 column blocks): the igemm_epilogue above is
+// reused unchanged.  K loop: chunks of 64 channels x 9 taps; per step one weight tile (2-stage ring) and, during taps 0..6, one
+// eighth of the NEXT chunk's patch per wave (double-buffered patch); DMAs are issued between the k-steps' MFMA groups, waits
+// are counted, one raw s_barrier per step.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PATCH_PP_MAX = 400;                        // patch pixels (incl. halo and pad columns): 10x34, 18x18, 4 x 10x10
+template <typename T, int BN>
+__global__ __launch_bounds__(512, 2) void igemm_patch_kernel(const IgemmArgs a) {
+  constexpr int BM = 256, NW = 8, ES = (int)sizeof(T), TN = BN / 32;
+  constexpr int CHK = 128 / ES;                          // channels per chunk (one 128-byte LDS row per pixel)
+  constexpr int ASZ = PATCH_PP_MAX * 8;                  // uint4 per patch buffer
+  constexpr int BIT = BN / 8;                            // weight-tile DMA instructions (8 rows of 128 bytes each)
+  constexpr int BI = (BIT + NW - 1) / NW;                // per wave (the last one only for wave < BIT - (BI-1)*NW)
+  constexpr int BSZ = BN * 8;
+  constexpr int AI = 7;                                  // patch DMAs per wave and chunk: PATCH_PP_MAX / 8 = 50 <= 7 * 8
+  static_assert(ES == 2 && BN % 32 == 0 && PATCH_PP_MAX / 8 <= AI * NW && BI <= 3, "patch tile");
+  __shared__ uint4 smem[2 * ASZ + 2 * BSZ + TAP_INTS / 4];
+  int* taps = reinterpret_cast<int*>(&smem[2 * ASZ + 2 * BSZ]);
+
+  preload_args(a);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nmt = (a.M + BM - 1) / BM;
+  int bid = blockIdx.x;
+  if (a.xcd_remap) {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nnt_ = gridDim.x / nmt;
+  const int ntile = a.xcd_remap ? bid % nnt_ : bid / nmt, mt = a.xcd_remap ? bid / nnt_ : bid % nmt;
+  const int m0 = mt * BM, n0 = ntile * BN;
+  const int H = a.Hs, W = a.Ws, HW = H * W, W2 = W + 2;
+  // patch geometry (wave-uniform)
+  const bool multi = HW < BM;
+  const int n_first = m0 / HW;
+  const int h_first = multi ? 0 : (m0 - n_first * HW) / W;
+  const int slab_rows = multi ? H + 2 : BM / W + 2;
+  const int nimg = multi ? BM / HW : 1;
+  const int PP = nimg * slab_rows * W2;
+  const int nA = (PP + 7) >> 3;
+  const int nchunk = (a.Cs + CHK - 1) / CHK;
+  const int nstep = nchunk * 9;
+
+  const size_t img_bytes = (size_t)HW * a.Cs * ES;
+  const v4i32 ra_desc = make_desc(reinterpret_cast<const char*>(a.src) + (size_t)n_first * img_bytes, (size_t)(a.N - n_first) * img_bytes);
+  const v4i32 rb_desc = make_desc(a.wt, (size_t)a.Kd * a.wrs * a.Cs * ES);
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);
+
+  fill_tap_tables<ES>(a, taps);
+  __syncthreads();
+
+  // ---- per-lane DMA roles ----
+  const int l8 = lane >> 3, sl = lane & 7;
+  unsigned aoff[AI];                                     // source byte offset of this lane's 16 bytes at chunk 0 (OOB: zero fill)
+  int ach[AI];                                           // its logical 16-byte column inside the chunk (channel-tail check)
+#pragma unroll
+  for (int t = 0; t < AI; ++t) {
+    const int idx = t * NW + wave;
+    const int pp = idx * 8 + l8;
+    const int ch = sl ^ ((pp >> 1) & 7);
+    ach[t] = ch;
+    aoff[t] = OOB;
+    if (idx < nA && pp < PP) {
+      const int prow = pp / W2, pcol = pp - prow * W2;
+      const int img = prow / slab_rows, hr = prow - img * slab_rows;
+      const int h = h_first - 1 + hr, n = n_first + img;
+      if (pcol >= 1 && pcol <= W && h >= 0 && h < H && n < a.N)
+        aoff[t] = (unsigned)((((size_t)img * H + h) * W + (pcol - 1)) * a.Cs * ES + ch * 16);
+    }
+  }
+  unsigned boff[BI];
+  int bch[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int j = i * NW + wave;
+    const int rn = j * 8 + l8;
+    const int ch = sl ^ ((rn >> 1) & 7);
+    bch[i] = ch;
+    const int k = n0 + rn;
+    boff[i] = (j < BIT && k < a.Kd) ? (unsigned)((size_t)k * a.wrs * a.Cs * ES + ch * 16) : OOB;
+  }
+  // ---- per-lane fragment roles ----
+  const int lr = lane & 31, lh = lane >> 5;
+  int base_pp;
+  {
+    int m = m0 + wave * 32 + lr;
+    if (m >= a.M) m = a.M - 1;                           // rows past the end read some valid pixel; the epilogue drops them
+    const int n = m / HW, rem = m - n * HW;
+    const int h = rem / W, w = rem - h * W;
+    base_pp = ((n - n_first) * (multi ? slab_rows : 0) + (h - h_first) + 1) * W2 + w + 1;
+  }
+  const int bsw = (lr >> 1) & 7;                         // weight-tile swizzle of rows lr + 32 j (32 j does not change (row >> 1) & 7)
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  auto dma_a = [&](int t, int chunk, int buf) {          // this wave's t-th patch DMA of `chunk` into patch buffer `buf`
+    const int idx = t * NW + wave;
+    if (idx >= nA) return false;                         // wave-uniform
+    const bool ok = aoff[t] != OOB && chunk * 8 + ach[t] < a.cpt;
+    dma16(ra_desc, ok ? aoff[t] + (unsigned)(chunk * 128) : OOB, lds0 + (unsigned)((buf * ASZ) * 16 + idx * 1024));
+    return true;
+  };
+  auto dma_b = [&](int i, int chunk, int woff, int stg) {     // this wave's i-th weight DMA of step (chunk, tap) into ring stage `stg`
+    const int j = i * NW + wave;
+    if (j >= BIT) return false;                          // wave-uniform
+    const bool ok = boff[i] != OOB && chunk * 8 + bch[i] < a.cpt;
+    dma16(rb_desc, ok ? boff[i] + (unsigned)(woff + chunk * 128) : OOB, lds0 + (unsigned)((2 * ASZ + stg * BSZ) * 16 + j * 1024));
+    return true;
+  };
+  auto tap_woff = [&](int t) { return __builtin_amdgcn_readfirstlane(taps[64 + t]); };
+  auto tap_poff = [&](int t) {                           // pixel offset of tap t inside the patch: dh * (W + 2) + dw
+    const int v = __builtin_amdgcn_readfirstlane(taps[128 + t]);
+    return (v >> 16) * W2 + (int)(short)(v & 0xFFFF);
+  };
+
+  // ---- prologue: the whole patch of chunk 0 and the weight tile of step 0 ----
+  {
+    const unsigned keep = m0_save();
+#pragma unroll
+    for (int t = 0; t < AI; ++t) dma_a(t, 0, 0);
+    const int w0 = tap_woff(0);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) dma_b(i, 0, w0, 0);
+    m0_restore(keep);
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  int step = 0;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const uint4* Ab = &smem[(chunk & 1) * ASZ];
+    const int kcount = min(4, (a.cpt - chunk * 8 + 1) >> 1);    // 16-channel k-steps of this chunk that hold data
+    const bool more_chunks = chunk + 1 < nchunk;
+#pragma unroll
+    for (int t = 0; t < 9; ++t, ++step) {
+      const uint4* Bb = &smem[2 * ASZ + (step & 1) * BSZ];
+      const bool more = step + 1 < nstep;
+      const int nchunk_b = t == 8 ? chunk + 1 : chunk, ntap_b = t == 8 ? 0 : t + 1;
+      const int wnext = tap_woff(ntap_b);
+      const int pp = base_pp + tap_poff(t);
+      const int pa = pp * 8, sa = (pp >> 1) & 7;
+      bool a_issued = false;
+      uint4 fa[2], fb[2][TN];
+      fa[0] = Ab[pa + (lh ^ sa)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[0][j] = Bb[(lr + 32 * j) * 8 + (lh ^ bsw)];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < 4 && ks + 1 < kcount) {
+          const int ch = 2 * (ks + 1) + lh;
+          fa[nxt] = Ab[pa + (ch ^ sa)];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[nxt][j] = Bb[(lr + 32 * j) * 8 + (ch ^ bsw)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks < kcount) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur], fb[cur][j], acc[j]);
+        }
+        // one DMA behind each k-step's MFMA group: its issue overlaps the matrix pipe's work on the group just queued
+        {
+          const unsigned keep = m0_save();
+          if (ks < BI) { if (more) dma_b(ks, nchunk_b, wnext, (step + 1) & 1); }
+          else if (ks == 3 && t < AI && more_chunks) a_issued = dma_a(t, chunk + 1, (chunk + 1) & 1);
+          m0_restore(keep);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // the next step's weight tile (and, at the last taps, the whole next patch) must have landed for every wave; the patch DMA
+      // issued in this step may stay in flight
+      if (a_issued) wait_vmcnt<1>(); else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  igemm_epilogue<T, BM, BN, NW, 1, 1, TN, 512, 64>(a, reinterpret_cast<f32x16(&)[1][TN]>(acc), m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
+}
+
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   int nmt = cdiv(a.M, BM), nnt = cdiv(a.Kd, BN);
@@ -840,9 +1034,41 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   return 0;
 }
 
+// geometry the LDS-patch kernel covers: 3x3 taps of a same-size stride-1 convolution (forward or data gradient), tiles of whole
+// image rows / whole images, a patch that fits its LDS buffer, and a grid that keeps at least 3/4 of the CUs busy
+static bool patch_ok(const IgemmArgs& a, int BN) {
+  if (g_rn_variant & 2) return false;                    // A/B switch: 2 = never use the patch kernel
+  if (a.nt != 9 || a.nth != 3 || a.ntw != 3 || a.ss != 1 || a.ds != 1 || a.Hs != a.Pc || a.Ws != a.Qc || a.Cs < 64) return false;
+  for (int t = 0; t < 9; ++t)
+    if (a.dh[t] < -1 || a.dh[t] > 1 || a.dw[t] < -1 || a.dw[t] > 1) return false;
+  const int HW = a.Hs * a.Ws;
+  int pp;
+  if (HW >= 256) {
+    if (HW % 256 || 256 % a.Ws) return false;
+    pp = (256 / a.Ws + 2) * (a.Ws + 2);
+  } else {
+    if (256 % HW) return false;
+    pp = (256 / HW) * (a.Hs + 2) * (a.Ws + 2);
+  }
+  if (pp > PATCH_PP_MAX) return false;
+  return (g_rn_variant & 16) || (long)cdiv(a.M, 256) * cdiv(a.Kd, BN) >= 192;     // 16: any grid (tests of small geometries)
+}
+
+template <typename T, int BN> int launch_patch(const IgemmArgs& a, hipStream_t s) {
+  rn_note_kernel("igemm_patch<256x%d>", BN);
+  if (rn_dry_run()) return 0;
+  hipLaunchKernelGGL((igemm_patch_kernel<T, BN>), dim3(cdiv(a.M, 256) * cdiv(a.Kd, BN)), dim3(512), 0, s, a);
+  RN_CHECK_LAUNCH("igemm_patch");
+  return 0;
+}
+
 template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   const int K = a.Kd;
+  if constexpr (sizeof(T) == 2) {
+    if (K % 160 == 0 && patch_ok(a, 160)) return launch_patch<T, 160>(a, s);
+    if (K % 160 != 0 && K % 128 == 0 && patch_ok(a, 128)) return launch_patch<T, 128>(a, s);
+  }
   // column tile: the widest of {160,128,96,64,32} that wastes no 32-column MFMA tile.  256-row tiles were measured and removed:
   // 4 consumer + 4 loader waves of 64 x BN, or 8 homogeneous waves with a 3-stage ring (one workgroup per CU): 5-12 % slower on
   // the WRN-28-10 shapes; 4 waves of 64 x BN with 64-byte K rows at two workgroups per CU (28 % fewer DMAs and 42 % fewer

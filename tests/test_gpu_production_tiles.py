@@ -145,12 +145,30 @@ def test_both_schedules_on_small_tiles(g, variant, dtype):
     assert all(('igemm_ws' in n) == (variant == 128) for n in ran if n.startswith('igemm_') and '256x32' not in n), ran
 
 
+PATCH_SMALL = [
+    (3, 8, 8, 160, 160, 3, 1, 1),        # 4 images per tile, only 3 exist: tile tail, image-validity of the patch DMAs
+    (5, 16, 16, 64, 128, 3, 1, 1),       # one image per tile, BN = 128, a single channel chunk
+    (2, 32, 32, 96, 160, 3, 1, 1),       # 8 rows per tile, 1.5 channel chunks (the half chunk runs two of four k-steps)
+    (1, 16, 16, 72, 320, 3, 1, 1),       # 72 channels: the tail chunk holds ONE 16-byte column (k-step half empty); two column tiles
+    (9, 8, 8, 128, 128, 3, 1, 1),        # 9 images of 8x8: 2.25 tiles (tile tail), BN = 128
+    (2, 64, 64, 64, 160, 3, 1, 1),       # 4 rows of 64 per tile
+]
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('g', PATCH_SMALL)
+def test_patch_kernel_on_small_geometries(g, dtype):
+    """the LDS-patch 3x3 kernel (forward AND data gradient) on shapes that exercise its tails; variant 16 lifts its minimum-grid rule."""
+    ran = run_conv_case(g, dtype, variant=16, expect_same_names=False)
+    assert sum(n.startswith('igemm_patch') for n in ran) == 2, ran          # forward and dgrad both took it
+
+
 def test_production_set_reaches_every_instantiation():
     """sanity of the list itself: the names it selects include both schedules and the wide tiles."""
     names = set()
     for g in PROD_GEOMS:
         for ps in range(3):
             names.update(_lib.conv_kernel_names(ps, ir.RN_BF16, geom(*resolve(g, False)), True))
-    for need in ('igemm_dma<128x160>', 'igemm_ws<128x160>', 'igemm_dma<128x128>', 'igemm_dma<256x32>', 'wgrad<160x160>', 'wgrad<128x128>',
+    for need in ('igemm_patch<256x160>', 'igemm_dma<128x160>', 'igemm_ws<128x160>', 'igemm_dma<128x128>', 'igemm_dma<256x32>', 'wgrad<160x160>', 'wgrad<128x128>',
                  'wgrad_reduce', 'wgrad_reduce_wide'):
         assert need in names, (need, sorted(names))
