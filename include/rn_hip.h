@@ -221,7 +221,8 @@ int rn_bn_bwd_apply(const void* dout, const void* x, const void* mask_src, const
                     rn_stream s);
 
 int rn_dropout_fwd(const void* x, void* out, int dtype, int64_t n, float p, uint32_t site, uint64_t step_seed, rn_stream s);
-int rn_dropout_bwd(const void* dout, const void* out, void* din, int dtype, int64_t n, float p, rn_stream s);
+/* din = dout * [keep(site, step_seed, index)] / (1-p): the mask is recomputed from the counter hash of the forward */
+int rn_dropout_bwd(const void* dout, void* din, int dtype, int64_t n, float p, uint32_t site, uint64_t step_seed, rn_stream s);
 /* dst[n,h,w,c] += res (RN_RES_* mapping) */
 int rn_add_res(void* dst, const void* res, int dtype, int N, int H, int W, int C, int res_mode, int res_C, rn_stream s);
 

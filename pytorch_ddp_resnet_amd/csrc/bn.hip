@@ -324,15 +324,16 @@ __global__ __launch_bounds__(NT) void dropout_fwd_kernel(const T* __restrict__ x
   }
 }
 
+// the keep mask is RECOMPUTED from the counter hash (site, step seed, element index), never inferred from the forward output: a kept
+// element whose input was exactly 0 (a stem without ReLU in front, fp16 underflow) must still pass its gradient
 template <typename T>
-__global__ __launch_bounds__(NT) void dropout_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ out, T* __restrict__ din, long nchunks,
-                                                         float inv_keep) {
+__global__ __launch_bounds__(NT) void dropout_bwd_kernel(const T* __restrict__ dout, T* __restrict__ din, long nchunks, float inv_keep, uint32_t key,
+                                                         uint32_t thr) {
   constexpr int CE = Elem<T>::CE;
   for (long i = (long)blockIdx.x * NT + threadIdx.x; i < nchunks; i += (long)gridDim.x * NT) {
     Chunk<T> d = load_chunk<T>(dout + i * CE);
-    Chunk<T> o = load_chunk<T>(out + i * CE);
 #pragma unroll
-    for (int e = 0; e < CE; ++e) d.e[e] = Elem<T>::from_f(Elem<T>::to_f(o.e[e]) != 0.f ? Elem<T>::to_f(d.e[e]) * inv_keep : 0.f);
+    for (int e = 0; e < CE; ++e) d.e[e] = Elem<T>::from_f(rn_keep(key, (uint32_t)(i * CE + e), thr) ? Elem<T>::to_f(d.e[e]) * inv_keep : 0.f);
     store_chunk<T>(din + i * CE, d);
   }
 }
@@ -523,12 +524,13 @@ extern "C" int rn_dropout_fwd(const void* x, void* out, int dtype, int64_t n, fl
   return 0;
 }
 
-extern "C" int rn_dropout_bwd(const void* dout, const void* out, void* din, int dtype, int64_t n, float p, rn_stream s) {
-  RN_CHECK_ARG(dout && out && din && p > 0.f && p < 1.f && n > 0, "rn_dropout_bwd: bad argument");
+extern "C" int rn_dropout_bwd(const void* dout, void* din, int dtype, int64_t n, float p, uint32_t site, uint64_t step_seed, rn_stream s) {
+  RN_CHECK_ARG(dout && din && p > 0.f && p < 1.f && n > 0 && n < (1L << 32), "rn_dropout_bwd: bad argument");
   const int ce = dtype == RN_F32 ? 4 : 8;
   RN_CHECK_ARG(n % ce == 0, "rn_dropout_bwd: n must be a multiple of %d", ce);
   const long nchunks = n / ce;
-  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((dropout_bwd_kernel<T_>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const T_*)dout, (const T_*)out, (T_*)din, nchunks, 1.f / (1.f - p)));
+  const uint32_t thr = rn_drop_threshold(p), key = rn_drop_key(site, step_seed);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((dropout_bwd_kernel<T_>), dim3(ew_grid(nchunks)), dim3(NT), 0, as_stream(s), (const T_*)dout, (T_*)din, nchunks, 1.f / (1.f - p), key, thr));
   RN_CHECK_LAUNCH("dropout_bwd");
   return 0;
 }

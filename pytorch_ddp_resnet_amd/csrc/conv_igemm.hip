@@ -59,6 +59,7 @@ struct IgemmArgs {
   unsigned probe_mask;     // timing probe (rn_set_variant bit6): AND-mask on DMA source offsets, 0xFFFFFFFF in production
   unsigned long long* stamps;   // diagnostic: per-workgroup s_memtime stamps [grid][16] (rn_set_stamp_buffer), NULL in production
   int probe_ep;            // timing probes: 1 = skip the global stores of the epilogue, 2 = skip the epilogue
+  int patch_mode;          // igemm_patch_kernel schedule switches (A/B through rn_set_variant): bit 0 = waves 4..7 issue their DMAs BEFORE the MFMA group
   int probe_k;             // K-loop timing probes (igemm_dma_kernel): 1 = DMA only (no fragment reads / MFMA), 2 = no DMA, 3 = every DMA out of range
   int xcd_remap;           // 1: blockIdx -> tile through the bijective XCD remap, column tiles fastest
   int dense_src;           // 1: one tap at offset (0,0), unit stride, source grid == compute grid (1x1 convolutions): row m reads pixel m
@@ -74,7 +75,7 @@ __device__ inline void preload_args(const IgemmArgs& a) {
   RN_TOUCH(a.nt); RN_TOUCH(a.wrs); RN_TOUCH(a.cpt); RN_TOUCH(a.nk); RN_TOUCH(a.nth); RN_TOUCH(a.ntw);
   RN_TOUCH(a.magic_pq); RN_TOUCH(a.magic_q); RN_TOUCH(a.accum); RN_TOUCH(a.tile_base);
   RN_TOUCH(a.stats); RN_TOUCH(a.bn_x); RN_TOUCH(a.bn_mask); RN_TOUCH(a.bn_coef); RN_TOUCH(a.bias); RN_TOUCH(a.gscale);
-  RN_TOUCH(a.probe_mask); RN_TOUCH(a.stamps); RN_TOUCH(a.probe_ep); RN_TOUCH(a.xcd_remap); RN_TOUCH(a.dense_src); RN_TOUCH(a.probe_k);
+  RN_TOUCH(a.probe_mask); RN_TOUCH(a.stamps); RN_TOUCH(a.probe_ep); RN_TOUCH(a.xcd_remap); RN_TOUCH(a.dense_src); RN_TOUCH(a.probe_k); RN_TOUCH(a.patch_mode);
 #undef RN_TOUCH
 }
 
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(512, 2) void igemm_patch_kernel(const IgemmArgs a) 
   __shared__ uint4 smem[2 * ASZ + 2 * BSZ + TAP_INTS / 4];
   int* taps = reinterpret_cast<int*>(&smem[2 * ASZ + 2 * BSZ]);
 
-  preload_args(a);
+  // (no preload_args here: the K loop keeps ~30 wave-uniform values live; holding every argument in SGPRs as well spills them)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nmt = (a.M + BM - 1) / BM;
@@ -993,17 +994,25 @@ __global__ __launch_bounds__(512, 2) void igemm_patch_kernel(const IgemmArgs a) 
           for (int j = 0; j < TN; ++j) fb[nxt][j] = Bb[(lr + 32 * j) * 8 + (ch ^ bsw)];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ks < kcount) {
+        // one DMA per k-step.  The two waves of a SIMD (w and w + 4) run the same program in lockstep: if both issued their DMA at the
+        // same point, all eight would queue at the texture addresser while the matrix pipe idles.  Waves 0..3 issue BEHIND the MFMA
+        // group, waves 4..7 IN FRONT of it: one wave of each SIMD feeds the matrix pipe while the other waits for its DMA to issue.
+#define RN_PATCH_ISSUE()                                                                                     \
+  if (a.probe_k != 2) {                                                                                      \
+    const unsigned keep = m0_save();                                                                         \
+    if (ks < BI) { if (more) dma_b(ks, nchunk_b, wnext, (step + 1) & 1); }                                    \
+    else if (ks == 3 && t < AI && more_chunks) a_issued = dma_a(t, chunk + 1, (chunk + 1) & 1);             \
+    m0_restore(keep);                                                                                        \
+  }
+        const bool early = (a.patch_mode & 1) && wave >= 4;
+        if (early) { RN_PATCH_ISSUE() }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks < kcount && a.probe_k != 1) {
 #pragma unroll
           for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur], fb[cur][j], acc[j]);
         }
-        // one DMA behind each k-step's MFMA group: its issue overlaps the matrix pipe's work on the group just queued
-        {
-          const unsigned keep = m0_save();
-          if (ks < BI) { if (more) dma_b(ks, nchunk_b, wnext, (step + 1) & 1); }
-          else if (ks == 3 && t < AI && more_chunks) a_issued = dma_a(t, chunk + 1, (chunk + 1) & 1);
-          m0_restore(keep);
-        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (!early) { RN_PATCH_ISSUE() }
         __builtin_amdgcn_sched_barrier(0);
       }
       // the next step's weight tile (and, at the last taps, the whole next patch) must have landed for every wave; the patch DMA
@@ -1012,6 +1021,7 @@ __global__ __launch_bounds__(512, 2) void igemm_patch_kernel(const IgemmArgs a) 
       __builtin_amdgcn_s_barrier();
     }
   }
+#undef RN_PATCH_ISSUE
   igemm_epilogue<T, BM, BN, NW, 1, 1, TN, 512, 64>(a, reinterpret_cast<f32x16(&)[1][TN]>(acc), m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
 }
 
@@ -1134,6 +1144,7 @@ static void fill_ep(IgemmArgs& a, const rn_conv_epilogue* ep, int tile_base) {
   a.probe_mask = (g_rn_variant & 64) ? 0x0000FFF0u : 0xFFFFFFFFu;
   a.stamps = reinterpret_cast<unsigned long long*>(g_rn_stamps);
   a.xcd_remap = (g_rn_variant & 8) ? 0 : 1;
+  a.patch_mode = (g_rn_variant & (1 << 17)) ? 0 : 1;      // 1 << 17: lockstep DMA placement (A/B)
   a.probe_k = (g_rn_variant & 1024) ? 1 : ((g_rn_variant & 2048) ? 2 : ((g_rn_variant & 4096) ? 3 : 0));
   a.probe_ep = (g_rn_variant & 8192) ? 1 : ((g_rn_variant & 16384) ? 2 : ((g_rn_variant & 32768) ? 3 : ((g_rn_variant & 65536) ? 4 : 0)));
 }

@@ -260,7 +260,7 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
       return rn_stem_conv_wgrad((const float*)B(0), B(1), dt, (float*)B(2), (float*)B(3), B(4), (o.flags & RN_F_ACCUM) ? 1 : 0, &g, s);
     }
     case RN_OP_DROPOUT_BWD:
-      return rn_dropout_bwd(B(0), B(1), B(2), dt, ((int64_t)d[1] << 31) | (int64_t)d[0], o.fp[0], s);
+      return rn_dropout_bwd(B(0), B(2), dt, ((int64_t)d[1] << 31) | (int64_t)d[0], o.fp[0], o.seed, step_seed, s);
     case RN_OP_SOFTMAX_CE:
       return rn_softmax_ce((const float*)B(0), (const int64_t*)B(1), (float*)B(2), (float*)B(3), d[0], d[1], o.fp[0], (const float*)B(4), s);
     case RN_OP_ZERO: {

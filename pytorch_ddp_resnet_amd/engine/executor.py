@@ -99,6 +99,7 @@ class Engine:
         self._graphs = {}
         self._profiling = False
         self._loss_scratch = None
+        self._xbuf = None
 
     def loss_scratch(self, i):
         """two 4-float device scratch rows for the fused loss kernel (forward sums / backward by-product)."""
@@ -131,7 +132,15 @@ class Engine:
             elif s.role == 'input' and x is not None:
                 if tuple(x.shape) != s.shape or x.dtype != torch.float32 or not x.is_contiguous() or x.device != self.device:
                     raise _lib.RnError(f"input must be a contiguous float32 NCHW tensor of shape {s.shape} on {self.device}")
-                self.tensors[i] = x
+                if self.use_graphs:
+                    # a captured range reads fixed addresses: a training loop hands over a NEW tensor every step (training.py:94
+                    # x.to(device)), which would invalidate the graphs each time -- the batch is copied into an engine-owned buffer
+                    if self._xbuf is None:
+                        self._xbuf = torch.empty_like(x)
+                    self._xbuf.copy_(x)
+                    self.tensors[i] = self._xbuf
+                else:
+                    self.tensors[i] = x
             elif s.role == 'labels' and labels is not None:
                 self.tensors[i] = labels
             t = self.tensors[i]

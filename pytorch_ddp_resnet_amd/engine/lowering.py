@@ -360,7 +360,7 @@ class Lowering:
                 x0 = self.act(f'{bp}.x0', i.N, i.H, i.W, i.C)
                 self.fwd.append(Op(ir.OP_DROPOUT_FWD, buf=dict(x=i.s, out=x0.s), dim=dict(n_lo=i.M * i.C & 0x7fffffff, n_hi=(i.M * i.C) >> 31),
                                    fp=dict(p=self.p), seed=self._site, note=bp))
-                x, p_in = x0, self.p
+                x, p_in, site_in = x0, self.p, self._site
             h = None
             for j, (ci, co, k, s, pd) in enumerate(convs, 1):
                 y, g, wd = self.conv_fwd(x, f'{bp}._conv{j}.weight', co, k, s, pd, f'{bp}.y{j}')
@@ -411,7 +411,7 @@ class Lowering:
                             t = self.conv_bwd(ops, r['x'], dy, f'{bp}._conv{j}.weight', r['g'], r['wd'], f'{bp}.dx0')
                             gcur = self.act(f'{bp}.di', i.N, i.H, i.W, i.C)
                             ops.append(Op(ir.OP_DROPOUT_BWD, buf=dict(dout=t.s, out=r['x'].s, din=gcur.s),
-                                          dim=dict(n_lo=i.M * i.C & 0x7fffffff, n_hi=(i.M * i.C) >> 31), fp=dict(p=p_in), note=bp))
+                                          dim=dict(n_lo=i.M * i.C & 0x7fffffff, n_hi=(i.M * i.C) >> 31), fp=dict(p=p_in), seed=site_in, note=bp))
                             if res is not None:
                                 ops.append(Op(ir.OP_ADD_RES, buf=dict(dst=gcur.s, res=res.s),
                                               dim=dict(N=i.N, H=i.H, W=i.W, C=i.C, res_mode=mode, res_C=res.C), note=bp))

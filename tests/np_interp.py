@@ -171,8 +171,8 @@ class NumpyPlan:
             x, p = B('x'), op.fp['p']
             put('out', x * keep_mask(x.size, p, op.seed, step_seed).reshape(x.shape) / (1.0 - p))
         elif k == ir.OP_DROPOUT_BWD:
-            p = op.fp['p']
-            put('din', B('dout') * (B('out') != 0) / (1.0 - p))
+            p, g = op.fp['p'], B('dout')
+            put('din', g * keep_mask(g.size, p, op.seed, step_seed).reshape(g.shape) / (1.0 - p))      # the hash, not (out != 0): exact zeros keep their gradient
         elif k == ir.OP_ADD_RES:
             put('dst', B('dst') + res_read(B('res'), d['res_mode'], d['N'], d['H'], d['W'], d['C']))
         elif k == ir.OP_MAXPOOL_FWD:

@@ -338,3 +338,20 @@ def test_sgd_step_matches_torch():
         _lib.check(L.rn_sgd_step(p.data_ptr(), g.data_ptr(), buf.data_ptr(), n, 0.1, 0.9, 0.0, 5e-4, 1, int(step == 0), 1.0, st))
     torch.cuda.synchronize()
     assert (p - pt.detach()).abs().max().item() < 1e-6
+
+
+@pytest.mark.parametrize('fp32', DT)
+def test_dropout_backward_recomputes_the_mask_from_the_hash(fp32):
+    """a kept element whose forward input was exactly 0 still passes its gradient (the mask is the counter hash, not out != 0)."""
+    h = H()
+    n = 4 * 8 * 8 * 16
+    b = h.PlanBuilder()
+    x = b.slot('x', (4, 8, 8, 16)); out = b.slot('out', (4, 8, 8, 16)); dout = b.slot('dout', (4, 8, 8, 16)); din = b.slot('din', (4, 8, 8, 16))
+    b.op(ir.OP_DROPOUT_FWD, buf=dict(x=x, out=out), dim=dict(n_lo=n, n_hi=0), fp=dict(p=0.3), seed=7)
+    b.op(ir.OP_DROPOUT_BWD, buf=dict(dout=dout, out=out, din=din), dim=dict(n_lo=n, n_hi=0), fp=dict(p=0.3), seed=7)
+    xv = fill((4, 8, 8, 16), 91)
+    xv[:, :4] = 0.0                                   # exact zeros in the forward input
+    hip, ref = h.run_both(b.plan(fp32), dict(x=xv, dout=fill((4, 8, 8, 16), 92, 1.0, 2.0)), fp32, step_seed=424242)
+    assert h.max_rel(hip['out'], ref['out']) < TOL[fp32] and h.max_rel(hip['din'], ref['din']) < TOL[fp32]
+    kept_zero = (hip['din'] != 0) & (np.broadcast_to(xv == 0, hip['din'].shape))
+    assert kept_zero.mean() > 0.3                     # ~70 % of the zero-input elements are kept and carry gradient

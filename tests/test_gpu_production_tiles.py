@@ -147,11 +147,11 @@ def test_both_schedules_on_small_tiles(g, variant, dtype):
 
 PATCH_SMALL = [
     (3, 8, 8, 160, 160, 3, 1, 1),        # 4 images per tile, only 3 exist: tile tail, image-validity of the patch DMAs
-    (5, 16, 16, 64, 128, 3, 1, 1),       # one image per tile, BN = 128, a single channel chunk
-    (2, 32, 32, 96, 160, 3, 1, 1),       # 8 rows per tile, 1.5 channel chunks (the half chunk runs two of four k-steps)
-    (1, 16, 16, 72, 320, 3, 1, 1),       # 72 channels: the tail chunk holds ONE 16-byte column (k-step half empty); two column tiles
+    (5, 16, 16, 128, 128, 3, 1, 1),      # one image per tile, BN = 128 (forward and dgrad), two channel chunks
+    (2, 32, 32, 160, 160, 3, 1, 1),      # 8 rows per tile, 2.5 channel chunks (the half chunk runs two of four k-steps)
+    (1, 16, 16, 320, 320, 3, 1, 1),      # five channel chunks, two column tiles
     (9, 8, 8, 128, 128, 3, 1, 1),        # 9 images of 8x8: 2.25 tiles (tile tail), BN = 128
-    (2, 64, 64, 64, 160, 3, 1, 1),       # 4 rows of 64 per tile
+    (2, 64, 64, 160, 160, 3, 1, 1),      # 4 rows of 64 per tile
 ]
 
 
@@ -161,6 +161,14 @@ def test_patch_kernel_on_small_geometries(g, dtype):
     """the LDS-patch 3x3 kernel (forward AND data gradient) on shapes that exercise its tails; variant 16 lifts its minimum-grid rule."""
     ran = run_conv_case(g, dtype, variant=16, expect_same_names=False)
     assert sum(n.startswith('igemm_patch') for n in ran) == 2, ran          # forward and dgrad both took it
+
+
+@pytest.mark.parametrize('g', [(4, 16, 16, 72, 160, 3, 1, 1), (4, 16, 16, 96, 160, 3, 1, 1)])
+def test_patch_kernel_channel_tails(g):
+    """forward only reaches the patch kernel here (the data gradient has 72 / 96 output channels): a tail chunk that holds ONE 16-byte
+    column (k-step half empty) and one that holds half a chunk."""
+    ran = run_conv_case(g, 'fp16', variant=16, expect_same_names=False)
+    assert ran[0].startswith('igemm_patch'), ran
 
 
 def test_production_set_reaches_every_instantiation():
