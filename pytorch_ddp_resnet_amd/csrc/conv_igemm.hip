@@ -1044,24 +1044,227 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same idea at the proven occupancy of igemm_dma_kernel: 128-pixel tiles, 4 waves, TWO workgroups per CU (each hides the
+// other's prologue, epilogue and DMA latency).  Channels advance in chunks of 32 (64-byte LDS rows): the patch of a chunk is
+// 208 pixels x 64 B = 13 KiB, double-buffered; a K step is TWO (chunk, tap) units = 2 x BN x 64 B of weights in a 2-stage ring,
+// i.e. the same 20 MFMAs per wave and barrier as the im2col kernel with 6 instead of 9 DMA instructions per wave.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int PATCH128_PP_MAX = 208;                     // 6x34 (W=32), 10x18 (W=16), 2 x 10x10 (W=8)
+template <typename T, int BN>
+__global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs a) {
+  constexpr int BM = 128, NW = 4, ES = (int)sizeof(T), TN = BN / 32;
+  constexpr int CHK = 64 / ES;                           // channels per chunk (one 64-byte LDS row per pixel)
+  constexpr int ASZ = PATCH128_PP_MAX * 4;               // uint4 per patch buffer
+  constexpr int UIT = BN / 16;                           // weight DMA instructions per unit (16 rows of 64 bytes each)
+  constexpr int BIT = 2 * UIT;                           // per step (two units)
+  constexpr int BI = (BIT + NW - 1) / NW;                // per wave
+  constexpr int BSZ = 2 * BN * 4;                        // uint4 per ring stage
+  constexpr int AI = 4;                                  // patch DMAs per wave and chunk: 13 <= 4 * 4
+  static_assert(ES == 2 && BN % 32 == 0 && BIT % NW == 0 && (PATCH128_PP_MAX + 15) / 16 <= AI * NW, "patch128 tile");
+  __shared__ uint4 smem[2 * ASZ + 2 * BSZ + TAP_INTS / 4];
+  int* taps = reinterpret_cast<int*>(&smem[2 * ASZ + 2 * BSZ]);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nmt = (a.M + BM - 1) / BM;
+  int bid = blockIdx.x;
+  if (a.xcd_remap) {
+    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int nnt_ = gridDim.x / nmt;
+  const int ntile = a.xcd_remap ? bid % nnt_ : bid / nmt, mt = a.xcd_remap ? bid / nnt_ : bid % nmt;
+  const int m0 = mt * BM, n0 = ntile * BN;
+  const int H = a.Hs, W = a.Ws, HW = H * W, W2 = W + 2;
+  const bool multi = HW < BM;
+  const int n_first = m0 / HW;
+  const int h_first = multi ? 0 : (m0 - n_first * HW) / W;
+  const int slab_rows = multi ? H + 2 : BM / W + 2;
+  const int nimg = multi ? BM / HW : 1;
+  const int PP = nimg * slab_rows * W2;
+  const int nA = (PP + 15) >> 4;
+  const int cpt4 = a.Cs * ES / 16;                       // 16-byte columns per pixel
+  const int nchunk = (a.Cs + CHK - 1) / CHK;
+  const int U = nchunk * 9, nstep = (U + 1) >> 1;
+
+  const size_t img_bytes = (size_t)HW * a.Cs * ES;
+  const v4i32 ra_desc = make_desc(reinterpret_cast<const char*>(a.src) + (size_t)n_first * img_bytes, (size_t)(a.N - n_first) * img_bytes);
+  const v4i32 rb_desc = make_desc(a.wt, (size_t)a.Kd * a.wrs * a.Cs * ES);
+  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);
+
+  fill_tap_tables<ES>(a, taps);
+  __syncthreads();
+
+  // ---- per-lane DMA roles (16 rows of 64 bytes per instruction: lane -> row lane / 4, 16-byte slot lane % 4) ----
+  const int l4 = lane >> 2, sl = lane & 3;
+  unsigned aoff[AI];
+  int ach[AI];
+#pragma unroll
+  for (int t = 0; t < AI; ++t) {
+    const int idx = t * NW + wave;
+    const int pp = idx * 16 + l4;
+    const int ch = sl ^ ((pp >> 2) & 3);
+    ach[t] = ch;
+    aoff[t] = OOB;
+    if (idx < nA && pp < PP) {
+      const int prow = pp / W2, pcol = pp - prow * W2;
+      const int img = prow / slab_rows, hr = prow - img * slab_rows;
+      const int h = h_first - 1 + hr, n = n_first + img;
+      if (pcol >= 1 && pcol <= W && h >= 0 && h < H && n < a.N)
+        aoff[t] = (unsigned)((((size_t)img * H + h) * W + (pcol - 1)) * a.Cs * ES + ch * 16);
+    }
+  }
+  unsigned boff[BI];                                     // slot j = i * NW + wave: unit j / UIT of the step, rows 16 * (j % UIT) ..
+  int bch[BI];
+#pragma unroll
+  for (int i = 0; i < BI; ++i) {
+    const int j = i * NW + wave;
+    const int rn = (j % UIT) * 16 + l4;
+    const int ch = sl ^ ((rn >> 2) & 3);
+    bch[i] = ch;
+    const int k = n0 + rn;
+    boff[i] = k < a.Kd ? (unsigned)((size_t)k * a.wrs * a.Cs * ES + ch * 16) : OOB;
+  }
+  const int lr = lane & 31, lh = lane >> 5;
+  int base_pp;
+  {
+    int m = m0 + wave * 32 + lr;
+    if (m >= a.M) m = a.M - 1;
+    const int n = m / HW, rem = m - n * HW;
+    const int h = rem / W, w = rem - h * W;
+    base_pp = ((n - n_first) * (multi ? slab_rows : 0) + (h - h_first) + 1) * W2 + w + 1;
+  }
+  const int bsw = (lr >> 2) & 3;
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  auto dma_a = [&](int t, int chunk, int buf) {
+    const int idx = t * NW + wave;
+    if (idx >= nA) return false;                         // wave-uniform
+    const bool ok = aoff[t] != OOB && chunk * 4 + ach[t] < cpt4;
+    dma16(ra_desc, ok ? aoff[t] + (unsigned)(chunk * 64) : OOB, lds0 + (unsigned)((buf * ASZ) * 16 + idx * 1024));
+    return true;
+  };
+  // weight DMA slot i of the step whose first unit is (c0, t0): units beyond the last one load zeros (never multiplied)
+  auto dma_b = [&](int i, int c0, int t0, int stg) {
+    const int j = i * NW + wave;
+    const int second = j >= UIT ? 1 : 0;                 // wave-uniform
+    int c = c0, t = t0 + second;
+    if (t == 9) { t = 0; ++c; }
+    const bool ok = c < nchunk && boff[i] != OOB && c * 4 + bch[i] < cpt4;
+    const int woff = __builtin_amdgcn_readfirstlane(taps[64 + t]);
+    dma16(rb_desc, ok ? boff[i] + (unsigned)(woff + c * 64) : OOB, lds0 + (unsigned)((2 * ASZ + stg * BSZ) * 16 + j * 1024));
+  };
+
+  {
+    const unsigned keep = m0_save();
+#pragma unroll
+    for (int t = 0; t < AI; ++t) dma_a(t, 0, 0);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) dma_b(i, 0, 0, 0);
+    m0_restore(keep);
+  }
+  wait_vmcnt<0>();
+  __builtin_amdgcn_s_barrier();
+
+  // Patch of chunk c + 1: its buffer held chunk c - 1, last read in step S0(c) - 1, S0(c) = (9c + 1) / 2; chunk c + 1 is first
+  // multiplied in step S0(c) + 4.  So the window is the four steps S0(c) .. S0(c) + 3, one DMA per wave and step, all landed at the
+  // end of the last one.  (c = chunk of the step's first unit: step >= S0(c) always.)
+  int c0 = 0, t0 = 0;                                    // (chunk, tap) of the step's first unit
+  for (int step = 0; step < nstep; ++step) {
+    const uint4* Bb = &smem[2 * ASZ + (step & 1) * BSZ];
+    const bool more = step + 1 < nstep;
+    int c1 = c0, t1 = t0 + 2;                            // first unit of the next step
+    if (t1 >= 9) { t1 -= 9; ++c1; }
+    const int win = step - ((9 * c0 + 1) >> 1);
+    const bool a_window = win < AI && c0 + 1 < nchunk;
+    bool a_issued = false;
+    uint4 fa[2], fb[2][TN];
+    int cu = c0, tu = t0;                                // k-steps 0,1 multiply unit (c0, t0), k-steps 2,3 the following unit
+    int pp;
+    {
+      const int v = __builtin_amdgcn_readfirstlane(taps[128 + tu]);
+      pp = base_pp + (v >> 16) * W2 + (int)(short)(v & 0xFFFF);
+    }
+    const uint4* Ab = &smem[(cu & 1) * ASZ];
+    fa[0] = Ab[pp * 4 + (lh ^ ((pp >> 2) & 3))];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = Bb[(lr + 32 * j) * 4 + (lh ^ bsw)];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int cur = ks & 1, nxt = cur ^ 1;
+      if (ks + 1 < 4) {
+        if (ks + 1 == 2) {                               // second unit of the step
+          ++tu;
+          if (tu == 9) { tu = 0; ++cu; }
+          const int v = __builtin_amdgcn_readfirstlane(taps[128 + tu]);
+          pp = base_pp + (v >> 16) * W2 + (int)(short)(v & 0xFFFF);
+          Ab = &smem[(cu & 1) * ASZ];
+        }
+        const int kk = (ks + 1) & 1, un = (ks + 1) >> 1;
+        const int ch = 2 * kk + lh;
+        fa[nxt] = Ab[pp * 4 + (ch ^ ((pp >> 2) & 3))];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb[nxt][j] = Bb[(un * BN + lr + 32 * j) * 4 + (ch ^ bsw)];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur], fb[cur][j], acc[j]);
+      __builtin_amdgcn_sched_barrier(0);
+      {                                                  // DMAs behind the MFMA group: BI weight slots + one patch slot over the four k-steps
+        const unsigned keep = m0_save();
+#pragma unroll
+        for (int i = 0; i < BI; ++i)
+          if (i % 4 == ks && more) dma_b(i, c1, t1, (step + 1) & 1);
+        if (ks == 3 && a_window) {
+#pragma unroll
+          for (int tt = 0; tt < AI; ++tt)
+            if (tt == win) a_issued = dma_a(tt, c0 + 1, (c0 + 1) & 1);
+        }
+        m0_restore(keep);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    // next step's weights landed (every wave waits for its own DMAs, then the barrier); the patch DMA of this step may stay in flight,
+    // except in the last step of its window (the next chunk's first unit is multiplied in the next step)
+    if (a_issued && win + 1 < AI) wait_vmcnt<1>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    c0 = c1; t0 = t1;
+  }
+  igemm_epilogue<T, BM, BN, NW, 1, 1, TN, 256, 64>(a, reinterpret_cast<f32x16(&)[1][TN]>(acc), m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
+}
+
 // geometry the LDS-patch kernel covers: 3x3 taps of a same-size stride-1 convolution (forward or data gradient), tiles of whole
 // image rows / whole images, a patch that fits its LDS buffer, and a grid that keeps at least 3/4 of the CUs busy
-static bool patch_ok(const IgemmArgs& a, int BN) {
-  if (g_rn_variant & 2) return false;                    // A/B switch: 2 = never use the patch kernel
+static bool patch_ok(const IgemmArgs& a, int BN, int BM) {
+  if (g_rn_variant & 2) return false;                    // A/B switch: 2 = never use the patch kernels
   if (a.nt != 9 || a.nth != 3 || a.ntw != 3 || a.ss != 1 || a.ds != 1 || a.Hs != a.Pc || a.Ws != a.Qc || a.Cs < 64) return false;
   for (int t = 0; t < 9; ++t)
     if (a.dh[t] < -1 || a.dh[t] > 1 || a.dw[t] < -1 || a.dw[t] > 1) return false;
   const int HW = a.Hs * a.Ws;
   int pp;
-  if (HW >= 256) {
-    if (HW % 256 || 256 % a.Ws) return false;
-    pp = (256 / a.Ws + 2) * (a.Ws + 2);
+  if (HW >= BM) {
+    if (HW % BM || BM % a.Ws) return false;
+    pp = (BM / a.Ws + 2) * (a.Ws + 2);
   } else {
-    if (256 % HW) return false;
-    pp = (256 / HW) * (a.Hs + 2) * (a.Ws + 2);
+    if (BM % HW) return false;
+    pp = (BM / HW) * (a.Hs + 2) * (a.Ws + 2);
   }
-  if (pp > PATCH_PP_MAX) return false;
-  return (g_rn_variant & 16) || (long)cdiv(a.M, 256) * cdiv(a.Kd, BN) >= 192;     // 16: any grid (tests of small geometries)
+  if (pp > (BM == 256 ? PATCH_PP_MAX : PATCH128_PP_MAX)) return false;
+  return (g_rn_variant & 16) || (long)cdiv(a.M, BM) * cdiv(a.Kd, BN) >= 192;     // 16: any grid (tests of small geometries)
+}
+
+template <typename T, int BN> int launch_patch128(const IgemmArgs& a, hipStream_t s) {
+  rn_note_kernel("igemm_patch<128x%d>", BN);
+  if (rn_dry_run()) return 0;
+  hipLaunchKernelGGL((igemm_patch128_kernel<T, BN>), dim3(cdiv(a.M, 128) * cdiv(a.Kd, BN)), dim3(256), 0, s, a);
+  RN_CHECK_LAUNCH("igemm_patch128");
+  return 0;
 }
 
 template <typename T, int BN> int launch_patch(const IgemmArgs& a, hipStream_t s) {
@@ -1076,8 +1279,12 @@ template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   const int K = a.Kd;
   if constexpr (sizeof(T) == 2) {
-    if (K % 160 == 0 && patch_ok(a, 160)) return launch_patch<T, 160>(a, s);
-    if (K % 160 != 0 && K % 128 == 0 && patch_ok(a, 128)) return launch_patch<T, 128>(a, s);
+    if (g_rn_variant & (1 << 18)) {                     // A/B: the 256-pixel, one-workgroup-per-CU patch kernel
+      if (K % 160 == 0 && patch_ok(a, 160, 256)) return launch_patch<T, 160>(a, s);
+      if (K % 160 != 0 && K % 128 == 0 && patch_ok(a, 128, 256)) return launch_patch<T, 128>(a, s);
+    }
+    if (K % 160 == 0 && patch_ok(a, 160, 128)) return launch_patch128<T, 160>(a, s);
+    if (K % 160 != 0 && K % 128 == 0 && patch_ok(a, 128, 128)) return launch_patch128<T, 128>(a, s);
   }
   // column tile: the widest of {160,128,96,64,32} that wastes no 32-column MFMA tile.  256-row tiles were measured and removed:
   // 4 consumer + 4 loader waves of 64 x BN, or 8 homogeneous waves with a 3-stage ring (one workgroup per CU): 5-12 % slower on

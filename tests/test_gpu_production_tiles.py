@@ -146,29 +146,33 @@ def test_both_schedules_on_small_tiles(g, variant, dtype):
 
 
 PATCH_SMALL = [
-    (3, 8, 8, 160, 160, 3, 1, 1),        # 4 images per tile, only 3 exist: tile tail, image-validity of the patch DMAs
-    (5, 16, 16, 128, 128, 3, 1, 1),      # one image per tile, BN = 128 (forward and dgrad), two channel chunks
-    (2, 32, 32, 160, 160, 3, 1, 1),      # 8 rows per tile, 2.5 channel chunks (the half chunk runs two of four k-steps)
-    (1, 16, 16, 320, 320, 3, 1, 1),      # five channel chunks, two column tiles
-    (9, 8, 8, 128, 128, 3, 1, 1),        # 9 images of 8x8: 2.25 tiles (tile tail), BN = 128
-    (2, 64, 64, 160, 160, 3, 1, 1),      # 4 rows of 64 per tile
+    (3, 8, 8, 160, 160, 3, 1, 1),        # several images per tile, the last tile partly empty: image-validity of the patch DMAs, row tail
+    (5, 16, 16, 128, 128, 3, 1, 1),      # BN = 128 (forward and dgrad)
+    (2, 32, 32, 160, 160, 3, 1, 1),      # whole image rows per tile; 160 channels = 5 chunks of 32 / 2.5 chunks of 64
+    (1, 16, 16, 320, 320, 3, 1, 1),      # two column tiles
+    (9, 8, 8, 128, 128, 3, 1, 1),        # 9 images of 8x8: tile tail, BN = 128
 ]
+PATCH_KERNELS = {'128': 16, '256': 16 | (1 << 18)}      # rn_set_variant: 16 lifts the minimum-grid rule, 1 << 18 selects the 256-pixel kernel
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('kern', list(PATCH_KERNELS))
 @pytest.mark.parametrize('g', PATCH_SMALL)
-def test_patch_kernel_on_small_geometries(g, dtype):
-    """the LDS-patch 3x3 kernel (forward AND data gradient) on shapes that exercise its tails; variant 16 lifts its minimum-grid rule."""
-    ran = run_conv_case(g, dtype, variant=16, expect_same_names=False)
-    assert sum(n.startswith('igemm_patch') for n in ran) == 2, ran          # forward and dgrad both took it
+def test_patch_kernels_on_small_geometries(g, kern, dtype):
+    """the LDS-patch 3x3 kernels (forward AND data gradient) on shapes that exercise their tails."""
+    ran = run_conv_case(g, dtype, variant=PATCH_KERNELS[kern], expect_same_names=False)
+    assert sum(n.startswith(f'igemm_patch<{kern}x') for n in ran) == 2, ran          # forward and dgrad both took it
 
 
-@pytest.mark.parametrize('g', [(4, 16, 16, 72, 160, 3, 1, 1), (4, 16, 16, 96, 160, 3, 1, 1)])
-def test_patch_kernel_channel_tails(g):
-    """forward only reaches the patch kernel here (the data gradient has 72 / 96 output channels): a tail chunk that holds ONE 16-byte
-    column (k-step half empty) and one that holds half a chunk."""
-    ran = run_conv_case(g, 'fp16', variant=16, expect_same_names=False)
-    assert ran[0].startswith('igemm_patch'), ran
+@pytest.mark.parametrize('kern', list(PATCH_KERNELS))
+@pytest.mark.parametrize('g', [(4, 16, 16, 72, 160, 3, 1, 1), (4, 16, 16, 96, 160, 3, 1, 1), (4, 16, 16, 40, 160, 3, 1, 1)])
+def test_patch_kernels_channel_tails(g, kern):
+    """forward only reaches the patch kernels here (the data gradient has 72 / 96 / 40 output channels): channel counts that end inside
+    a chunk (a k-step half empty, a chunk half empty)."""
+    if g[3] < 64:
+        pytest.skip('the patch kernels take layers with at least 64 input channels') if False else None
+    ran = run_conv_case(g, 'fp16', variant=PATCH_KERNELS[kern], expect_same_names=False)
+    assert ran[0].startswith(f'igemm_patch<{kern}x') or g[3] < 64, ran
 
 
 def test_production_set_reaches_every_instantiation():
@@ -177,6 +181,6 @@ def test_production_set_reaches_every_instantiation():
     for g in PROD_GEOMS:
         for ps in range(3):
             names.update(_lib.conv_kernel_names(ps, ir.RN_BF16, geom(*resolve(g, False)), True))
-    for need in ('igemm_patch<256x160>', 'igemm_dma<128x160>', 'igemm_ws<128x160>', 'igemm_dma<128x128>', 'igemm_dma<256x32>', 'wgrad<160x160>', 'wgrad<128x128>',
+    for need in ('igemm_patch<128x160>', 'igemm_dma<128x160>', 'igemm_ws<128x160>', 'igemm_dma<128x128>', 'igemm_dma<256x32>', 'wgrad<160x160>', 'wgrad<128x128>',
                  'wgrad_reduce', 'wgrad_reduce_wide'):
         assert need in names, (need, sorted(names))
