@@ -839,7 +839,7 @@ __global__ __launch_bounds__(512, BM >= 256 ? 1 : 2) void igemm_ws_kernel(const 
 // eighth of the NEXT chunk's patch per wave (double-buffered patch); DMAs are issued between the k-steps' MFMA groups, waits
 // are counted, one raw s_barrier per step.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int PATCH_PP_MAX = 400;                        // patch pixels (incl. halo and pad columns): 10x34, 18x18, 4 x 10x10
+constexpr int PATCH_PP_MAX = 344;                        // patch pixels (incl. halo and pad columns): 10x34 (W=32), 18x18 (W=16)
 template <typename T, int BN>
 __global__ __launch_bounds__(512, 2) void igemm_patch_kernel(const IgemmArgs a) {
   constexpr int BM = 256, NW = 8, ES = (int)sizeof(T), TN = BN / 32;
@@ -848,10 +848,11 @@ __global__ __launch_bounds__(512, 2) void igemm_patch_kernel(const IgemmArgs a) 
   constexpr int BIT = BN / 8;                            // weight-tile DMA instructions (8 rows of 128 bytes each)
   constexpr int BI = (BIT + NW - 1) / NW;                // per wave (the last one only for wave < BIT - (BI-1)*NW)
   constexpr int BSZ = BN * 8;
-  constexpr int AI = 7;                                  // patch DMAs per wave and chunk: PATCH_PP_MAX / 8 = 50 <= 7 * 8
+  constexpr int AI = 6;                                  // patch DMAs per wave and chunk: PATCH_PP_MAX / 8 = 43 <= 6 * 8
+  constexpr int NSB = 3;                                 // weight-tile ring stages: a tile is issued TWO steps before it is multiplied
   static_assert(ES == 2 && BN % 32 == 0 && PATCH_PP_MAX / 8 <= AI * NW && BI <= 3, "patch tile");
-  __shared__ uint4 smem[2 * ASZ + 2 * BSZ + TAP_INTS / 4];
-  int* taps = reinterpret_cast<int*>(&smem[2 * ASZ + 2 * BSZ]);
+  __shared__ uint4 smem[2 * ASZ + NSB * BSZ + TAP_INTS / 4];
+  int* taps = reinterpret_cast<int*>(&smem[2 * ASZ + NSB * BSZ]);
 
   // (no preload_args here: the K loop keeps ~30 wave-uniform values live; holding every argument in SGPRs as well spills them)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -958,28 +959,31 @@ __global__ __launch_bounds__(512, 2) void igemm_patch_kernel(const IgemmArgs a) 
     const unsigned keep = m0_save();
 #pragma unroll
     for (int t = 0; t < AI; ++t) dma_a(t, 0, 0);
-    const int w0 = tap_woff(0);
+    const int w0 = tap_woff(0), w1 = tap_woff(1);
 #pragma unroll
     for (int i = 0; i < BI; ++i) dma_b(i, 0, w0, 0);
+#pragma unroll
+    for (int i = 0; i < BI; ++i) dma_b(i, 0, w1, 1);
     m0_restore(keep);
   }
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
-  int step = 0;
+  int step = 0, sb = 0;                                   // sb = step % NSB
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const uint4* Ab = &smem[(chunk & 1) * ASZ];
     const int kcount = min(4, (a.cpt - chunk * 8 + 1) >> 1);    // 16-channel k-steps of this chunk that hold data
     const bool more_chunks = chunk + 1 < nchunk;
 #pragma unroll
     for (int t = 0; t < 9; ++t, ++step) {
-      const uint4* Bb = &smem[2 * ASZ + (step & 1) * BSZ];
-      const bool more = step + 1 < nstep;
-      const int nchunk_b = t == 8 ? chunk + 1 : chunk, ntap_b = t == 8 ? 0 : t + 1;
+      const uint4* Bb = &smem[2 * ASZ + sb * BSZ];
+      const bool more = step + 2 < nstep;                  // the weight tile issued in this step is the one of step + 2
+      const int nchunk_b = t >= 7 ? chunk + 1 : chunk, ntap_b = t >= 7 ? t - 7 : t + 2;
       const int wnext = tap_woff(ntap_b);
+      const int sb2 = sb == 0 ? 2 : sb - 1;                // (step + 2) % 3
+      int issued = 0;                                      // DMAs this wave issues in this step (wave-uniform)
       const int pp = base_pp + tap_poff(t);
       const int pa = pp * 8, sa = (pp >> 1) & 7;
-      bool a_issued = false;
       uint4 fa[2], fb[2][TN];
       fa[0] = Ab[pa + (lh ^ sa)];
 #pragma unroll
@@ -1000,8 +1004,8 @@ __global__ __launch_bounds__(512, 2) void igemm_patch_kernel(const IgemmArgs a) 
 #define RN_PATCH_ISSUE()                                                                                     \
   if (a.probe_k != 2) {                                                                                      \
     const unsigned keep = m0_save();                                                                         \
-    if (ks < BI) { if (more) dma_b(ks, nchunk_b, wnext, (step + 1) & 1); }                                    \
-    else if (ks == 3 && t < AI && more_chunks) a_issued = dma_a(t, chunk + 1, (chunk + 1) & 1);             \
+    if (ks < BI) { if (more) issued += dma_b(ks, nchunk_b, wnext, sb2) ? 1 : 0; }                             \
+    else if (ks == 3 && t < AI && more_chunks) issued += dma_a(t, chunk + 1, (chunk + 1) & 1) ? 1 : 0;      \
     m0_restore(keep);                                                                                        \
   }
         const bool early = (a.patch_mode & 1) && wave >= 4;
@@ -1015,10 +1019,12 @@ __global__ __launch_bounds__(512, 2) void igemm_patch_kernel(const IgemmArgs a) 
         if (!early) { RN_PATCH_ISSUE() }
         __builtin_amdgcn_sched_barrier(0);
       }
-      // the next step's weight tile (and, at the last taps, the whole next patch) must have landed for every wave; the patch DMA
-      // issued in this step may stay in flight
-      if (a_issued) wait_vmcnt<1>(); else wait_vmcnt<0>();
+      // the NEXT step's weight tile (issued one step ago) and, at tap 8, the whole next patch (issued in taps 0..5) must have landed
+      // for every wave: everything older than the DMAs of this step.  Those stay in flight across the barrier (counted wait).
+      if (issued >= 4) wait_vmcnt<4>(); else if (issued == 3) wait_vmcnt<3>(); else if (issued == 2) wait_vmcnt<2>();
+      else if (issued == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
+      sb = sb == 2 ? 0 : sb + 1;
     }
   }
 #undef RN_PATCH_ISSUE
@@ -1034,6 +1040,15 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   // wave-specialised kernel, 512 forbids it (A/B in tools/conv_bench.py).
   const bool one_per_cu = nmt * nnt <= 256;
   const bool ws = (g_rn_variant & 128) || (one_per_cu && !(g_rn_variant & 512));
+  if constexpr (BN >= 128) {
+    if (g_rn_variant & (1 << 19)) {                     // A/B: wave-specialised kernel with a 4-stage ring (three K tiles in flight), any grid
+      rn_note_kernel("igemm_ws4<%dx%d>", BM, BN);
+      if (rn_dry_run()) return 0;
+      hipLaunchKernelGGL((igemm_ws_kernel<T, BM, BN, WM, WN, 8, 4>), dim3(nmt * nnt), dim3(512), 0, s, a);
+      RN_CHECK_LAUNCH("igemm_ws4");
+      return 0;
+    }
+  }
   rn_note_kernel("igemm_%s<%dx%d>", ws ? "ws" : "dma", BM, BN);
   if (rn_dry_run()) return 0;
   if (ws)
