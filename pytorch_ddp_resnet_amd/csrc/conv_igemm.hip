@@ -1199,6 +1199,22 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
     const int win = step - ((9 * c0 + 1) >> 1);
     const bool a_window = win < AI && c0 + 1 < nchunk;
     bool a_issued = false;
+    if (!(a.patch_mode & 2)) {
+      // all of the step's DMAs at its head, as igemm_dma_kernel does: the wave then runs its 20 MFMAs uninterrupted while the other
+      // workgroup of the CU covers the issue stall (DMAs spread behind the MFMA groups measured 8-15 % slower: every issue can
+      // block the in-order wave in front of MFMAs the matrix pipe is ready for)
+      const unsigned keep = m0_save();
+      if (more) {
+#pragma unroll
+        for (int i = 0; i < BI; ++i) dma_b(i, c1, t1, (step + 1) & 1);
+      }
+      if (a_window) {
+#pragma unroll
+        for (int tt = 0; tt < AI; ++tt)
+          if (tt == win) a_issued = dma_a(tt, c0 + 1, (c0 + 1) & 1);
+      }
+      m0_restore(keep);
+    }
     uint4 fa[2], fb[2][TN];
     int cu = c0, tu = t0;                                // k-steps 0,1 multiply unit (c0, t0), k-steps 2,3 the following unit
     int pp;
@@ -1231,7 +1247,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
 #pragma unroll
       for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur], fb[cur][j], acc[j]);
       __builtin_amdgcn_sched_barrier(0);
-      {                                                  // DMAs behind the MFMA group: BI weight slots + one patch slot over the four k-steps
+      if (a.patch_mode & 2) {                            // A/B (rn_set_variant 1 << 20): DMAs spread behind the MFMA groups
         const unsigned keep = m0_save();
 #pragma unroll
         for (int i = 0; i < BI; ++i)
@@ -1242,8 +1258,8 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
             if (tt == win) a_issued = dma_a(tt, c0 + 1, (c0 + 1) & 1);
         }
         m0_restore(keep);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
     // next step's weights landed (every wave waits for its own DMAs, then the barrier); the patch DMA of this step may stay in flight,
     // except in the last step of its window (the next chunk's first unit is multiplied in the next step)
@@ -1366,7 +1382,7 @@ static void fill_ep(IgemmArgs& a, const rn_conv_epilogue* ep, int tile_base) {
   a.probe_mask = (g_rn_variant & 64) ? 0x0000FFF0u : 0xFFFFFFFFu;
   a.stamps = reinterpret_cast<unsigned long long*>(g_rn_stamps);
   a.xcd_remap = (g_rn_variant & 8) ? 0 : 1;
-  a.patch_mode = (g_rn_variant & (1 << 17)) ? 0 : 1;      // 1 << 17: lockstep DMA placement (A/B)
+  a.patch_mode = ((g_rn_variant & (1 << 17)) ? 0 : 1) | ((g_rn_variant & (1 << 20)) ? 2 : 0);      // 1 << 17: lockstep DMA placement, 1 << 20: spread DMAs (A/B)
   a.probe_k = (g_rn_variant & 1024) ? 1 : ((g_rn_variant & 2048) ? 2 : ((g_rn_variant & 4096) ? 3 : 0));
   a.probe_ep = (g_rn_variant & 8192) ? 1 : ((g_rn_variant & 16384) ? 2 : ((g_rn_variant & 32768) ? 3 : ((g_rn_variant & 65536) ? 4 : 0)));
 }

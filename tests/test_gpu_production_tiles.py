@@ -160,6 +160,8 @@ PATCH_KERNELS = {'128': 16, '256': 16 | (1 << 18)}      # rn_set_variant: 16 lif
 @pytest.mark.parametrize('g', PATCH_SMALL)
 def test_patch_kernels_on_small_geometries(g, kern, dtype):
     """the LDS-patch 3x3 kernels (forward AND data gradient) on shapes that exercise their tails."""
+    if kern == '256' and g[1] * g[2] < 256:
+        pytest.skip('the 256-pixel kernel holds whole-row patches of 16- and 32-wide maps only')
     ran = run_conv_case(g, dtype, variant=PATCH_KERNELS[kern], expect_same_names=False)
     assert sum(n.startswith(f'igemm_patch<{kern}x') for n in ran) == 2, ran          # forward and dgrad both took it
 
