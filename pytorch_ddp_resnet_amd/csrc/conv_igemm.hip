@@ -1309,13 +1309,19 @@ template <typename T, int BN> int launch_patch(const IgemmArgs& a, hipStream_t s
 template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   const int K = a.Kd;
+  // LDS-patch kernels (3x3 stride 1): EXPERIMENTAL, opt-in through rn_set_variant.  They cut the LDS-DMA instructions per FLOP by 1.6x
+  // (128-pixel tiles) / 2.9x (256-pixel tiles) and are parity-tested, but measured 0-17 % SLOWER than the im2col kernels below on the
+  // WRN-28-10 shapes (the K loop is bound by bytes in flight per CU and by LDS fragment reads, not by DMA issue
+  // alone).  Bits: 1 << 21 = 128-pixel tiles (two workgroups per CU), 1 << 18 = 256-pixel tiles (one per CU).
   if constexpr (sizeof(T) == 2) {
-    if (g_rn_variant & (1 << 18)) {                     // A/B: the 256-pixel, one-workgroup-per-CU patch kernel
+    if (g_rn_variant & (1 << 18)) {
       if (K % 160 == 0 && patch_ok(a, 160, 256)) return launch_patch<T, 160>(a, s);
       if (K % 160 != 0 && K % 128 == 0 && patch_ok(a, 128, 256)) return launch_patch<T, 128>(a, s);
     }
-    if (K % 160 == 0 && patch_ok(a, 160, 128)) return launch_patch128<T, 160>(a, s);
-    if (K % 160 != 0 && K % 128 == 0 && patch_ok(a, 128, 128)) return launch_patch128<T, 128>(a, s);
+    if (g_rn_variant & (1 << 21)) {
+      if (K % 160 == 0 && patch_ok(a, 160, 128)) return launch_patch128<T, 160>(a, s);
+      if (K % 160 != 0 && K % 128 == 0 && patch_ok(a, 128, 128)) return launch_patch128<T, 128>(a, s);
+    }
   }
   // column tile: the widest of {160,128,96,64,32} that wastes no 32-column MFMA tile.  256-row tiles were measured and removed:
   // 4 consumer + 4 loader waves of 64 x BN, or 8 homogeneous waves with a 3-stage ring (one workgroup per CU): 5-12 % slower on

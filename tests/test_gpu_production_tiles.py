@@ -152,14 +152,14 @@ PATCH_SMALL = [
     (1, 16, 16, 320, 320, 3, 1, 1),      # two column tiles
     (9, 8, 8, 128, 128, 3, 1, 1),        # 9 images of 8x8: tile tail, BN = 128
 ]
-PATCH_KERNELS = {'128': 16, '256': 16 | (1 << 18)}      # rn_set_variant: 16 lifts the minimum-grid rule, 1 << 18 selects the 256-pixel kernel
+PATCH_KERNELS = {'128': 16 | (1 << 21), '256': 16 | (1 << 18)}      # rn_set_variant: 16 lifts the minimum-grid rule; 1 << 21 / 1 << 18 select a kernel
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 @pytest.mark.parametrize('kern', list(PATCH_KERNELS))
 @pytest.mark.parametrize('g', PATCH_SMALL)
 def test_patch_kernels_on_small_geometries(g, kern, dtype):
-    """the LDS-patch 3x3 kernels (forward AND data gradient) on shapes that exercise their tails."""
+    """the (opt-in, experimental) LDS-patch 3x3 kernels, forward AND data gradient, on shapes that exercise their tails."""
     if kern == '256' and g[1] * g[2] < 256:
         pytest.skip('the 256-pixel kernel holds whole-row patches of 16- and 32-wide maps only')
     ran = run_conv_case(g, dtype, variant=PATCH_KERNELS[kern], expect_same_names=False)
@@ -183,6 +183,14 @@ def test_production_set_reaches_every_instantiation():
     for g in PROD_GEOMS:
         for ps in range(3):
             names.update(_lib.conv_kernel_names(ps, ir.RN_BF16, geom(*resolve(g, False)), True))
-    for need in ('igemm_patch<128x160>', 'igemm_dma<128x160>', 'igemm_ws<128x160>', 'igemm_dma<128x128>', 'igemm_dma<256x32>', 'wgrad<160x160>', 'wgrad<128x128>',
+    for need in ('igemm_dma<128x160>', 'igemm_ws<128x160>', 'igemm_dma<128x128>', 'igemm_dma<256x32>', 'wgrad<160x160>', 'wgrad<128x128>',
                  'wgrad_reduce', 'wgrad_reduce_wide'):
         assert need in names, (need, sorted(names))
+
+
+@pytest.mark.parametrize('kern', list(PATCH_KERNELS))
+@pytest.mark.parametrize('g', [PROD_GEOMS[0], PROD_GEOMS[3]])
+def test_patch_kernels_on_production_shapes(g, kern):
+    """WRN-28-10 stage 1 / stage 2 at batch 128 through the opt-in patch kernels (grids of 512-1024 workgroups, XCD remap, two column tiles)."""
+    ran = run_conv_case(g, 'fp16', variant=PATCH_KERNELS[kern] & ~16, expect_same_names=False)
+    assert sum(n.startswith(f'igemm_patch<{kern}x') for n in ran) == 2, ran
