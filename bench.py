@@ -41,6 +41,19 @@ def conv_flops(op):
     return 2.0 * d['N'] * d['P'] * d['Q'] * d['K'] * d['R'] * d['S'] * d['C']
 
 
+def conv_bytes(op, ir, elem):
+    """algorithmic HBM bytes of one convolution launch: every operand read once, every result written once (weights included;
+    fused-epilogue operands -- residual, accumulate target, BatchNorm-backward x and mask -- counted where the op has them)."""
+    d, b = op.dim, op.buf
+    x_, y_, w_ = d['N'] * d['H'] * d['W'] * d['C'], d['N'] * d['P'] * d['Q'] * d['K'], d['K'] * d['R'] * d['S'] * d['C']
+    if op.kind == ir.OP_CONV_FWD:
+        return elem * (x_ + y_ + w_ + (y_ if b.get('res', -1) >= 0 else 0))
+    if op.kind == ir.OP_CONV_DGRAD:
+        extra = sum(x_ for k in ('res', 'bn_x', 'bn_mask') if b.get(k, -1) >= 0) + (x_ if op.flags & ir.F_ACCUM else 0)
+        return elem * (y_ + x_ + w_ + extra)
+    return elem * (x_ + y_) + 4 * w_                     # wgrad: fp32 dw
+
+
 def cpu_baseline(cfg, steps=3):
     """the reference's CPU training loop (torch-CPU port, fp32 NCHW, same region: fwd + loss/metrics + bwd) on a
     bounded sample of the same workload: reduced batch, a few steps."""
@@ -146,7 +159,7 @@ def main():
             'metric': 'images/sec fwd+bwd (whole node)', 'value': round(res['value'], 1), 'unit': 'images/sec', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': round(res['ms'], 3), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': args.dtype, 'data': 'synthetic',
-            'config': {'workload': f"{args.workload} CIFAR-10 32x32" if cfg['hw'] == 32 else f"{args.workload} 224x224", 'architecture_spec': cfg['spec'],
+            'config': {'workload': f"{args.workload} CIFAR-{cfg['classes']} 32x32" if cfg['hw'] == 32 else f"{args.workload} 224x224", 'architecture_spec': cfg['spec'],
                        'preact': cfg['preact'], 'use_proj': cfg['use_proj'], 'dropout_prob': cfg['p'], 'batch_per_gpu': cfg['batch'],
                        'global_batch': cfg['batch'] * world, 'parallelism': f'dp{world}',
                        'timed_region': 'fwd + CE loss/top-k + bwd + grad all-reduce' + (' (no optimizer step)' if args.optimizer == 'none' else f' + SGD step ({args.optimizer})'),
@@ -258,6 +271,8 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
     nprof = max(3, min(10, steps))
     agg, conv_t, conv_f, nconv = {}, 0.0, 0.0, 0
     per_op = {}
+    roof_t, hbm_bound = 0.0, 0                           # per-launch rooflines: max(FLOPs / MFMA peak, bytes / HBM peak)
+    elem = 4 if dtype == 'fp32' else 2
     from pytorch_ddp_resnet_amd import _lib
     _lib.lib().rn_kernel_log(1)
     for _ in range(nprof):
@@ -272,6 +287,9 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
                 conv_t += t_ms
                 conv_f += conv_flops(op)
                 nconv += 1
+                t_m, t_h = conv_flops(op) / (PEAK_TFLOPS[dtype] * 1e12), conv_bytes(op, ir, elem) / (HBM_PEAK_GBS * 1e9)
+                roof_t += max(t_m, t_h) * 1e3
+                hbm_bound += 1 if t_h > t_m else 0
     eng.profile(False)
     kernels = sorted(set(n for n in _lib.lib().rn_kernel_log_read().decode().split(',') if n and 'reduce' not in n))
     _lib.lib().rn_kernel_log(0)
@@ -298,7 +316,11 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
                     kernel='implicit-GEMM convolution launches (forward, dgrad, wgrad): ' + ' '.join(kernels),
                     launches_per_step=nconv // nprof, avg_launch_ms=round(conv_t / max(nconv, 1), 4),
                     algorithmic_gflop_per_launch=round(conv_f / max(nconv, 1) / 1e9, 2),
-                    conv_ms_per_step=round(conv_t / nprof, 3), all_ops_ms_per_step=round(sum(agg.values()), 3))
+                    conv_ms_per_step=round(conv_t / nprof, 3), all_ops_ms_per_step=round(sum(agg.values()), 3),
+                    # the same launches against their OWN rooflines: several are bound by their output / fused-operand bytes, not by
+                    # the matrix pipe (1x1 layers with a short reduction, the 7x7 stem), which a pure MFMA fraction under-reports
+                    layer_roofline_ms_per_step=round(roof_t / nprof, 3), frac_of_layer_rooflines=round(roof_t / conv_t, 4) if conv_t > 0 else None,
+                    hbm_bound_launches_per_step=hbm_bound // nprof)
         if args.breakdown and main_run:
             for k, v in sorted(agg.items(), key=lambda kv: -kv[1]):
                 print(f'  {k:22s} {v:9.3f} ms/step', file=sys.stderr)

@@ -22,9 +22,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def short(name):
     name = re.sub(r'\(anonymous namespace\)::', '', name)
-    m = re.match(r'_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)I(DF16b|f)?', name)
+    m = re.match(r'_ZN12_GLOBAL__N_1\d+([a-z_0-9]+?)I(DF16b|DF16_|f)?', name)
     if m:
-        return m.group(1) + ('<bf16>' if m.group(2) == 'DF16b' else ('<f32>' if m.group(2) == 'f' else ''))
+        return m.group(1) + {'DF16b': '<bf16>', 'DF16_': '<f16>', 'f': '<f32>', None: ''}[m.group(2)]
     m = re.match(r'(?:void )?([a-z_0-9]+)(<[^(]*)?\(', name)
     return m.group(1) if m else name[:60]
 
@@ -42,6 +42,7 @@ def counters(path, wanted):
 
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    opts = dict(a[2:].split('=', 1) for a in sys.argv[1:] if a.startswith('--') and '=' in a)      # --workload=wrn-28-10 --dtype=fp16
     tag, trace = args[0], args[1]
     os.makedirs(os.path.join(ROOT, 'profiles'), exist_ok=True)
     stats = glob.glob(os.path.join(trace, '*kernel_stats.csv'))[0]
@@ -51,7 +52,7 @@ def main():
         k = short(r['Name'])
         dur[k][0] += int(r['Calls'])
         dur[k][1] += float(r['TotalDurationNs'])
-    out = {'tag': tag, 'kernels': {}}
+    out = {'tag': tag, 'workload': opts.get('workload', 'wrn-28-10'), 'dtype': opts.get('dtype', 'fp16'), 'kernels': {}}
     if len(args) >= 5:
         sq = counters(args[2], {'SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_VALU_MFMA_BUSY_CYCLES', 'SQ_LDS_IDX_ACTIVE', 'SQ_LDS_BANK_CONFLICT',
                                 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_ACTIVE_INST_ANY', 'GRBM_GUI_ACTIVE'})
@@ -76,7 +77,8 @@ def main():
             if len(e) > 2:
                 out['kernels'][k] = e
         json.dump(out, open(os.path.join(ROOT, 'profiles', f'{tag}_pmc_summary.json'), 'w'), indent=1)
-        json.dump(out, open(os.path.join(ROOT, 'profiles', 'latest_pmc_summary.json'), 'w'), indent=1)      # what bench.py reads
+        if 'no-latest' not in opts and '--no-latest' not in sys.argv:
+            json.dump(out, open(os.path.join(ROOT, 'profiles', 'latest_pmc_summary.json'), 'w'), indent=1)      # what bench.py reads
     tot = sum(v[1] for v in dur.values())
     for k in sorted(dur, key=lambda k: -dur[k][1])[:14]:
         e = out['kernels'].get(k, {})
