@@ -1061,24 +1061,25 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The same idea at the proven occupancy of igemm_dma_kernel: 128-pixel tiles, 4 waves, TWO workgroups per CU (each hides the
-// other's prologue, epilogue and DMA latency).  Channels advance in chunks of 32 (64-byte LDS rows): the patch of a chunk is
-// 208 pixels x 64 B = 13 KiB, double-buffered; a K step is TWO (chunk, tap) units = 2 x BN x 64 B of weights in a 2-stage ring,
-// i.e. the same 20 MFMAs per wave and barrier as the im2col kernel with 6 instead of 9 DMA instructions per wave.
+// other's prologue, epilogue, DMA latency and patch reload).  The per-CU load path moves ~25 bytes per clock whatever the
+// instruction mix (an LDS-DMA instruction costs ~5 cycles per 128-byte line it touches, out-of-range lanes included; 64-byte rows
+// use half of every line and were measured slower), so the lever is BYTES per FLOP: the patch of a 64-channel chunk (208 pixels x
+// 128 B = 26 KiB, single buffer: reloaded between chunks while the other workgroup computes) + one 20 KiB weight tile per
+// (chunk, tap) step = 23 KiB per step instead of the im2col kernel's 36 KiB, at the same 20 MFMAs per wave and barrier.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PATCH128_PP_MAX = 208;                     // 6x34 (W=32), 10x18 (W=16), 2 x 10x10 (W=8)
 template <typename T, int BN>
 __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs a) {
   constexpr int BM = 128, NW = 4, ES = (int)sizeof(T), TN = BN / 32;
-  constexpr int CHK = 64 / ES;                           // channels per chunk (one 64-byte LDS row per pixel)
-  constexpr int ASZ = PATCH128_PP_MAX * 4;               // uint4 per patch buffer
-  constexpr int UIT = BN / 16;                           // weight DMA instructions per unit (16 rows of 64 bytes each)
-  constexpr int BIT = 2 * UIT;                           // per step (two units)
+  constexpr int CHK = 128 / ES;                          // channels per chunk (one 128-byte LDS row per pixel)
+  constexpr int ASZ = PATCH128_PP_MAX * 8;               // uint4 in the patch buffer
+  constexpr int BIT = BN / 8;                            // weight-tile DMA instructions per step (8 rows of 128 bytes each)
   constexpr int BI = (BIT + NW - 1) / NW;                // per wave
-  constexpr int BSZ = 2 * BN * 4;                        // uint4 per ring stage
-  constexpr int AI = 4;                                  // patch DMAs per wave and chunk: 13 <= 4 * 4
-  static_assert(ES == 2 && BN % 32 == 0 && BIT % NW == 0 && (PATCH128_PP_MAX + 15) / 16 <= AI * NW, "patch128 tile");
-  __shared__ uint4 smem[2 * ASZ + 2 * BSZ + TAP_INTS / 4];
-  int* taps = reinterpret_cast<int*>(&smem[2 * ASZ + 2 * BSZ]);
+  constexpr int BSZ = BN * 8;                            // uint4 per ring stage
+  constexpr int AI = (PATCH128_PP_MAX / 8 + NW - 1) / NW;    // patch DMAs per wave and chunk (26 instructions)
+  static_assert(ES == 2 && BN % 32 == 0 && BIT % NW == 0, "patch128 tile");
+  __shared__ uint4 smem[ASZ + 2 * BSZ + TAP_INTS / 4];
+  int* taps = reinterpret_cast<int*>(&smem[ASZ + 2 * BSZ]);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1098,10 +1099,9 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
   const int slab_rows = multi ? H + 2 : BM / W + 2;
   const int nimg = multi ? BM / HW : 1;
   const int PP = nimg * slab_rows * W2;
-  const int nA = (PP + 15) >> 4;
-  const int cpt4 = a.Cs * ES / 16;                       // 16-byte columns per pixel
+  const int nA = (PP + 7) >> 3;
   const int nchunk = (a.Cs + CHK - 1) / CHK;
-  const int U = nchunk * 9, nstep = (U + 1) >> 1;
+  const int nstep = nchunk * 9;
 
   const size_t img_bytes = (size_t)HW * a.Cs * ES;
   const v4i32 ra_desc = make_desc(reinterpret_cast<const char*>(a.src) + (size_t)n_first * img_bytes, (size_t)(a.N - n_first) * img_bytes);
@@ -1111,15 +1111,14 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
   fill_tap_tables<ES>(a, taps);
   __syncthreads();
 
-  // ---- per-lane DMA roles (16 rows of 64 bytes per instruction: lane -> row lane / 4, 16-byte slot lane % 4) ----
-  const int l4 = lane >> 2, sl = lane & 3;
+  const int l8 = lane >> 3, sl = lane & 7;
   unsigned aoff[AI];
   int ach[AI];
 #pragma unroll
   for (int t = 0; t < AI; ++t) {
     const int idx = t * NW + wave;
-    const int pp = idx * 16 + l4;
-    const int ch = sl ^ ((pp >> 2) & 3);
+    const int pp = idx * 8 + l8;
+    const int ch = sl ^ ((pp >> 1) & 7);
     ach[t] = ch;
     aoff[t] = OOB;
     if (idx < nA && pp < PP) {
@@ -1130,13 +1129,13 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
         aoff[t] = (unsigned)((((size_t)img * H + h) * W + (pcol - 1)) * a.Cs * ES + ch * 16);
     }
   }
-  unsigned boff[BI];                                     // slot j = i * NW + wave: unit j / UIT of the step, rows 16 * (j % UIT) ..
+  unsigned boff[BI];
   int bch[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
     const int j = i * NW + wave;
-    const int rn = (j % UIT) * 16 + l4;
-    const int ch = sl ^ ((rn >> 2) & 3);
+    const int rn = j * 8 + l8;
+    const int ch = sl ^ ((rn >> 1) & 7);
     bch[i] = ch;
     const int k = n0 + rn;
     boff[i] = k < a.Kd ? (unsigned)((size_t)k * a.wrs * a.Cs * ES + ch * 16) : OOB;
@@ -1150,7 +1149,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
     const int h = rem / W, w = rem - h * W;
     base_pp = ((n - n_first) * (multi ? slab_rows : 0) + (h - h_first) + 1) * W2 + w + 1;
   }
-  const int bsw = (lr >> 2) & 3;
+  const int bsw = (lr >> 1) & 7;
 
   f32x16 acc[TN];
 #pragma unroll
@@ -1158,114 +1157,83 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
-  auto dma_a = [&](int t, int chunk, int buf) {
-    const int idx = t * NW + wave;
-    if (idx >= nA) return false;                         // wave-uniform
-    const bool ok = aoff[t] != OOB && chunk * 4 + ach[t] < cpt4;
-    dma16(ra_desc, ok ? aoff[t] + (unsigned)(chunk * 64) : OOB, lds0 + (unsigned)((buf * ASZ) * 16 + idx * 1024));
-    return true;
+  auto load_patch = [&](int chunk) {                     // the whole patch of `chunk` (AI instructions per wave)
+#pragma unroll
+    for (int t = 0; t < AI; ++t) {
+      const int idx = t * NW + wave;
+      if (idx < nA) {                                    // wave-uniform
+        const bool ok = aoff[t] != OOB && chunk * 8 + ach[t] < a.cpt;
+        dma16(ra_desc, ok ? aoff[t] + (unsigned)(chunk * 128) : OOB, lds0 + (unsigned)(idx * 1024));
+      }
+    }
   };
-  // weight DMA slot i of the step whose first unit is (c0, t0): units beyond the last one load zeros (never multiplied)
-  auto dma_b = [&](int i, int c0, int t0, int stg) {
-    const int j = i * NW + wave;
-    const int second = j >= UIT ? 1 : 0;                 // wave-uniform
-    int c = c0, t = t0 + second;
-    if (t == 9) { t = 0; ++c; }
-    const bool ok = c < nchunk && boff[i] != OOB && c * 4 + bch[i] < cpt4;
+  auto load_weights = [&](int chunk, int t, int stg) {   // the weight tile of step (chunk, tap t) into ring stage `stg`
     const int woff = __builtin_amdgcn_readfirstlane(taps[64 + t]);
-    dma16(rb_desc, ok ? boff[i] + (unsigned)(woff + c * 64) : OOB, lds0 + (unsigned)((2 * ASZ + stg * BSZ) * 16 + j * 1024));
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int j = i * NW + wave;
+      const bool ok = boff[i] != OOB && chunk * 8 + bch[i] < a.cpt;
+      dma16(rb_desc, ok ? boff[i] + (unsigned)(woff + chunk * 128) : OOB, lds0 + (unsigned)((ASZ + stg * BSZ) * 16 + j * 1024));
+    }
   };
 
   {
     const unsigned keep = m0_save();
-#pragma unroll
-    for (int t = 0; t < AI; ++t) dma_a(t, 0, 0);
-#pragma unroll
-    for (int i = 0; i < BI; ++i) dma_b(i, 0, 0, 0);
+    load_patch(0);
+    load_weights(0, 0, 0);
     m0_restore(keep);
   }
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
-  // Patch of chunk c + 1: its buffer held chunk c - 1, last read in step S0(c) - 1, S0(c) = (9c + 1) / 2; chunk c + 1 is first
-  // multiplied in step S0(c) + 4.  So the window is the four steps S0(c) .. S0(c) + 3, one DMA per wave and step, all landed at the
-  // end of the last one.  (c = chunk of the step's first unit: step >= S0(c) always.)
-  int c0 = 0, t0 = 0;                                    // (chunk, tap) of the step's first unit
-  for (int step = 0; step < nstep; ++step) {
-    const uint4* Bb = &smem[2 * ASZ + (step & 1) * BSZ];
-    const bool more = step + 1 < nstep;
-    int c1 = c0, t1 = t0 + 2;                            // first unit of the next step
-    if (t1 >= 9) { t1 -= 9; ++c1; }
-    const int win = step - ((9 * c0 + 1) >> 1);
-    const bool a_window = win < AI && c0 + 1 < nchunk;
-    bool a_issued = false;
-    if (!(a.patch_mode & 2)) {
-      // all of the step's DMAs at its head, as igemm_dma_kernel does: the wave then runs its 20 MFMAs uninterrupted while the other
-      // workgroup of the CU covers the issue stall (DMAs spread behind the MFMA groups measured 8-15 % slower: every issue can
-      // block the in-order wave in front of MFMAs the matrix pipe is ready for)
-      const unsigned keep = m0_save();
-      if (more) {
+  int step = 0;
+  for (int chunk = 0; chunk < nchunk; ++chunk) {
+    const int kcount = min(4, (a.cpt - chunk * 8 + 1) >> 1);    // 16-channel k-steps of this chunk that hold data
+    const uint4* Ab = &smem[0];
 #pragma unroll
-        for (int i = 0; i < BI; ++i) dma_b(i, c1, t1, (step + 1) & 1);
-      }
-      if (a_window) {
-#pragma unroll
-        for (int tt = 0; tt < AI; ++tt)
-          if (tt == win) a_issued = dma_a(tt, c0 + 1, (c0 + 1) & 1);
-      }
-      m0_restore(keep);
-    }
-    uint4 fa[2], fb[2][TN];
-    int cu = c0, tu = t0;                                // k-steps 0,1 multiply unit (c0, t0), k-steps 2,3 the following unit
-    int pp;
-    {
-      const int v = __builtin_amdgcn_readfirstlane(taps[128 + tu]);
-      pp = base_pp + (v >> 16) * W2 + (int)(short)(v & 0xFFFF);
-    }
-    const uint4* Ab = &smem[(cu & 1) * ASZ];
-    fa[0] = Ab[pp * 4 + (lh ^ ((pp >> 2) & 3))];
-#pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = Bb[(lr + 32 * j) * 4 + (lh ^ bsw)];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      const int cur = ks & 1, nxt = cur ^ 1;
-      if (ks + 1 < 4) {
-        if (ks + 1 == 2) {                               // second unit of the step
-          ++tu;
-          if (tu == 9) { tu = 0; ++cu; }
-          const int v = __builtin_amdgcn_readfirstlane(taps[128 + tu]);
-          pp = base_pp + (v >> 16) * W2 + (int)(short)(v & 0xFFFF);
-          Ab = &smem[(cu & 1) * ASZ];
-        }
-        const int kk = (ks + 1) & 1, un = (ks + 1) >> 1;
-        const int ch = 2 * kk + lh;
-        fa[nxt] = Ab[pp * 4 + (ch ^ ((pp >> 2) & 3))];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb[nxt][j] = Bb[(un * BN + lr + 32 * j) * 4 + (ch ^ bsw)];
-      }
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur], fb[cur][j], acc[j]);
-      __builtin_amdgcn_sched_barrier(0);
-      if (a.patch_mode & 2) {                            // A/B (rn_set_variant 1 << 20): DMAs spread behind the MFMA groups
+    for (int t = 0; t < 9; ++t, ++step) {
+      const uint4* Bb = &smem[ASZ + (step & 1) * BSZ];
+      if (step + 1 < nstep) {                            // next step's weights, all at the head (as igemm_dma_kernel)
         const unsigned keep = m0_save();
-#pragma unroll
-        for (int i = 0; i < BI; ++i)
-          if (i % 4 == ks && more) dma_b(i, c1, t1, (step + 1) & 1);
-        if (ks == 3 && a_window) {
-#pragma unroll
-          for (int tt = 0; tt < AI; ++tt)
-            if (tt == win) a_issued = dma_a(tt, c0 + 1, (c0 + 1) & 1);
-        }
+        load_weights(t == 8 ? chunk + 1 : chunk, t == 8 ? 0 : t + 1, (step + 1) & 1);
         m0_restore(keep);
+      }
+      int pp;
+      {
+        const int v = __builtin_amdgcn_readfirstlane(taps[128 + t]);
+        pp = base_pp + (v >> 16) * W2 + (int)(short)(v & 0xFFFF);
+      }
+      const int pa = pp * 8, sa = (pp >> 1) & 7;
+      uint4 fa[2], fb[2][TN];
+      fa[0] = Ab[pa + (lh ^ sa)];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[0][j] = Bb[(lr + 32 * j) * 8 + (lh ^ bsw)];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < 4 && ks + 1 < kcount) {
+          const int ch = 2 * (ks + 1) + lh;
+          fa[nxt] = Ab[pa + (ch ^ sa)];
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[nxt][j] = Bb[(lr + 32 * j) * 8 + (ch ^ bsw)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks < kcount) {
+#pragma unroll
+          for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur], fb[cur][j], acc[j]);
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
+      wait_vmcnt<0>();                                   // next step's weight tile landed (own DMAs), then everybody's
+      __builtin_amdgcn_s_barrier();
     }
-    // next step's weights landed (every wave waits for its own DMAs, then the barrier); the patch DMA of this step may stay in flight,
-    // except in the last step of its window (the next chunk's first unit is multiplied in the next step)
-    if (a_issued && win + 1 < AI) wait_vmcnt<1>(); else wait_vmcnt<0>();
-    __builtin_amdgcn_s_barrier();
-    c0 = c1; t0 = t1;
+    if (chunk + 1 < nchunk) {                            // every wave is done with the patch: reload it for the next chunk
+      const unsigned keep = m0_save();
+      load_patch(chunk + 1);
+      m0_restore(keep);
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+    }
   }
   igemm_epilogue<T, BM, BN, NW, 1, 1, TN, 256, 64>(a, reinterpret_cast<f32x16(&)[1][TN]>(acc), m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
 }
