@@ -1068,7 +1068,8 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 // (chunk, tap) step = 23 KiB per step instead of the im2col kernel's 36 KiB, at the same 20 MFMAs per wave and barrier.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PATCH128_PP_MAX = 208;                     // 6x34 (W=32), 10x18 (W=16), 2 x 10x10 (W=8)
-template <typename T, int BN>
+// FULLC: the channel count is a multiple of 64 (every chunk runs its four k-steps: no tail branches in the hot loop)
+template <typename T, int BN, bool FULLC>
 __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs a) {
   constexpr int BM = 128, NW = 4, ES = (int)sizeof(T), TN = BN / 32;
   constexpr int CHK = 128 / ES;                          // channels per chunk (one 128-byte LDS row per pixel)
@@ -1167,8 +1168,16 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
       }
     }
   };
-  auto load_weights = [&](int chunk, int t, int stg) {   // the weight tile of step (chunk, tap t) into ring stage `stg`
-    const int woff = __builtin_amdgcn_readfirstlane(taps[64 + t]);
+  // per-tap weight byte offsets and patch pixel offsets, read ONCE (the tap index is a compile-time constant in the unrolled loop):
+  // a table lookup per step put an LDS round trip in front of every step's first fragment read
+  int woff_t[9], poff_t[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    woff_t[t] = __builtin_amdgcn_readfirstlane(taps[64 + t]);
+    const int v = __builtin_amdgcn_readfirstlane(taps[128 + t]);
+    poff_t[t] = (v >> 16) * W2 + (int)(short)(v & 0xFFFF);
+  }
+  auto load_weights = [&](int chunk, int woff, int stg) {   // the weight tile of a step into ring stage `stg`
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int j = i * NW + wave;
@@ -1180,7 +1189,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
   {
     const unsigned keep = m0_save();
     load_patch(0);
-    load_weights(0, 0, 0);
+    load_weights(0, woff_t[0], 0);
     m0_restore(keep);
   }
   wait_vmcnt<0>();
@@ -1188,21 +1197,17 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
 
   int step = 0;
   for (int chunk = 0; chunk < nchunk; ++chunk) {
-    const int kcount = min(4, (a.cpt - chunk * 8 + 1) >> 1);    // 16-channel k-steps of this chunk that hold data
+    const int kcount = FULLC ? 4 : min(4, (a.cpt - chunk * 8 + 1) >> 1);    // 16-channel k-steps of this chunk that hold data
     const uint4* Ab = &smem[0];
 #pragma unroll
     for (int t = 0; t < 9; ++t, ++step) {
       const uint4* Bb = &smem[ASZ + (step & 1) * BSZ];
       if (step + 1 < nstep) {                            // next step's weights, all at the head (as igemm_dma_kernel)
         const unsigned keep = m0_save();
-        load_weights(t == 8 ? chunk + 1 : chunk, t == 8 ? 0 : t + 1, (step + 1) & 1);
+        load_weights(t == 8 ? chunk + 1 : chunk, woff_t[t == 8 ? 0 : t + 1], (step + 1) & 1);
         m0_restore(keep);
       }
-      int pp;
-      {
-        const int v = __builtin_amdgcn_readfirstlane(taps[128 + t]);
-        pp = base_pp + (v >> 16) * W2 + (int)(short)(v & 0xFFFF);
-      }
+      const int pp = base_pp + poff_t[t];
       const int pa = pp * 8, sa = (pp >> 1) & 7;
       uint4 fa[2], fb[2][TN];
       fa[0] = Ab[pa + (lh ^ sa)];
@@ -1211,14 +1216,14 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) {
         const int cur = ks & 1, nxt = cur ^ 1;
-        if (ks + 1 < 4 && ks + 1 < kcount) {
+        if (ks + 1 < 4 && (FULLC || ks + 1 < kcount)) {
           const int ch = 2 * (ks + 1) + lh;
           fa[nxt] = Ab[pa + (ch ^ sa)];
 #pragma unroll
           for (int j = 0; j < TN; ++j) fb[nxt][j] = Bb[(lr + 32 * j) * 8 + (ch ^ bsw)];
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (ks < kcount) {
+        if (FULLC || ks < kcount) {
 #pragma unroll
           for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur], fb[cur][j], acc[j]);
         }
@@ -1261,7 +1266,8 @@ static bool patch_ok(const IgemmArgs& a, int BN, int BM) {
 template <typename T, int BN> int launch_patch128(const IgemmArgs& a, hipStream_t s) {
   rn_note_kernel("igemm_patch<128x%d>", BN);
   if (rn_dry_run()) return 0;
-  hipLaunchKernelGGL((igemm_patch128_kernel<T, BN>), dim3(cdiv(a.M, 128) * cdiv(a.Kd, BN)), dim3(256), 0, s, a);
+  if (a.Cs % 64 == 0) hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, true>), dim3(cdiv(a.M, 128) * cdiv(a.Kd, BN)), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, false>), dim3(cdiv(a.M, 128) * cdiv(a.Kd, BN)), dim3(256), 0, s, a);
   RN_CHECK_LAUNCH("igemm_patch128");
   return 0;
 }
@@ -1277,19 +1283,20 @@ template <typename T, int BN> int launch_patch(const IgemmArgs& a, hipStream_t s
 template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   const int K = a.Kd;
-  // LDS-patch kernels (3x3 stride 1): EXPERIMENTAL, opt-in through rn_set_variant.  They cut the LDS-DMA instructions per FLOP by 1.6x
-  // (128-pixel tiles) / 2.9x (256-pixel tiles) and are parity-tested, but measured 0-17 % SLOWER than the im2col kernels below on the
-  // WRN-28-10 shapes (the K loop is bound by bytes in flight per CU and by LDS fragment reads, not by DMA issue
-  // alone).  Bits: 1 << 21 = 128-pixel tiles (two workgroups per CU), 1 << 18 = 256-pixel tiles (one per CU).
+  // LDS-patch kernels (3x3 stride 1, 16-bit types).  The 128-pixel kernel (two workgroups per CU, 23 KiB instead of 36 KiB of DMA per K
+  // step) is the default wherever the grid keeps two workgroups on every CU (>= 512 tiles): measured in one process against the im2col
+  // kernel on the WRN-28-10 shapes, forward / dgrad: stage 1 (1,024 tiles) 84.5 / 84.1 vs 88.2 / 89.0 us, stage 2 (512 tiles) 65.7 / 67.3
+  // vs 71.5 / 74.6 us; on a 256-tile grid the wave-specialised im2col kernel wins (79 vs 69 us).  rn_set_variant: 2 = never,
+  // 1 << 21 = wherever the geometry allows (with 16: any grid), 1 << 18 = the 256-pixel one-workgroup-per-CU variant (experimental:
+  // 2.9x fewer DMA bytes per FLOP, but its single workgroup exposes prologue, epilogue and per-step latencies: 0-20 % slower).
   if constexpr (sizeof(T) == 2) {
     if (g_rn_variant & (1 << 18)) {
       if (K % 160 == 0 && patch_ok(a, 160, 256)) return launch_patch<T, 160>(a, s);
       if (K % 160 != 0 && K % 128 == 0 && patch_ok(a, 128, 256)) return launch_patch<T, 128>(a, s);
     }
-    if (g_rn_variant & (1 << 21)) {
-      if (K % 160 == 0 && patch_ok(a, 160, 128)) return launch_patch128<T, 160>(a, s);
-      if (K % 160 != 0 && K % 128 == 0 && patch_ok(a, 128, 128)) return launch_patch128<T, 128>(a, s);
-    }
+    const int bn = K % 160 == 0 ? 160 : (K % 128 == 0 ? 128 : 0);
+    if (bn && patch_ok(a, bn, 128) && ((g_rn_variant & (1 << 21)) || (long)cdiv(a.M, 128) * cdiv(K, bn) >= 512))
+      return bn == 160 ? launch_patch128<T, 160>(a, s) : launch_patch128<T, 128>(a, s);
   }
   // column tile: the widest of {160,128,96,64,32} that wastes no 32-column MFMA tile.  256-row tiles were measured and removed:
   // 4 consumer + 4 loader waves of 64 x BN, or 8 homogeneous waves with a 3-stage ring (one workgroup per CU): 5-12 % slower on
