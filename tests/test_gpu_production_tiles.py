@@ -194,3 +194,54 @@ def test_patch_kernels_on_production_shapes(g, kern):
     """WRN-28-10 stage 1 / stage 2 at batch 128 through the opt-in patch kernels (grids of 512-1024 workgroups, XCD remap, two column tiles)."""
     ran = run_conv_case(g, 'fp16', variant=PATCH_KERNELS[kern] & ~16, expect_same_names=False)
     assert sum(n.startswith(f'igemm_patch<{kern}x') for n in ran) == 2, ran
+
+
+WGRAD3_SMALL = [
+    (3, 8, 8, 64, 64, 3, 1, 1),          # one 64-channel tile, several images per 64-pixel step (image boundaries inside a k-step)
+    (2, 9, 7, 72, 48, 3, 1, 1),          # odd map (rows of 7 pixels), channel tail (72 = 64 + 8), K = 48
+    (5, 16, 16, 160, 160, 3, 1, 1),      # 2.5 channel tiles, K tile 160
+    (1, 32, 32, 64, 320, 3, 1, 1),       # two K tiles
+    (2, 5, 3, 64, 32, 3, 1, 1),          # 3-pixel rows: both halo taps masked on almost every pixel
+    (7, 8, 8, 128, 96, 3, 1, 1),         # 448 pixels: uneven pixel splits
+]
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('g', WGRAD3_SMALL)
+def test_wgrad_three_taps_per_workgroup(g, dtype):
+    """the 3x3 weight-gradient kernel that gives a workgroup a whole row of taps (zero-row masking of the padding, shifted reads of
+    one x tile), on shapes that exercise image boundaries, tails and splits; and the same shapes through the one-tap kernel."""
+    ran = run_conv_case(g, dtype, expect_same_names=False)
+    assert any(n.startswith('wgrad3<') for n in ran), ran
+    ran = run_conv_case(g, dtype, variant=256, expect_same_names=False)
+    assert not any(n.startswith('wgrad3<') for n in ran), ran
+
+
+def test_wgrad3_exact_integers():
+    """integer-valued operands: every product and partial sum is exact in fp32, the result must equal the reference bit for bit
+    (catches a wrong pixel <-> fragment-element map or a mis-shifted tap, which a tolerance could blur)."""
+    import gpu_harness as h
+    g = (4, 16, 16, 64, 64, 3, 1, 1)
+    gm = geom(*g)
+    N, Hh, W, C, K, k, s, p = g
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, Hh, W, C)); dy = b.slot('dy', (N, Hh, W, K)); dw = b.slot('dw', (K, 3, 3, C), 'f32'); ws = b.slot('workspace', (0,), 'u8')
+    b.op(ir.OP_CONV_WGRAD, buf=dict(x=x, dy=dy, dw=dw, ws=ws), dim=dict(gm))
+    b.ws_need.append(('wgrad', gm))
+    plan = b.plan(False)
+    plan.slot_of['ws'] = ws
+    rng = np.random.RandomState(0)
+    xv = rng.randint(-3, 4, size=(N, Hh, W, C)).astype(np.float32)
+    dv = rng.randint(-2, 3, size=(N, Hh, W, K)).astype(np.float32)
+    from pytorch_ddp_resnet_amd.engine.executor import Engine
+    eng = Engine(plan, h.DEV, torch.float16)
+    eng.tensors[x].copy_(torch.from_numpy(xv).to(torch.float16)); eng.tensors[dy].copy_(torch.from_numpy(dv).to(torch.float16))
+    eng.bind({})
+    L = _lib.lib()
+    L.rn_kernel_log(1)
+    eng.run(0, 1, 0)
+    torch.cuda.synchronize()
+    assert 'wgrad3<' in L.rn_kernel_log_read().decode()
+    L.rn_kernel_log(0)
+    ref = torch.nn.grad.conv2d_weight(_nchw(torch.from_numpy(xv)), (K, C, 3, 3), _nchw(torch.from_numpy(dv)), 1, 1).permute(0, 2, 3, 1)
+    assert torch.equal(eng.tensors[dw].cpu(), ref.contiguous())
