@@ -558,9 +558,14 @@ int wgrad_splits(const rn_conv_geom* g, int bk, int bc, bool im2col = false) {
 }
 
 // three-taps-per-workgroup kernel: which geometries take it, and its split count (one resident round of 512 workgroups)
+inline bool wgrad3_geom_ok(const rn_conv_geom* g) {
+  return g->R == 3 && g->S == 3 && g->stride == 1 && g->pad == 1 && g->P == g->H && g->Q == g->W && g->C >= 64 && g->Q >= 2;
+}
 inline bool use_wgrad3(const rn_conv_geom* g, int dtype) {
-  if (g_rn_variant & 256) return false;                 // A/B switch: 256 = one tap per workgroup everywhere
-  return dtype != RN_F32 && g->R == 3 && g->S == 3 && g->stride == 1 && g->pad == 1 && g->P == g->H && g->Q == g->W && g->C >= 64 && g->Q >= 2;
+  // EXPERIMENTAL, opt-in (rn_set_variant 1 << 22): parity-tested, 28-40 % fewer bytes per FLOP, but measured 10-30 % SLOWER than
+  // wgrad_kernel on the WRN-28-10 shapes (253 registers, per-k-step pixel decode and address selects for the zero-row masking)
+  if (!(g_rn_variant & (1 << 22))) return false;
+  return dtype != RN_F32 && wgrad3_geom_ok(g);
 }
 inline int wgrad3_splits(const rn_conv_geom* g, int bk) {
   const long M = (long)g->N * g->P * g->Q;
@@ -624,7 +629,7 @@ extern "C" size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g) {
     const size_t need = (size_t)wgrad_splits(g, bk, bc, ic) * g->K * g->R * g->S * g->C * sizeof(float);
     if (need > best) best = need;
   }
-  if (use_wgrad3(g, RN_F16)) {
+  if (wgrad3_geom_ok(g)) {                               // sized for either kernel, whatever the variant switch says at this moment
     const size_t need = (size_t)wgrad3_splits(g, pick_tile(g->K)) * g->K * g->R * g->S * g->C * sizeof(float);
     if (need > best) best = need;
   }
