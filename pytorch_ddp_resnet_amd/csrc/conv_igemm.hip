@@ -1069,7 +1069,7 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PATCH128_PP_MAX = 208;                     // 6x34 (W=32), 10x18 (W=16), 2 x 10x10 (W=8)
 // FULLC: the channel count is a multiple of 64 (every chunk runs its four k-steps: no tail branches in the hot loop)
-template <typename T, int BN, bool FULLC>
+template <typename T, int BN, bool FULLC, bool DEFER>
 __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs a) {
   constexpr int BM = 128, NW = 4, ES = (int)sizeof(T), TN = BN / 32;
   constexpr int CHK = 128 / ES;                          // channels per chunk (one 128-byte LDS row per pixel)
@@ -1195,42 +1195,88 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
+  // One step = (chunk, tap): four 16-channel k-steps of 5 MFMAs per wave.  With DEFER, in a full chunk the LAST k-step's MFMAs run
+  // behind the step's closing barrier: their fragments are already in registers, so they cover the flight of the NEXT step's first
+  // fragments (which may only be read after that barrier) -- the post-barrier fragment latency no longer idles the matrix pipe.
+  uint4 fa0, fa1, fb0[TN], fb1[TN];
+#define RN_LOAD_FRAGS(FA, FB, AB, BB, PA, SA, KS)                                   \
+  {                                                                                \
+    const int ch_ = 2 * (KS) + lh;                                                 \
+    FA = (AB)[(PA) + (ch_ ^ (SA))];                                                \
+    _Pragma("unroll") for (int j = 0; j < TN; ++j) FB[j] = (BB)[(lr + 32 * j) * 8 + (ch_ ^ bsw)]; \
+  }
+#define RN_MFMA_GROUP(FA, FB)                                                      \
+  { _Pragma("unroll") for (int j = 0; j < TN; ++j) Mfma<T>::run(FA, FB[j], acc[j]); }
   int step = 0;
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const int kcount = FULLC ? 4 : min(4, (a.cpt - chunk * 8 + 1) >> 1);    // 16-channel k-steps of this chunk that hold data
+    const bool full = FULLC || kcount == 4;
     const uint4* Ab = &smem[0];
+    if (DEFER && full) {
 #pragma unroll
-    for (int t = 0; t < 9; ++t, ++step) {
-      const uint4* Bb = &smem[ASZ + (step & 1) * BSZ];
-      if (step + 1 < nstep) {                            // next step's weights, all at the head (as igemm_dma_kernel)
-        const unsigned keep = m0_save();
-        load_weights(t == 8 ? chunk + 1 : chunk, woff_t[t == 8 ? 0 : t + 1], (step + 1) & 1);
-        m0_restore(keep);
-      }
-      const int pp = base_pp + poff_t[t];
-      const int pa = pp * 8, sa = (pp >> 1) & 7;
-      uint4 fa[2], fb[2][TN];
-      fa[0] = Ab[pa + (lh ^ sa)];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[0][j] = Bb[(lr + 32 * j) * 8 + (lh ^ bsw)];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int cur = ks & 1, nxt = cur ^ 1;
-        if (ks + 1 < 4 && (FULLC || ks + 1 < kcount)) {
-          const int ch = 2 * (ks + 1) + lh;
-          fa[nxt] = Ab[pa + (ch ^ sa)];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) fb[nxt][j] = Bb[(lr + 32 * j) * 8 + (ch ^ bsw)];
+      for (int t = 0; t < 9; ++t, ++step) {
+        const uint4* Bb = &smem[ASZ + (step & 1) * BSZ];
+        const uint4* Bn = &smem[ASZ + ((step + 1) & 1) * BSZ];
+        if (step + 1 < nstep) {                          // next step's weights, all at the head (as igemm_dma_kernel)
+          const unsigned keep = m0_save();
+          load_weights(t == 8 ? chunk + 1 : chunk, woff_t[t == 8 ? 0 : t + 1], (step + 1) & 1);
+          m0_restore(keep);
+        }
+        const int pp = base_pp + poff_t[t];
+        const int pa = pp * 8, sa = (pp >> 1) & 7;
+        if (t == 0) RN_LOAD_FRAGS(fa0, fb0, Ab, Bb, pa, sa, 0)      // taps 1..8: prefetched behind the previous step's barrier
+        RN_LOAD_FRAGS(fa1, fb1, Ab, Bb, pa, sa, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        RN_MFMA_GROUP(fa0, fb0)
+        __builtin_amdgcn_sched_barrier(0);
+        RN_LOAD_FRAGS(fa0, fb0, Ab, Bb, pa, sa, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        RN_MFMA_GROUP(fa1, fb1)
+        __builtin_amdgcn_sched_barrier(0);
+        RN_LOAD_FRAGS(fa1, fb1, Ab, Bb, pa, sa, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        RN_MFMA_GROUP(fa0, fb0)
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt<0>();                                 // next step's weight tile landed (own DMAs) ...
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and this wave's reads of the current stage have returned
+        __builtin_amdgcn_s_barrier();
+        if (t < 8) {                                     // same patch, next tap: its first fragments fly under the deferred MFMAs
+          const int pn = base_pp + poff_t[t < 8 ? t + 1 : 0];
+          RN_LOAD_FRAGS(fa0, fb0, Ab, Bn, pn * 8, (pn >> 1) & 7, 0)
         }
         __builtin_amdgcn_sched_barrier(0);
-        if (FULLC || ks < kcount) {
-#pragma unroll
-          for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur], fb[cur][j], acc[j]);
-        }
+        RN_MFMA_GROUP(fa1, fb1)                          // k-step 3 of THIS step
         __builtin_amdgcn_sched_barrier(0);
       }
-      wait_vmcnt<0>();                                   // next step's weight tile landed (own DMAs), then everybody's
-      __builtin_amdgcn_s_barrier();
+    } else {
+#pragma unroll
+      for (int t = 0; t < 9; ++t, ++step) {
+        const uint4* Bb = &smem[ASZ + (step & 1) * BSZ];
+        if (step + 1 < nstep) {
+          const unsigned keep = m0_save();
+          load_weights(t == 8 ? chunk + 1 : chunk, woff_t[t == 8 ? 0 : t + 1], (step + 1) & 1);
+          m0_restore(keep);
+        }
+        const int pp = base_pp + poff_t[t];
+        const int pa = pp * 8, sa = (pp >> 1) & 7;
+        RN_LOAD_FRAGS(fa0, fb0, Ab, Bb, pa, sa, 0)
+        if (full || 1 < kcount) RN_LOAD_FRAGS(fa1, fb1, Ab, Bb, pa, sa, 1)
+        __builtin_amdgcn_sched_barrier(0);
+        RN_MFMA_GROUP(fa0, fb0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (full || 2 < kcount) RN_LOAD_FRAGS(fa0, fb0, Ab, Bb, pa, sa, 2)
+        __builtin_amdgcn_sched_barrier(0);
+        if (full || 1 < kcount) RN_MFMA_GROUP(fa1, fb1)
+        __builtin_amdgcn_sched_barrier(0);
+        if (full || 3 < kcount) RN_LOAD_FRAGS(fa1, fb1, Ab, Bb, pa, sa, 3)
+        __builtin_amdgcn_sched_barrier(0);
+        if (full || 2 < kcount) RN_MFMA_GROUP(fa0, fb0)
+        __builtin_amdgcn_sched_barrier(0);
+        if (full || 3 < kcount) RN_MFMA_GROUP(fa1, fb1)
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vmcnt<0>();                                 // next step's weight tile landed (own DMAs), then everybody's
+        __builtin_amdgcn_s_barrier();
+      }
     }
     if (chunk + 1 < nchunk) {                            // every wave is done with the patch: reload it for the next chunk
       const unsigned keep = m0_save();
@@ -1240,6 +1286,8 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
       __builtin_amdgcn_s_barrier();
     }
   }
+#undef RN_LOAD_FRAGS
+#undef RN_MFMA_GROUP
   igemm_epilogue<T, BM, BN, NW, 1, 1, TN, 256, 64>(a, reinterpret_cast<f32x16(&)[1][TN]>(acc), m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
 }
 
@@ -1266,8 +1314,14 @@ static bool patch_ok(const IgemmArgs& a, int BN, int BM) {
 template <typename T, int BN> int launch_patch128(const IgemmArgs& a, hipStream_t s) {
   rn_note_kernel("igemm_patch<128x%d>", BN);
   if (rn_dry_run()) return 0;
-  if (a.Cs % 64 == 0) hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, true>), dim3(cdiv(a.M, 128) * cdiv(a.Kd, BN)), dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, false>), dim3(cdiv(a.M, 128) * cdiv(a.Kd, BN)), dim3(256), 0, s, a);
+  const dim3 grid(cdiv(a.M, 128) * cdiv(a.Kd, BN));
+  if (g_rn_variant & (1 << 23)) {                        // A/B: no deferral of the last k-step
+    if (a.Cs % 64 == 0) hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, false, false>), grid, dim3(256), 0, s, a);
+  } else {
+    if (a.Cs % 64 == 0) hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, true, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, false, false>), grid, dim3(256), 0, s, a);   // both step bodies in one kernel spill: no deferral with a tail chunk
+  }
   RN_CHECK_LAUNCH("igemm_patch128");
   return 0;
 }
