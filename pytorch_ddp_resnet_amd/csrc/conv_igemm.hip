@@ -1069,7 +1069,7 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PATCH128_PP_MAX = 208;                     // 6x34 (W=32), 10x18 (W=16), 2 x 10x10 (W=8)
 // FULLC: the channel count is a multiple of 64 (every chunk runs its four k-steps: no tail branches in the hot loop)
-template <typename T, int BN, bool FULLC, bool DEFER>
+template <typename T, int BN, bool FULLC>
 __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs a) {
   constexpr int BM = 128, NW = 4, ES = (int)sizeof(T), TN = BN / 32;
   constexpr int CHK = 128 / ES;                          // channels per chunk (one 128-byte LDS row per pixel)
@@ -1195,9 +1195,8 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
-  // One step = (chunk, tap): four 16-channel k-steps of 5 MFMAs per wave.  With DEFER, in a full chunk the LAST k-step's MFMAs run
-  // behind the step's closing barrier: their fragments are already in registers, so they cover the flight of the NEXT step's first
-  // fragments (which may only be read after that barrier) -- the post-barrier fragment latency no longer idles the matrix pipe.
+  // One step = (chunk, tap): four 16-channel k-steps of 5 MFMAs per wave, fragments of k-step ks + 1 in flight under the MFMAs of ks.
+  // (Deferring the last k-step's MFMAs behind the closing barrier, to cover the next step's first fragment reads, was measured +-0.)
   uint4 fa0, fa1, fb0[TN], fb1[TN];
 #define RN_LOAD_FRAGS(FA, FB, AB, BB, PA, SA, KS)                                   \
   {                                                                                \
@@ -1212,43 +1211,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
     const int kcount = FULLC ? 4 : min(4, (a.cpt - chunk * 8 + 1) >> 1);    // 16-channel k-steps of this chunk that hold data
     const bool full = FULLC || kcount == 4;
     const uint4* Ab = &smem[0];
-    if (DEFER && full) {
-#pragma unroll
-      for (int t = 0; t < 9; ++t, ++step) {
-        const uint4* Bb = &smem[ASZ + (step & 1) * BSZ];
-        const uint4* Bn = &smem[ASZ + ((step + 1) & 1) * BSZ];
-        if (step + 1 < nstep) {                          // next step's weights, all at the head (as igemm_dma_kernel)
-          const unsigned keep = m0_save();
-          load_weights(t == 8 ? chunk + 1 : chunk, woff_t[t == 8 ? 0 : t + 1], (step + 1) & 1);
-          m0_restore(keep);
-        }
-        const int pp = base_pp + poff_t[t];
-        const int pa = pp * 8, sa = (pp >> 1) & 7;
-        if (t == 0) RN_LOAD_FRAGS(fa0, fb0, Ab, Bb, pa, sa, 0)      // taps 1..8: prefetched behind the previous step's barrier
-        RN_LOAD_FRAGS(fa1, fb1, Ab, Bb, pa, sa, 1)
-        __builtin_amdgcn_sched_barrier(0);
-        RN_MFMA_GROUP(fa0, fb0)
-        __builtin_amdgcn_sched_barrier(0);
-        RN_LOAD_FRAGS(fa0, fb0, Ab, Bb, pa, sa, 2)
-        __builtin_amdgcn_sched_barrier(0);
-        RN_MFMA_GROUP(fa1, fb1)
-        __builtin_amdgcn_sched_barrier(0);
-        RN_LOAD_FRAGS(fa1, fb1, Ab, Bb, pa, sa, 3)
-        __builtin_amdgcn_sched_barrier(0);
-        RN_MFMA_GROUP(fa0, fb0)
-        __builtin_amdgcn_sched_barrier(0);
-        wait_vmcnt<0>();                                 // next step's weight tile landed (own DMAs) ...
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // ... and this wave's reads of the current stage have returned
-        __builtin_amdgcn_s_barrier();
-        if (t < 8) {                                     // same patch, next tap: its first fragments fly under the deferred MFMAs
-          const int pn = base_pp + poff_t[t < 8 ? t + 1 : 0];
-          RN_LOAD_FRAGS(fa0, fb0, Ab, Bn, pn * 8, (pn >> 1) & 7, 0)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        RN_MFMA_GROUP(fa1, fb1)                          // k-step 3 of THIS step
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
+    {
 #pragma unroll
       for (int t = 0; t < 9; ++t, ++step) {
         const uint4* Bb = &smem[ASZ + (step & 1) * BSZ];
@@ -1315,13 +1278,8 @@ template <typename T, int BN> int launch_patch128(const IgemmArgs& a, hipStream_
   rn_note_kernel("igemm_patch<128x%d>", BN);
   if (rn_dry_run()) return 0;
   const dim3 grid(cdiv(a.M, 128) * cdiv(a.Kd, BN));
-  if (g_rn_variant & (1 << 23)) {                        // A/B: no deferral of the last k-step
-    if (a.Cs % 64 == 0) hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, true, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, false, false>), grid, dim3(256), 0, s, a);
-  } else {
-    if (a.Cs % 64 == 0) hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, true, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, false, false>), grid, dim3(256), 0, s, a);   // both step bodies in one kernel spill: no deferral with a tail chunk
-  }
+  if (a.Cs % 64 == 0) hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, false>), grid, dim3(256), 0, s, a);
   RN_CHECK_LAUNCH("igemm_patch128");
   return 0;
 }

@@ -545,10 +545,10 @@ constexpr int IM2COL_BC = 160;
 inline int col_tile(const rn_conv_geom* g, bool ic) { return ic ? IM2COL_BC : pick_tile(g->C); }
 inline bool use_im2col(const rn_conv_geom* g, int dtype_ce) { return g->C == dtype_ce && g->R * g->S >= 4; }   // one-chunk inputs: the stem
 
-int wgrad_splits(const rn_conv_geom* g, int bk, int bc, bool im2col = false) {
+int wgrad_splits(const rn_conv_geom* g, int bk, int bc, bool im2col = false, int capacity = 512) {
   const long M = (long)g->N * g->P * g->Q;
   const int tiles = im2col ? cdiv(g->K, bk) * cdiv(g->R * g->S * g->C, bc) : cdiv(g->K, bk) * cdiv(g->C, bc) * g->R * g->S;
-  int splits = 512 / tiles;                              // one resident round: 2 workgroups per CU x 256 CUs (1 per CU for the
+  int splits = capacity / tiles;                         // one resident round: 2 workgroups per CU x 256 CUs (1 per CU for the
                                                          // forked launches, to leave registers for the main stream: -1.5 %)
   const int max_by_rows = (int)((M + 255) / 256);      // at least 8 K-steps per block
   if (splits > max_by_rows) splits = max_by_rows;
@@ -661,7 +661,11 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   for (int r = 0; r < g->R; ++r)
     for (int t = 0; t < g->S; ++t) { a.dh[r * g->S + t] = r - g->pad; a.dw[r * g->S + t] = t - g->pad; }
   a.M = g->N * g->P * g->Q;
-  a.splits = w3 ? wgrad3_splits(g, bk) : wgrad_splits(g, bk, bc, ic);
+  // A FORKED weight gradient (side stream, beside the data-gradient / BatchNorm chain) is sized to 7/8 of a resident round: a
+  // one-round grid retires no workgroup until it ends, so the chain's tiny finalize kernels waited ~19 us each for a slot
+  // (26 per WRN-28-10 step); with an eighth of the slots left free they dispatch at once.  rn_set_variant 1 << 24: full round.
+  const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? 448 : 512;
+  a.splits = w3 ? wgrad3_splits(g, bk) : wgrad_splits(g, bk, bc, ic, capacity);
   a.rows_per_split = ((a.M + a.splits - 1) / a.splits + 31) / 32 * 32;
   a.kt = cdiv(g->K, bk); a.ct = cdiv(ic ? g->R * g->S * g->C : g->C, bc);
   const size_t n = (size_t)g->K * a.RS * g->C;
