@@ -10,6 +10,7 @@
 // Work split: (K tile x C tile x tap) x pixel-splits; each block reduces its pixel range into an fp32 slab, a
 // second kernel sums the slabs in a fixed order (bitwise reproducible; no float atomics).
 #include "common.h"
+#include <stdlib.h>
 
 extern int g_rn_variant;   // conv_igemm.hip (rn_set_variant)
 
@@ -664,7 +665,8 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   // A FORKED weight gradient (side stream, beside the data-gradient / BatchNorm chain) is sized to 7/8 of a resident round: a
   // one-round grid retires no workgroup until it ends, so the chain's tiny finalize kernels waited ~19 us each for a slot
   // (26 per WRN-28-10 step); with an eighth of the slots left free they dispatch at once.  rn_set_variant 1 << 24: full round.
-  const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? 448 : 512;
+  static const int fork_cap = getenv("RN_WGRAD_FORK_CAP") ? atoi(getenv("RN_WGRAD_FORK_CAP")) : 448;      // tuning hook
+  const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? fork_cap : 512;
   a.splits = w3 ? wgrad3_splits(g, bk) : wgrad_splits(g, bk, bc, ic, capacity);
   a.rows_per_split = ((a.M + a.splits - 1) / a.splits + 31) / 32 * 32;
   a.kt = cdiv(g->K, bk); a.ct = cdiv(ic ? g->R * g->S * g->C : g->C, bc);
