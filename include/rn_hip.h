@@ -244,6 +244,16 @@ int rn_pool_fc_bwd(const float* dlogits, const float* feat, const float* w, void
 int rn_softmax_ce(const float* logits, const int64_t* labels, float* out3, float* dlogits, int N, int O, float scale,
                   const float* scale_dev, rn_stream s);
 
+/* Input pipeline on the device: the data_aug_train chain of the reference's shipped configs (transform_util.py:36-205, order
+ * config.yaml:6-14) for a whole batch in ONE launch: ToTensor (u8 HWC / 255) -> whitening ((x - mean) [/ stddev], per pixel and
+ * channel, [C,H,W] images; stddev NULL = ZeroMeanWhiteningTransform) -> horizontal flip (per-sample byte) -> padding (pad pixels,
+ * zero or mirror = F.pad reflect) -> crop (per-sample top / left, crop x crop).  The random draws are inputs.  Outputs (either
+ * may be NULL): out_nchw fp32 [N,C,crop,crop] (what the reference's loader hands to classifier(x)) and out_nhwc [N,crop,crop,CP]
+ * in `dtype` with the channels zero-padded to CP (the engine's stem input: skips rn_img_to_nhwc). */
+int rn_augment_batch(const unsigned char* x_nhwc_u8, const float* mean_chw, const float* stddev_chw, const unsigned char* flip,
+                     const int32_t* top, const int32_t* left, float* out_nchw, void* out_nhwc, int dtype, int N, int H, int W, int C,
+                     int pad, int pad_mirror, int crop, int CP, rn_stream s);
+
 /* fused multi-tensor SGD over one flat fp32 buffer (torch.optim.SGD rule; optim_util.py:11-18, config.yaml:22-28) */
 int rn_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
                 float dampening, float weight_decay, int nesterov, int first_step, float grad_scale, rn_stream s);

@@ -369,6 +369,47 @@ __global__ __launch_bounds__(NT) void sgd_kernel(float* __restrict__ p, const fl
   }
 }
 
+// ---- input pipeline on the device: the data_aug_train chain of the shipped configs as ONE pass over a batch -------
+// reference, per sample on the host (transform_util.py): ToTensorTransform :36-47 (u8 HWC -> float CHW / 255), ZeroMean / Standardize
+// whitening :50-109 ((x - mean) / stddev with per-pixel per-channel statistics), FlipTransform :156-166 (tc.flip(x, dims=(2,)) = the W
+// axis), PaddingTransform :169-187 (F.pad reflect | constant 0), RandomCropTransform :190-205 (x[:, t:t+s, l:l+s]); order config.yaml:6-14.
+// One thread per output pixel composes the index maps backwards: crop -> padding (reflect / zero) -> flip -> whitening at the SOURCE
+// coordinate (whitening precedes the flip).  The random draws (flip bit, crop offsets) are inputs.
+template <typename T>
+__global__ __launch_bounds__(NT) void augment_kernel(const unsigned char* __restrict__ x, const float* __restrict__ mean, const float* __restrict__ inv_std,
+                                                     const unsigned char* __restrict__ flip, const int* __restrict__ top, const int* __restrict__ left,
+                                                     float* __restrict__ out_nchw, T* __restrict__ out_nhwc, int N, int H, int W, int C, int pad,
+                                                     int mirror, int crop, int CP) {
+  const long n_out = (long)N * crop * crop;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n_out; i += (long)gridDim.x * NT) {
+    const int n = (int)(i / (crop * crop)), r = (int)(i - (long)n * crop * crop);
+    const int oi = r / crop, oj = r - oi * crop;
+    int hi = top[n] + oi - pad, wj = left[n] + oj - pad;   // coordinates in the (flipped) unpadded image
+    bool inside = true;
+    if (mirror) {                                          // F.pad(mode='reflect'): -1 -> 1, H -> H - 2 (the edge is not repeated)
+      hi = hi < 0 ? -hi : (hi >= H ? 2 * (H - 1) - hi : hi);
+      wj = wj < 0 ? -wj : (wj >= W ? 2 * (W - 1) - wj : wj);
+      hi = min(max(hi, 0), H - 1);                         // offsets outside RandomCrop's range (caller error) must not leave the image
+      wj = min(max(wj, 0), W - 1);
+    } else {
+      inside = (unsigned)hi < (unsigned)H && (unsigned)wj < (unsigned)W;
+    }
+    const int ws = flip[n] ? W - 1 - wj : wj;              // source column before the flip
+    for (int c = 0; c < (out_nhwc ? CP : C); ++c) {
+      float v = 0.f;
+      if (c < C && inside) {
+        const long hw = (long)hi * W + ws;
+        v = (float)x[((long)n * H * W + hw) * C + c] / 255.f;        // ToTensor
+        const long st = (long)c * H * W + hw;
+        v = v - mean[st];
+        if (inv_std) v = v / inv_std[st];                  // inv_std holds the stddev image: the reference DIVIDES (kept bit-exact)
+      }
+      if (out_nchw && c < C) out_nchw[(((long)n * C + c) * crop + oi) * crop + oj] = v;
+      if (out_nhwc) out_nhwc[i * CP + c] = Elem<T>::from_f(v);
+    }
+  }
+}
+
 inline int ew_grid(long n) {
   long b = (n + NT - 1) / NT;
   if (b > 4096) b = 4096;
@@ -489,6 +530,25 @@ extern "C" int rn_pool_fc_bwd(const float* dlogits, const float* feat, const flo
     RN_BY_DTYPE(dtype, hipLaunchKernelGGL((fc_dgrad_kernel<T_>), dim3(N), dim3(NT), 0, as_stream(s), dlogits, w, (T_*)dx, HW, C, O));
     RN_CHECK_LAUNCH("fc_dgrad");
   }
+  return 0;
+}
+
+extern "C" int rn_augment_batch(const unsigned char* x_nhwc_u8, const float* mean_chw, const float* stddev_chw, const unsigned char* flip, const int32_t* top,
+                                const int32_t* left, float* out_nchw, void* out_nhwc, int dtype, int N, int H, int W, int C, int pad, int pad_mirror,
+                                int crop, int CP, rn_stream s) {
+  RN_CHECK_ARG(x_nhwc_u8 && mean_chw && flip && top && left && (out_nchw || out_nhwc), "rn_augment_batch: null pointer");
+  RN_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && pad >= 0 && crop > 0 && crop <= H + 2 * pad && crop <= W + 2 * pad, "rn_augment_batch: bad shape");
+  RN_CHECK_ARG(!pad_mirror || (pad < H && pad < W), "rn_augment_batch: reflect padding needs pad < H, W");
+  RN_CHECK_ARG(!out_nhwc || (RN_DTYPE_OK(dtype) && CP >= C), "rn_augment_batch: bad NHWC output (dtype %d, CP %d)", dtype, CP);
+  const long n = (long)N * crop * crop;
+  if (!out_nhwc) {
+    hipLaunchKernelGGL((augment_kernel<float>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), x_nhwc_u8, mean_chw, stddev_chw, flip, top, left, out_nchw,
+                       (float*)nullptr, N, H, W, C, pad, pad_mirror ? 1 : 0, crop, CP);
+  } else {
+    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((augment_kernel<T_>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), x_nhwc_u8, mean_chw, stddev_chw, flip, top, left,
+                                          out_nchw, (T_*)out_nhwc, N, H, W, C, pad, pad_mirror ? 1 : 0, crop, CP));
+  }
+  RN_CHECK_LAUNCH("augment_batch");
   return 0;
 }
 
