@@ -1,5 +1,6 @@
 """Micro-benchmark of the convolution launchers on the WRN-28-10 shapes (A/B inside one process).
-usage: python tools/conv_bench.py [fwd|dgrad|wgrad] [iters]   env RN_CONV_VARIANT selects kernel variants."""
+usage: python tools/conv_bench.py [fwd|dgrad|wgrad] [iters]   env RN_CONV_VARIANT selects kernel variants (run interleaved,
+RN_CONV_ROUNDS rounds, median reported: single runs of one kernel differ by up to 10 % on one box), RN_CONV_DTYPE fp16|bf16."""
 import ctypes as C
 import os
 import sys
@@ -33,32 +34,45 @@ def run(which, iters, variants, dtype=torch.bfloat16):
         dw = torch.empty(K, ks * ks, Cc, device='cuda')
         wsb = int(L.rn_conv_wgrad_ws_bytes(C.byref(g)))
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device='cuda')
-        rn = 1 if dtype == torch.bfloat16 else 0
+        rn = {torch.bfloat16: 1, torch.float16: 2, torch.float32: 0}[dtype]
         flops = 2.0 * N * H * W * K * ks * ks * Cc
-        for v in variants:
-            L.rn_set_variant(v)
+        ref = {}
+        rounds = int(os.environ.get('RN_CONV_ROUNDS', '5'))
+        times = {v: [] for v in variants}
+        errs = {}
+        for rd in range(rounds):                          # variants interleaved: box drift and clock state hit all of them alike
+            for v in variants:
+                L.rn_set_variant(v)
 
-            def call():
-                if which == 'fwd':
-                    _lib.check(L.rn_conv_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, 0, 0, rn, C.byref(g), None, st))
-                elif which == 'dgrad':
-                    _lib.check(L.rn_conv_dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, 0, 0, 0, rn, C.byref(g), None, st))
-                else:
-                    _lib.check(L.rn_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsb, 0, rn, C.byref(g), st))
-            for _ in range(3):
-                call()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            for _ in range(iters):
-                call()
-            e1.record()
-            torch.cuda.synchronize()
-            us = e0.elapsed_time(e1) / iters * 1e3
-            print(f'{which} {N}x{H}x{W} C{Cc}->K{K} k{ks} variant {v}: {us:8.1f} us  {flops / us / 1e6:7.1f} TFLOP/s', flush=True)
+                def call():
+                    if which == 'fwd':
+                        _lib.check(L.rn_conv_fwd(x.data_ptr(), w.data_ptr(), y.data_ptr(), None, 0, 0, rn, C.byref(g), None, st))
+                    elif which == 'dgrad':
+                        _lib.check(L.rn_conv_dgrad(dy.data_ptr(), wd.data_ptr(), dx.data_ptr(), None, 0, 0, 0, rn, C.byref(g), None, st))
+                    else:
+                        _lib.check(L.rn_conv_wgrad(x.data_ptr(), dy.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsb, 0, rn, C.byref(g), st))
+                for _ in range(3):
+                    call()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(iters):
+                    call()
+                e1.record()
+                torch.cuda.synchronize()
+                times[v].append(e0.elapsed_time(e1) / iters * 1e3)
+                if rd == 0:
+                    out = (y if which == 'fwd' else dx if which == 'dgrad' else dw).float().clone()
+                    if not ref:
+                        ref['o'] = out
+                    errs[v] = float((out - ref['o']).abs().max()) / (float(ref['o'].abs().max()) + 1e-30)
+        for v in variants:
+            t = sorted(times[v])
+            us = t[len(t) // 2]
+            print(f'{which} {N}x{H}x{W} C{Cc}->K{K} k{ks} variant {v}: median {us:7.1f} us (min {t[0]:.1f} max {t[-1]:.1f})  {flops / us / 1e6:7.1f} TFLOP/s  vs first variant: {errs[v]:.2e}', flush=True)
 
 
 if __name__ == '__main__':
     which = sys.argv[1] if len(sys.argv) > 1 else 'fwd'
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     variants = [int(v) for v in os.environ.get('RN_CONV_VARIANT', '0,1').split(',')]
-    run(which, iters, variants)
+    run(which, iters, variants, dtype={'bf16': torch.bfloat16, 'fp16': torch.float16}[os.environ.get('RN_CONV_DTYPE', 'fp16')])
