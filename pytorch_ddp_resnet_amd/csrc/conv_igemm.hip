@@ -98,6 +98,20 @@ template <> struct Mfma<bf16_t> {
     c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
   }
 };
+// v_mfma_f32_16x16x32: A = 16 rows x 32 k (lane l: row l & 15, k 8 (l >> 4) .. + 7), B likewise by column, D = 4 registers (row 4 (l >> 4) + r,
+// column l & 15).  Same FLOPs per pipe cycle as 32x32x16, but the chip holds a higher clock on it under load (measured here as a timing
+// probe on the WRN-28-10 shapes: +8 % per launch; MI355X_MICROARCH.md, DVFS give-back (7)).
+template <typename T> struct Mfma16;
+template <> struct Mfma16<bf16_t> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma16<f16_t> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&a), *reinterpret_cast<const f16x8*>(&b), c, 0, 0, 0);
+  }
+};
 template <> struct Mfma<f16_t> {     // same cycles as the bf16 form (MI355X_MICROARCH.md, matrix cores)
   __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
     c = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&a), *reinterpret_cast<const f16x8*>(&b), c, 0, 0, 0);
@@ -149,16 +163,18 @@ __device__ inline void lds_barrier() {
 }
 
 // SR: staged rows per pass (64 or 32, whatever fits the K-loop's LDS next to the reduction scratch)
-template <typename T, int BM, int BN, int WM, int WN, int TM, int TN, int NTH = WM * WN * 64, int SR = 64>
-__device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN], int m0, int n0, int wave, int lane, float* lds_f,
-                                      bool active = true) {
+// L16: the accumulators come from v_mfma_f32_16x16x32 tiles -- acc[2 TM][2 TN] of f32x4, element r of lane l = tile row 4 (l >> 4) + r,
+// column l & 15 -- instead of 32x32 tiles (acc[TM][TN] of f32x16: row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31); only the parking
+// of the registers in LDS (phase 1) and the staged-row <-> tile-row map differ
+template <typename T, int BM, int BN, int WM, int WN, int TM, int TN, int NTH = WM * WN * 64, int SR = 64, bool L16 = false, typename AccT>
+__device__ inline void igemm_epilogue(const IgemmArgs& a, AccT& acc, int m0, int n0, int wave, int lane, float* lds_f, bool active = true) {
   if (a.probe_ep >= 2) {                       // keep every accumulator live (no dead-code elimination of the MFMAs)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int i = 0; i < (L16 ? 2 * TM : TM); ++i)
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int j = 0; j < (L16 ? 2 * TN : TN); ++j)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) asm volatile("" ::"v"(acc[i][j][r]));
+        for (int r = 0; r < (L16 ? 4 : 16); ++r) asm volatile("" ::"v"(acc[i][j][r]));
     if (a.probe_ep == 2) return;
   }
   constexpr int CE = Elem<T>::CE;
@@ -201,6 +217,7 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
   }
   auto tile_row = [&](int srow, int pass) {    // staged row -> row of the tile
     const int blk = srow / RPB, rem = srow - blk * RPB;
+    if constexpr (L16) return blk * 32 + pass * RPB + rem;      // a pass takes RPB consecutive rows of every 32-row block
     const int hh = rem / NR, r = NR * pass + (rem - hh * NR);
     return blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
   };
@@ -210,6 +227,25 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
   for (int pass = 0; pass < NPASS; ++pass) {
     // ---- phase 1: every wave parks NR accumulator registers of each of its MFMA blocks (fp32) ----
     if (active && a.probe_ep != 3) {
+      if constexpr (L16) {
+        static_assert(!L16 || RPB == 16 || RPB == 8, "16x16 accumulator tiles: 16 or 8 rows of a block per pass");
+        const int l16 = lane & 15, lq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int blk = wm * TM + i;
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {               // the two 16-row tiles of the 32-row block
+            if (RPB == 16 ? it != pass : it != pass / 2) continue;
+            if (RPB == 8 && (lq >> 1) != (pass & 1)) continue;          // half a tile per pass: lanes whose rows 4 lq + r fall into it
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int srow = blk * RPB + (RPB == 16 ? 4 * lq + r : 4 * (lq & 1) + r);
+#pragma unroll
+              for (int j = 0; j < 2 * TN; ++j) ctile[srow * LDC + wn * (BN / WN) + 16 * j + l16] = acc[2 * i + it][j][r];
+            }
+          }
+        }
+      } else {
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         const int blk = wm * TM + i;
@@ -219,6 +255,7 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, f32x16 (&acc)[TM][TN],
 #pragma unroll
           for (int j = 0; j < TN; ++j) ctile[srow * LDC + wn * (BN / WN) + 32 * j + lr] = acc[i][j][NR * pass + jr];
         }
+      }
       }
     }
     lds_barrier();
@@ -1069,7 +1106,8 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PATCH128_PP_MAX = 208;                     // 6x34 (W=32), 10x18 (W=16), 2 x 10x10 (W=8)
 // FULLC: the channel count is a multiple of 64 (every chunk runs its four k-steps: no tail branches in the hot loop)
-template <typename T, int BN, bool FULLC>
+// L16: 16x16x32 MFMA tiles (a wave's 32 x BN block = 2 x BN/16 tiles; one 64-channel step = two 32-channel k-steps)
+template <typename T, int BN, bool FULLC, bool L16 = true>
 __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs a) {
   constexpr int BM = 128, NW = 4, ES = (int)sizeof(T), TN = BN / 32;
   constexpr int CHK = 128 / ES;                          // channels per chunk (one 128-byte LDS row per pixel)
@@ -1142,21 +1180,32 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
     boff[i] = k < a.Kd ? (unsigned)((size_t)k * a.wrs * a.Cs * ES + ch * 16) : OOB;
   }
   const int lr = lane & 31, lh = lane >> 5;
-  int base_pp;
-  {
-    int m = m0 + wave * 32 + lr;
+  const int l16 = lane & 15, lq = lane >> 4;             // L16: row / column of a 16x16 tile, 8-channel group of the 32-channel k-step
+  auto patch_pixel = [&](int m) {                        // tile row m -> its pixel in the patch
     if (m >= a.M) m = a.M - 1;
     const int n = m / HW, rem = m - n * HW;
     const int h = rem / W, w = rem - h * W;
-    base_pp = ((n - n_first) * (multi ? slab_rows : 0) + (h - h_first) + 1) * W2 + w + 1;
-  }
-  const int bsw = (lr >> 1) & 7;
+    return ((n - n_first) * (multi ? slab_rows : 0) + (h - h_first) + 1) * W2 + w + 1;
+  };
+  int base_pp = patch_pixel(m0 + wave * 32 + (L16 ? l16 : lr));
+  int base_pp1 = L16 ? patch_pixel(m0 + wave * 32 + 16 + l16) : 0;
+  const int bsw = L16 ? (l16 >> 1) & 7 : (lr >> 1) & 7;
 
-  f32x16 acc[TN];
+  f32x16 acc[L16 ? 1 : TN];
+  f32x4 acc16[L16 ? 2 : 1][L16 ? 2 * TN : 1];
+  if constexpr (L16) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j)
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+      for (int j = 0; j < 2 * TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
+  } else {
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  }
 
   auto load_patch = [&](int chunk) {                     // the whole patch of `chunk` (AI instructions per wave)
 #pragma unroll
@@ -1211,6 +1260,10 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
     const int kcount = FULLC ? 4 : min(4, (a.cpt - chunk * 8 + 1) >> 1);    // 16-channel k-steps of this chunk that hold data
     const bool full = FULLC || kcount == 4;
     const uint4* Ab = &smem[0];
+    if constexpr (L16) {                                 // the per-tap fragment addresses repeat in every chunk: left alone, hipcc computes all 36 once and spills
+      asm volatile("" : "+v"(base_pp));
+      asm volatile("" : "+v"(base_pp1));
+    }
     {
 #pragma unroll
       for (int t = 0; t < 9; ++t, ++step) {
@@ -1222,6 +1275,41 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
         }
         const int pp = base_pp + poff_t[t];
         const int pa = pp * 8, sa = (pp >> 1) & 7;
+        if constexpr (L16) {
+          // two 32-channel k-steps of 2 x 2TN MFMAs; the weight fragments live in ONE buffer: fragment j of the second k-step is read
+          // into the registers the first k-step's MFMAs on column j have just consumed
+          const int pp1 = base_pp1 + poff_t[t];
+          const int pa1 = pp1 * 8, sa1 = (pp1 >> 1) & 7;
+          const bool two = full || 2 < kcount;           // the chunk's second 32 channels hold data
+          uint4 ga0[2], ga1[2], gb[2 * TN];
+          ga0[0] = Ab[pa + (lq ^ sa)];
+          ga0[1] = Ab[pa1 + (lq ^ sa1)];
+#pragma unroll
+          for (int j = 0; j < 2 * TN; ++j) gb[j] = Bb[(l16 + 16 * j) * 8 + (lq ^ bsw)];
+          if (two) {
+            ga1[0] = Ab[pa + ((4 + lq) ^ sa)];
+            ga1[1] = Ab[pa1 + ((4 + lq) ^ sa1)];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int j = 0; j < 2 * TN; ++j) {
+            Mfma16<T>::run(ga0[0], gb[j], acc16[0][j]);
+            Mfma16<T>::run(ga0[1], gb[j], acc16[1][j]);
+            if (two) gb[j] = Bb[(l16 + 16 * j) * 8 + ((4 + lq) ^ bsw)];
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          if (two) {
+#pragma unroll
+            for (int j = 0; j < 2 * TN; ++j) {
+              Mfma16<T>::run(ga1[0], gb[j], acc16[0][j]);
+              Mfma16<T>::run(ga1[1], gb[j], acc16[1][j]);
+            }
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          wait_vmcnt<0>();
+          __builtin_amdgcn_s_barrier();
+          continue;
+        }
         RN_LOAD_FRAGS(fa0, fb0, Ab, Bb, pa, sa, 0)
         if (full || 1 < kcount) RN_LOAD_FRAGS(fa1, fb1, Ab, Bb, pa, sa, 1)
         __builtin_amdgcn_sched_barrier(0);
@@ -1251,7 +1339,8 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
   }
 #undef RN_LOAD_FRAGS
 #undef RN_MFMA_GROUP
-  igemm_epilogue<T, BM, BN, NW, 1, 1, TN, 256, 64>(a, reinterpret_cast<f32x16(&)[1][TN]>(acc), m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
+  if constexpr (L16) igemm_epilogue<T, BM, BN, NW, 1, 1, TN, 256, 64, true>(a, acc16, m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
+  else igemm_epilogue<T, BM, BN, NW, 1, 1, TN, 256, 64>(a, reinterpret_cast<f32x16(&)[1][TN]>(acc), m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
 }
 
 // geometry the LDS-patch kernel covers: 3x3 taps of a same-size stride-1 convolution (forward or data gradient), tiles of whole
@@ -1278,6 +1367,12 @@ template <typename T, int BN> int launch_patch128(const IgemmArgs& a, hipStream_
   rn_note_kernel("igemm_patch<128x%d>", BN);
   if (rn_dry_run()) return 0;
   const dim3 grid(cdiv(a.M, 128) * cdiv(a.Kd, BN));
+  if (g_rn_variant & (1 << 28)) {                        // A/B: the 32x32x16 MFMA shape
+    if (a.Cs % 64 == 0) hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, true, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, false, false>), grid, dim3(256), 0, s, a);
+    RN_CHECK_LAUNCH("igemm_patch128_mfma32");
+    return 0;
+  }
   if (a.Cs % 64 == 0) hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, true>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, false>), grid, dim3(256), 0, s, a);
   RN_CHECK_LAUNCH("igemm_patch128");
