@@ -7,8 +7,9 @@ merged over ``{mode, data_dir, checkpoint_dir, log_dir}``, :32-46), one process 
 changes: on an MI355X node the backend is RCCL over xGMI whatever the YAML says (``nccl`` IS RCCL under PyTorch-ROCm;
 ``gloo`` is kept for CPU-only plumbing runs, which cannot execute the HIP path), each rank binds to its own GPU, and
 DistributedDataParallel (:64-71) is replaced by ``ddp.GradReducer`` (bucketed all-reduce overlapped with the engine's
-backward) + a rank-0 parameter broadcast.  Dataset loading (torchvision, transforms) is outside the accelerated path:
-``--data_dir synthetic`` (or a missing torchvision) feeds the fixed-shape synthetic batches the benchmark uses.
+backward) + a rank-0 parameter broadcast.  ``--data_dir synthetic`` feeds the fixed-shape synthetic batches the benchmark uses; any
+other ``--data_dir`` must hold the extracted CIFAR archive (as torchvision leaves it): the dataset then lives in HBM and the ``data_aug``
+chains run as one launch per batch (``utils/data_util.py``).
 """
 import argparse
 import os
@@ -66,13 +67,23 @@ def setup(rank, config):
         torch.cuda.set_device(rank)
     torch.distributed.init_process_group(backend=backend, world_size=world, rank=rank)
     device = torch.device('cuda', rank) if on_gpu else torch.device('cpu')
+    sampler_train = None
     if config.get('data_dir') != 'synthetic':
-        raise NotImplementedError("dataset loading is outside the accelerated path (SURVEY 2, row 11): run with --data_dir synthetic")
-    hw, classes = _SHAPES[config.get('dataset_cls_name')]
-    local_batch = config.get('batch_size') // (config.get('num_microbatches') * world)          # data_util.py:216 (batch_size is global)
-    steps = config.get('num_microbatches') * 4
-    dl_train = SyntheticLoader(local_batch, hw, classes, steps, device, 1234 + rank)
-    dl_test = SyntheticLoader(local_batch, hw, classes, 2, device, 4321 + rank)
+        # the dataset archive under data_dir, resident on the device; sampler = the reference's DistributedSampler(seed=0); the
+        # data_aug chains as one launch per batch (utils/data_util.py, utils/transform_util.py)
+        from pytorch_ddp_resnet_amd.utils import data_util
+        if not on_gpu:
+            raise RuntimeError("the input pipeline runs on the device (rn_augment_batch): no GPU, no CPU fallback")
+        datasets = data_util.get_datasets(device=device, **config)
+        samplers = data_util.get_samplers(rank, **config, **datasets)
+        loaders = data_util.get_dataloaders(rank=rank, **config, **datasets, **samplers)
+        dl_train, dl_test, sampler_train = loaders['dl_train'], loaders['dl_test'], samplers['sampler_train']
+    else:
+        hw, classes = _SHAPES[config.get('dataset_cls_name')]
+        local_batch = config.get('batch_size') // (config.get('num_microbatches') * world)          # data_util.py:216 (batch_size is global)
+        steps = config.get('num_microbatches') * 4
+        dl_train = SyntheticLoader(local_batch, hw, classes, steps, device, 1234 + rank)
+        dl_test = SyntheticLoader(local_batch, hw, classes, 2, device, 4321 + rank)
     # the reference turns AMP (fp16 autocast + GradScaler) on whenever a GPU is present (script.py:63, training.py:95-110): the
     # engine's counterpart is fp16 storage / f16 MFMA with fp32 accumulation, statistics and master weights, under the same
     # GradScaler.  `compute_dtype: fp32 | bf16 | fp16` in the YAML overrides it (neither fp32 nor bf16 needs a scaler).
@@ -87,7 +98,7 @@ def setup(rank, config):
     optimizer = get_optimizer(config.get('optimizer_cls_name'), classifier, config.get('optimizer_args'))
     scheduler = get_scheduler(config.get('scheduler_cls_name'), optimizer, config.get('scheduler_args'))
     return dict(device=device, dl_train=dl_train, dl_test=dl_test, classifier=classifier, optimizer=optimizer, scheduler=scheduler,
-                reducer=reducer, global_step=0, scaler=scaler)
+                reducer=reducer, global_step=0, scaler=scaler, sampler_train=sampler_train)
 
 
 def train(rank, config):
