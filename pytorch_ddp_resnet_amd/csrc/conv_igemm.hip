@@ -59,7 +59,6 @@ struct IgemmArgs {
   unsigned probe_mask;     // timing probe (rn_set_variant bit6): AND-mask on DMA source offsets, 0xFFFFFFFF in production
   unsigned long long* stamps;   // diagnostic: per-workgroup s_memtime stamps [grid][16] (rn_set_stamp_buffer), NULL in production
   int probe_ep;            // timing probes: 1 = skip the global stores of the epilogue, 2 = skip the epilogue
-  int patch_mode;          // igemm_patch_kernel schedule switches (A/B through rn_set_variant): bit 0 = waves 4..7 issue their DMAs BEFORE the MFMA group
   int probe_k;             // K-loop timing probes (igemm_dma_kernel): 1 = DMA only (no fragment reads / MFMA), 2 = no DMA, 3 = every DMA out of range
   int xcd_remap;           // 1: blockIdx -> tile through the bijective XCD remap, column tiles fastest
   int dense_src;           // 1: one tap at offset (0,0), unit stride, source grid == compute grid (1x1 convolutions): row m reads pixel m
@@ -75,7 +74,7 @@ __device__ inline void preload_args(const IgemmArgs& a) {
   RN_TOUCH(a.nt); RN_TOUCH(a.wrs); RN_TOUCH(a.cpt); RN_TOUCH(a.nk); RN_TOUCH(a.nth); RN_TOUCH(a.ntw);
   RN_TOUCH(a.magic_pq); RN_TOUCH(a.magic_q); RN_TOUCH(a.accum); RN_TOUCH(a.tile_base);
   RN_TOUCH(a.stats); RN_TOUCH(a.bn_x); RN_TOUCH(a.bn_mask); RN_TOUCH(a.bn_coef); RN_TOUCH(a.bias); RN_TOUCH(a.gscale);
-  RN_TOUCH(a.probe_mask); RN_TOUCH(a.stamps); RN_TOUCH(a.probe_ep); RN_TOUCH(a.xcd_remap); RN_TOUCH(a.dense_src); RN_TOUCH(a.probe_k); RN_TOUCH(a.patch_mode);
+  RN_TOUCH(a.probe_mask); RN_TOUCH(a.stamps); RN_TOUCH(a.probe_ep); RN_TOUCH(a.xcd_remap); RN_TOUCH(a.dense_src); RN_TOUCH(a.probe_k);
 #undef RN_TOUCH
 }
 
@@ -859,215 +858,6 @@ __global__ __launch_bounds__(512, BM >= 256 ? 1 : 2) void igemm_ws_kernel(const 
   igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 512>(a, acc, m0, n0, loader ? 0 : wave, lane, reinterpret_cast<float*>(&smem[0]), !loader);
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// LDS-resident input patch for 3x3 stride-1 convolutions (forward and the stride-1 data gradient), 16-bit element types.
-//
-// Why: the implicit-GEMM kernels above are bound by the rate at which a CU can issue LDS-DMA instructions, not by the matrix
-// pipe (round-2 timing probes, WRN-28-10 stage 1: K loop with the DMAs alone 72 us, with the MFMAs alone 54 us, both 84 us;
-// a DMA whose 64 lanes are all out of range costs the same, so it is instruction issue, ~40 cycles per 1 KiB instruction and
-// CU, not memory).  An im2col tile loads every input pixel once per tap: (BM + BN) * 128 B per 64-deep K step.  Here the
-// input pixels a 256-pixel output tile needs (its rows plus a one-pixel halo, explicit zero pad columns) are loaded ONCE per
-// 64-channel chunk into LDS and read by all nine taps through a per-tap pixel offset; only the 20 KiB weight tile of the
-// (tap, chunk) step is streamed.  DMA instructions per FLOP: 13.7 -> 4.7 per MFLOP at 160 output channels.
-//
-// Tile: BM = 256 consecutive output pixels = whole image rows (H*W >= 256) or whole images (H*W < 256), BN output channels;
-// 8 waves, wave w owns tile rows 32w..32w+31 (one 32x32 MFMA row block, BN/32 column blocks): the igemm_epilogue above is
-// reused unchanged.  K loop: chunks of 64 channels x 9 taps; per step one weight tile (2-stage ring) and, during taps 0..6, one
-// eighth of the NEXT chunk's patch per wave (double-buffered patch); DMAs are issued between the k-steps' MFMA groups, waits
-// are counted, one raw s_barrier per step.
-// ---------------------------------------------------------------------------------------------------------------------
-constexpr int PATCH_PP_MAX = 344;                        // patch pixels (incl. halo and pad columns): 10x34 (W=32), 18x18 (W=16)
-template <typename T, int BN>
-__global__ __launch_bounds__(512, 2) void igemm_patch_kernel(const IgemmArgs a) {
-  constexpr int BM = 256, NW = 8, ES = (int)sizeof(T), TN = BN / 32;
-  constexpr int CHK = 128 / ES;                          // channels per chunk (one 128-byte LDS row per pixel)
-  constexpr int ASZ = PATCH_PP_MAX * 8;                  // uint4 per patch buffer
-  constexpr int BIT = BN / 8;                            // weight-tile DMA instructions (8 rows of 128 bytes each)
-  constexpr int BI = (BIT + NW - 1) / NW;                // per wave (the last one only for wave < BIT - (BI-1)*NW)
-  constexpr int BSZ = BN * 8;
-  constexpr int AI = 6;                                  // patch DMAs per wave and chunk: PATCH_PP_MAX / 8 = 43 <= 6 * 8
-  constexpr int NSB = 3;                                 // weight-tile ring stages: a tile is issued TWO steps before it is multiplied
-  static_assert(ES == 2 && BN % 32 == 0 && PATCH_PP_MAX / 8 <= AI * NW && BI <= 3, "patch tile");
-  __shared__ uint4 smem[2 * ASZ + NSB * BSZ + TAP_INTS / 4];
-  int* taps = reinterpret_cast<int*>(&smem[2 * ASZ + NSB * BSZ]);
-
-  // (no preload_args here: the K loop keeps ~30 wave-uniform values live; holding every argument in SGPRs as well spills them)
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nmt = (a.M + BM - 1) / BM;
-  int bid = blockIdx.x;
-  if (a.xcd_remap) {
-    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int nnt_ = gridDim.x / nmt;
-  const int ntile = a.xcd_remap ? bid % nnt_ : bid / nmt, mt = a.xcd_remap ? bid / nnt_ : bid % nmt;
-  const int m0 = mt * BM, n0 = ntile * BN;
-  const int H = a.Hs, W = a.Ws, HW = H * W, W2 = W + 2;
-  // patch geometry (wave-uniform)
-  const bool multi = HW < BM;
-  const int n_first = m0 / HW;
-  const int h_first = multi ? 0 : (m0 - n_first * HW) / W;
-  const int slab_rows = multi ? H + 2 : BM / W + 2;
-  const int nimg = multi ? BM / HW : 1;
-  const int PP = nimg * slab_rows * W2;
-  const int nA = (PP + 7) >> 3;
-  const int nchunk = (a.Cs + CHK - 1) / CHK;
-  const int nstep = nchunk * 9;
-
-  const size_t img_bytes = (size_t)HW * a.Cs * ES;
-  const v4i32 ra_desc = make_desc(reinterpret_cast<const char*>(a.src) + (size_t)n_first * img_bytes, (size_t)(a.N - n_first) * img_bytes);
-  const v4i32 rb_desc = make_desc(a.wt, (size_t)a.Kd * a.wrs * a.Cs * ES);
-  const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);
-
-  fill_tap_tables<ES>(a, taps);
-  __syncthreads();
-
-  // ---- per-lane DMA roles ----
-  const int l8 = lane >> 3, sl = lane & 7;
-  unsigned aoff[AI];                                     // source byte offset of this lane's 16 bytes at chunk 0 (OOB: zero fill)
-  int ach[AI];                                           // its logical 16-byte column inside the chunk (channel-tail check)
-#pragma unroll
-  for (int t = 0; t < AI; ++t) {
-    const int idx = t * NW + wave;
-    const int pp = idx * 8 + l8;
-    const int ch = sl ^ ((pp >> 1) & 7);
-    ach[t] = ch;
-    aoff[t] = OOB;
-    if (idx < nA && pp < PP) {
-      const int prow = pp / W2, pcol = pp - prow * W2;
-      const int img = prow / slab_rows, hr = prow - img * slab_rows;
-      const int h = h_first - 1 + hr, n = n_first + img;
-      if (pcol >= 1 && pcol <= W && h >= 0 && h < H && n < a.N)
-        aoff[t] = (unsigned)((((size_t)img * H + h) * W + (pcol - 1)) * a.Cs * ES + ch * 16);
-    }
-  }
-  unsigned boff[BI];
-  int bch[BI];
-#pragma unroll
-  for (int i = 0; i < BI; ++i) {
-    const int j = i * NW + wave;
-    const int rn = j * 8 + l8;
-    const int ch = sl ^ ((rn >> 1) & 7);
-    bch[i] = ch;
-    const int k = n0 + rn;
-    boff[i] = (j < BIT && k < a.Kd) ? (unsigned)((size_t)k * a.wrs * a.Cs * ES + ch * 16) : OOB;
-  }
-  // ---- per-lane fragment roles ----
-  const int lr = lane & 31, lh = lane >> 5;
-  int base_pp;
-  {
-    int m = m0 + wave * 32 + lr;
-    if (m >= a.M) m = a.M - 1;                           // rows past the end read some valid pixel; the epilogue drops them
-    const int n = m / HW, rem = m - n * HW;
-    const int h = rem / W, w = rem - h * W;
-    base_pp = ((n - n_first) * (multi ? slab_rows : 0) + (h - h_first) + 1) * W2 + w + 1;
-  }
-  const int bsw = (lr >> 1) & 7;                         // weight-tile swizzle of rows lr + 32 j (32 j does not change (row >> 1) & 7)
-
-  f32x16 acc[TN];
-#pragma unroll
-  for (int j = 0; j < TN; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-  auto dma_a = [&](int t, int chunk, int buf) {          // this wave's t-th patch DMA of `chunk` into patch buffer `buf`
-    const int idx = t * NW + wave;
-    if (idx >= nA) return false;                         // wave-uniform
-    const bool ok = aoff[t] != OOB && chunk * 8 + ach[t] < a.cpt;
-    dma16(ra_desc, ok ? aoff[t] + (unsigned)(chunk * 128) : OOB, lds0 + (unsigned)((buf * ASZ) * 16 + idx * 1024));
-    return true;
-  };
-  auto dma_b = [&](int i, int chunk, int woff, int stg) {     // this wave's i-th weight DMA of step (chunk, tap) into ring stage `stg`
-    const int j = i * NW + wave;
-    if (j >= BIT) return false;                          // wave-uniform
-    const bool ok = boff[i] != OOB && chunk * 8 + bch[i] < a.cpt;
-    dma16(rb_desc, ok ? boff[i] + (unsigned)(woff + chunk * 128) : OOB, lds0 + (unsigned)((2 * ASZ + stg * BSZ) * 16 + j * 1024));
-    return true;
-  };
-  auto tap_woff = [&](int t) { return __builtin_amdgcn_readfirstlane(taps[64 + t]); };
-  auto tap_poff = [&](int t) {                           // pixel offset of tap t inside the patch: dh * (W + 2) + dw
-    const int v = __builtin_amdgcn_readfirstlane(taps[128 + t]);
-    return (v >> 16) * W2 + (int)(short)(v & 0xFFFF);
-  };
-
-  // ---- prologue: the whole patch of chunk 0 and the weight tile of step 0 ----
-  {
-    const unsigned keep = m0_save();
-#pragma unroll
-    for (int t = 0; t < AI; ++t) dma_a(t, 0, 0);
-    const int w0 = tap_woff(0), w1 = tap_woff(1);
-#pragma unroll
-    for (int i = 0; i < BI; ++i) dma_b(i, 0, w0, 0);
-#pragma unroll
-    for (int i = 0; i < BI; ++i) dma_b(i, 0, w1, 1);
-    m0_restore(keep);
-  }
-  wait_vmcnt<0>();
-  __builtin_amdgcn_s_barrier();
-
-  int step = 0, sb = 0;                                   // sb = step % NSB
-  for (int chunk = 0; chunk < nchunk; ++chunk) {
-    const uint4* Ab = &smem[(chunk & 1) * ASZ];
-    const int kcount = min(4, (a.cpt - chunk * 8 + 1) >> 1);    // 16-channel k-steps of this chunk that hold data
-    const bool more_chunks = chunk + 1 < nchunk;
-#pragma unroll
-    for (int t = 0; t < 9; ++t, ++step) {
-      const uint4* Bb = &smem[2 * ASZ + sb * BSZ];
-      const bool more = step + 2 < nstep;                  // the weight tile issued in this step is the one of step + 2
-      const int nchunk_b = t >= 7 ? chunk + 1 : chunk, ntap_b = t >= 7 ? t - 7 : t + 2;
-      const int wnext = tap_woff(ntap_b);
-      const int sb2 = sb == 0 ? 2 : sb - 1;                // (step + 2) % 3
-      int issued = 0;                                      // DMAs this wave issues in this step (wave-uniform)
-      const int pp = base_pp + tap_poff(t);
-      const int pa = pp * 8, sa = (pp >> 1) & 7;
-      uint4 fa[2], fb[2][TN];
-      fa[0] = Ab[pa + (lh ^ sa)];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[0][j] = Bb[(lr + 32 * j) * 8 + (lh ^ bsw)];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int cur = ks & 1, nxt = cur ^ 1;
-        if (ks + 1 < 4 && ks + 1 < kcount) {
-          const int ch = 2 * (ks + 1) + lh;
-          fa[nxt] = Ab[pa + (ch ^ sa)];
-#pragma unroll
-          for (int j = 0; j < TN; ++j) fb[nxt][j] = Bb[(lr + 32 * j) * 8 + (ch ^ bsw)];
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        // one DMA per k-step.  The two waves of a SIMD (w and w + 4) run the same program in lockstep: if both issued their DMA at the
-        // same point, all eight would queue at the texture addresser while the matrix pipe idles.  Waves 0..3 issue BEHIND the MFMA
-        // group, waves 4..7 IN FRONT of it: one wave of each SIMD feeds the matrix pipe while the other waits for its DMA to issue.
-#define RN_PATCH_ISSUE()                                                                                     \
-  if (a.probe_k != 2) {                                                                                      \
-    const unsigned keep = m0_save();                                                                         \
-    if (ks < BI) { if (more) issued += dma_b(ks, nchunk_b, wnext, sb2) ? 1 : 0; }                             \
-    else if (ks == 3 && t < AI && more_chunks) issued += dma_a(t, chunk + 1, (chunk + 1) & 1) ? 1 : 0;      \
-    m0_restore(keep);                                                                                        \
-  }
-        const bool early = (a.patch_mode & 1) && wave >= 4;
-        if (early) { RN_PATCH_ISSUE() }
-        __builtin_amdgcn_sched_barrier(0);
-        if (ks < kcount && a.probe_k != 1) {
-#pragma unroll
-          for (int j = 0; j < TN; ++j) Mfma<T>::run(fa[cur], fb[cur][j], acc[j]);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        if (!early) { RN_PATCH_ISSUE() }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      // the NEXT step's weight tile (issued one step ago) and, at tap 8, the whole next patch (issued in taps 0..5) must have landed
-      // for every wave: everything older than the DMAs of this step.  Those stay in flight across the barrier (counted wait).
-      if (issued >= 4) wait_vmcnt<4>(); else if (issued == 3) wait_vmcnt<3>(); else if (issued == 2) wait_vmcnt<2>();
-      else if (issued == 1) wait_vmcnt<1>(); else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      sb = sb == 2 ? 0 : sb + 1;
-    }
-  }
-#undef RN_PATCH_ISSUE
-  igemm_epilogue<T, BM, BN, NW, 1, 1, TN, 512, 64>(a, reinterpret_cast<f32x16(&)[1][TN]>(acc), m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
-}
-
 template <typename T, int BM, int BN, int WM, int WN>
 int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   int nmt = cdiv(a.M, BM), nnt = cdiv(a.Kd, BN);
@@ -1077,15 +867,6 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
   // wave-specialised kernel, 512 forbids it (A/B in tools/conv_bench.py).
   const bool one_per_cu = nmt * nnt <= 256;
   const bool ws = (g_rn_variant & 128) || (one_per_cu && !(g_rn_variant & 512));
-  if constexpr (BN >= 128) {
-    if (g_rn_variant & (1 << 19)) {                     // A/B: wave-specialised kernel with a 4-stage ring (three K tiles in flight), any grid
-      rn_note_kernel("igemm_ws4<%dx%d>", BM, BN);
-      if (rn_dry_run()) return 0;
-      hipLaunchKernelGGL((igemm_ws_kernel<T, BM, BN, WM, WN, 8, 4>), dim3(nmt * nnt), dim3(512), 0, s, a);
-      RN_CHECK_LAUNCH("igemm_ws4");
-      return 0;
-    }
-  }
   rn_note_kernel("igemm_%s<%dx%d>", ws ? "ws" : "dma", BM, BN);
   if (rn_dry_run()) return 0;
   if (ws)
@@ -1097,17 +878,29 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// The same idea at the proven occupancy of igemm_dma_kernel: 128-pixel tiles, 4 waves, TWO workgroups per CU (each hides the
-// other's prologue, epilogue, DMA latency and patch reload).  The per-CU load path moves ~25 bytes per clock whatever the
+// LDS-resident input patch for 3x3 stride-1 convolutions (forward and the stride-1 data gradient), 16-bit element types.
+//
+// Why: the implicit-GEMM kernels above are bound by the rate at which a CU can issue LDS-DMA instructions, not by the matrix
+// pipe (round-2 timing probes, WRN-28-10 stage 1: K loop with the DMAs alone 72 us, with the MFMAs alone 54 us, both 84 us;
+// a DMA whose 64 lanes are all out of range costs the same, so it is instruction issue, ~40 cycles per 1 KiB instruction and
+// CU, not memory).  An im2col tile loads every input pixel once per tap: (BM + BN) * 128 B per 64-deep K step.  Here the
+// input pixels an output tile needs (its rows plus a one-pixel halo, explicit zero pad columns) are loaded ONCE per 64-channel
+// chunk into LDS and read by all nine taps through a per-tap pixel offset; only the weight tile of the (tap, chunk) step is
+// streamed.  (A 256-pixel, 8-wave, one-workgroup-per-CU form with a double-buffered patch was built first and measured 0-20 %
+// slower than the 128-pixel form below -- DESIGN.md 6a -- and is gone.)
+//
+// Tile: 128 consecutive output pixels = whole image rows (H*W >= 128) or whole images, at the proven occupancy of igemm_dma_kernel:
+// 4 waves, TWO workgroups per CU (each hides the other's prologue, epilogue, DMA latency and patch reload).  The per-CU load path moves ~25 bytes per clock whatever the
 // instruction mix (an LDS-DMA instruction costs ~5 cycles per 128-byte line it touches, out-of-range lanes included; 64-byte rows
 // use half of every line and were measured slower), so the lever is BYTES per FLOP: the patch of a 64-channel chunk (208 pixels x
 // 128 B = 26 KiB, single buffer: reloaded between chunks while the other workgroup computes) + one 20 KiB weight tile per
-// (chunk, tap) step = 23 KiB per step instead of the im2col kernel's 36 KiB, at the same 20 MFMAs per wave and barrier.
+// (chunk, tap) step = 23 KiB per step instead of the im2col kernel's 36 KiB, at the same MFMA work per wave and barrier.
+// MFMA shape: v_mfma_f32_16x16x32 (a wave's 32 x BN block = 2 x BN/16 tiles; one 64-channel step = two 32-channel k-steps) -- the chip
+// holds a higher clock on it than on 32x32x16 in this loop (-2.5 / -7.5 % per launch, bit-identical results).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PATCH128_PP_MAX = 208;                     // 6x34 (W=32), 10x18 (W=16), 2 x 10x10 (W=8)
-// FULLC: the channel count is a multiple of 64 (every chunk runs its four k-steps: no tail branches in the hot loop)
-// L16: 16x16x32 MFMA tiles (a wave's 32 x BN block = 2 x BN/16 tiles; one 64-channel step = two 32-channel k-steps)
-template <typename T, int BN, bool FULLC, bool L16 = true>
+// FULLC: the channel count is a multiple of 64 (every chunk runs both k-steps: no tail branches in the hot loop)
+template <typename T, int BN, bool FULLC>
 __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs a) {
   constexpr int BM = 128, NW = 4, ES = (int)sizeof(T), TN = BN / 32;
   constexpr int CHK = 128 / ES;                          // channels per chunk (one 128-byte LDS row per pixel)
@@ -1179,33 +972,24 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
     const int k = n0 + rn;
     boff[i] = k < a.Kd ? (unsigned)((size_t)k * a.wrs * a.Cs * ES + ch * 16) : OOB;
   }
-  const int lr = lane & 31, lh = lane >> 5;
-  const int l16 = lane & 15, lq = lane >> 4;             // L16: row / column of a 16x16 tile, 8-channel group of the 32-channel k-step
+  const int l16 = lane & 15, lq = lane >> 4;             // row / column of a 16x16 tile, 8-channel group of the 32-channel k-step
   auto patch_pixel = [&](int m) {                        // tile row m -> its pixel in the patch
     if (m >= a.M) m = a.M - 1;
     const int n = m / HW, rem = m - n * HW;
     const int h = rem / W, w = rem - h * W;
     return ((n - n_first) * (multi ? slab_rows : 0) + (h - h_first) + 1) * W2 + w + 1;
   };
-  int base_pp = patch_pixel(m0 + wave * 32 + (L16 ? l16 : lr));
-  int base_pp1 = L16 ? patch_pixel(m0 + wave * 32 + 16 + l16) : 0;
-  const int bsw = L16 ? (l16 >> 1) & 7 : (lr >> 1) & 7;
+  int base_pp = patch_pixel(m0 + wave * 32 + l16);      // the wave's two 16-row tiles
+  int base_pp1 = patch_pixel(m0 + wave * 32 + 16 + l16);
+  const int bsw = (l16 >> 1) & 7;
 
-  f32x16 acc[L16 ? 1 : TN];
-  f32x4 acc16[L16 ? 2 : 1][L16 ? 2 * TN : 1];
-  if constexpr (L16) {
+  f32x4 acc16[2][2 * TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-      for (int j = 0; j < 2 * TN; ++j)
+    for (int j = 0; j < 2 * TN; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
-  } else {
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-  }
+      for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
 
   auto load_patch = [&](int chunk) {                     // the whole patch of `chunk` (AI instructions per wave)
 #pragma unroll
@@ -1244,26 +1028,16 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
   wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
-  // One step = (chunk, tap): four 16-channel k-steps of 5 MFMAs per wave, fragments of k-step ks + 1 in flight under the MFMAs of ks.
+  // One step = (chunk, tap): two 32-channel k-steps of 2 x 2TN MFMAs per wave.  The weight fragments live in ONE buffer: fragment j of
+  // the second k-step is read into the registers the first k-step's MFMAs on column j have just consumed.
   // (Deferring the last k-step's MFMAs behind the closing barrier, to cover the next step's first fragment reads, was measured +-0.)
-  uint4 fa0, fa1, fb0[TN], fb1[TN];
-#define RN_LOAD_FRAGS(FA, FB, AB, BB, PA, SA, KS)                                   \
-  {                                                                                \
-    const int ch_ = 2 * (KS) + lh;                                                 \
-    FA = (AB)[(PA) + (ch_ ^ (SA))];                                                \
-    _Pragma("unroll") for (int j = 0; j < TN; ++j) FB[j] = (BB)[(lr + 32 * j) * 8 + (ch_ ^ bsw)]; \
-  }
-#define RN_MFMA_GROUP(FA, FB)                                                      \
-  { _Pragma("unroll") for (int j = 0; j < TN; ++j) Mfma<T>::run(FA, FB[j], acc[j]); }
   int step = 0;
   for (int chunk = 0; chunk < nchunk; ++chunk) {
     const int kcount = FULLC ? 4 : min(4, (a.cpt - chunk * 8 + 1) >> 1);    // 16-channel k-steps of this chunk that hold data
     const bool full = FULLC || kcount == 4;
     const uint4* Ab = &smem[0];
-    if constexpr (L16) {                                 // the per-tap fragment addresses repeat in every chunk: left alone, hipcc computes all 36 once and spills
-      asm volatile("" : "+v"(base_pp));
-      asm volatile("" : "+v"(base_pp1));
-    }
+    asm volatile("" : "+v"(base_pp));                    // the per-tap fragment addresses repeat in every chunk: left alone, hipcc computes
+    asm volatile("" : "+v"(base_pp1));                   // all 36 of them once and spills them
     {
 #pragma unroll
       for (int t = 0; t < 9; ++t, ++step) {
@@ -1275,55 +1049,33 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
         }
         const int pp = base_pp + poff_t[t];
         const int pa = pp * 8, sa = (pp >> 1) & 7;
-        if constexpr (L16) {
-          // two 32-channel k-steps of 2 x 2TN MFMAs; the weight fragments live in ONE buffer: fragment j of the second k-step is read
-          // into the registers the first k-step's MFMAs on column j have just consumed
-          const int pp1 = base_pp1 + poff_t[t];
-          const int pa1 = pp1 * 8, sa1 = (pp1 >> 1) & 7;
-          const bool two = full || 2 < kcount;           // the chunk's second 32 channels hold data
-          uint4 ga0[2], ga1[2], gb[2 * TN];
-          ga0[0] = Ab[pa + (lq ^ sa)];
-          ga0[1] = Ab[pa1 + (lq ^ sa1)];
+        const int pp1 = base_pp1 + poff_t[t];
+        const int pa1 = pp1 * 8, sa1 = (pp1 >> 1) & 7;
+        const bool two = full || 2 < kcount;             // the chunk's second 32 channels hold data
+        uint4 ga0[2], ga1[2], gb[2 * TN];
+        ga0[0] = Ab[pa + (lq ^ sa)];
+        ga0[1] = Ab[pa1 + (lq ^ sa1)];
 #pragma unroll
-          for (int j = 0; j < 2 * TN; ++j) gb[j] = Bb[(l16 + 16 * j) * 8 + (lq ^ bsw)];
-          if (two) {
-            ga1[0] = Ab[pa + ((4 + lq) ^ sa)];
-            ga1[1] = Ab[pa1 + ((4 + lq) ^ sa1)];
-          }
+        for (int j = 0; j < 2 * TN; ++j) gb[j] = Bb[(l16 + 16 * j) * 8 + (lq ^ bsw)];
+        if (two) {
+          ga1[0] = Ab[pa + ((4 + lq) ^ sa)];
+          ga1[1] = Ab[pa1 + ((4 + lq) ^ sa1)];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = 0; j < 2 * TN; ++j) {
+          Mfma16<T>::run(ga0[0], gb[j], acc16[0][j]);
+          Mfma16<T>::run(ga0[1], gb[j], acc16[1][j]);
+          if (two) gb[j] = Bb[(l16 + 16 * j) * 8 + ((4 + lq) ^ bsw)];
           __builtin_amdgcn_sched_barrier(0);
+        }
+        if (two) {
 #pragma unroll
           for (int j = 0; j < 2 * TN; ++j) {
-            Mfma16<T>::run(ga0[0], gb[j], acc16[0][j]);
-            Mfma16<T>::run(ga0[1], gb[j], acc16[1][j]);
-            if (two) gb[j] = Bb[(l16 + 16 * j) * 8 + ((4 + lq) ^ bsw)];
-            __builtin_amdgcn_sched_barrier(0);
+            Mfma16<T>::run(ga1[0], gb[j], acc16[0][j]);
+            Mfma16<T>::run(ga1[1], gb[j], acc16[1][j]);
           }
-          if (two) {
-#pragma unroll
-            for (int j = 0; j < 2 * TN; ++j) {
-              Mfma16<T>::run(ga1[0], gb[j], acc16[0][j]);
-              Mfma16<T>::run(ga1[1], gb[j], acc16[1][j]);
-            }
-          }
-          __builtin_amdgcn_sched_barrier(0);
-          wait_vmcnt<0>();
-          __builtin_amdgcn_s_barrier();
-          continue;
         }
-        RN_LOAD_FRAGS(fa0, fb0, Ab, Bb, pa, sa, 0)
-        if (full || 1 < kcount) RN_LOAD_FRAGS(fa1, fb1, Ab, Bb, pa, sa, 1)
-        __builtin_amdgcn_sched_barrier(0);
-        RN_MFMA_GROUP(fa0, fb0)
-        __builtin_amdgcn_sched_barrier(0);
-        if (full || 2 < kcount) RN_LOAD_FRAGS(fa0, fb0, Ab, Bb, pa, sa, 2)
-        __builtin_amdgcn_sched_barrier(0);
-        if (full || 1 < kcount) RN_MFMA_GROUP(fa1, fb1)
-        __builtin_amdgcn_sched_barrier(0);
-        if (full || 3 < kcount) RN_LOAD_FRAGS(fa1, fb1, Ab, Bb, pa, sa, 3)
-        __builtin_amdgcn_sched_barrier(0);
-        if (full || 2 < kcount) RN_MFMA_GROUP(fa0, fb0)
-        __builtin_amdgcn_sched_barrier(0);
-        if (full || 3 < kcount) RN_MFMA_GROUP(fa1, fb1)
         __builtin_amdgcn_sched_barrier(0);
         wait_vmcnt<0>();                                 // next step's weight tile landed (own DMAs), then everybody's
         __builtin_amdgcn_s_barrier();
@@ -1337,10 +1089,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
       __builtin_amdgcn_s_barrier();
     }
   }
-#undef RN_LOAD_FRAGS
-#undef RN_MFMA_GROUP
-  if constexpr (L16) igemm_epilogue<T, BM, BN, NW, 1, 1, TN, 256, 64, true>(a, acc16, m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
-  else igemm_epilogue<T, BM, BN, NW, 1, 1, TN, 256, 64>(a, reinterpret_cast<f32x16(&)[1][TN]>(acc), m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
+  igemm_epilogue<T, BM, BN, NW, 1, 1, TN, 256, 64, true>(a, acc16, m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
 }
 
 // geometry the LDS-patch kernel covers: 3x3 taps of a same-size stride-1 convolution (forward or data gradient), tiles of whole
@@ -1359,7 +1108,7 @@ static bool patch_ok(const IgemmArgs& a, int BN, int BM) {
     if (BM % HW) return false;
     pp = (BM / HW) * (a.Hs + 2) * (a.Ws + 2);
   }
-  if (pp > (BM == 256 ? PATCH_PP_MAX : PATCH128_PP_MAX)) return false;
+  if (pp > PATCH128_PP_MAX) return false;
   return (g_rn_variant & 16) || (long)cdiv(a.M, BM) * cdiv(a.Kd, BN) >= 192;     // 16: any grid (tests of small geometries)
 }
 
@@ -1367,23 +1116,9 @@ template <typename T, int BN> int launch_patch128(const IgemmArgs& a, hipStream_
   rn_note_kernel("igemm_patch<128x%d>", BN);
   if (rn_dry_run()) return 0;
   const dim3 grid(cdiv(a.M, 128) * cdiv(a.Kd, BN));
-  if (g_rn_variant & (1 << 28)) {                        // A/B: the 32x32x16 MFMA shape
-    if (a.Cs % 64 == 0) hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, true, false>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, false, false>), grid, dim3(256), 0, s, a);
-    RN_CHECK_LAUNCH("igemm_patch128_mfma32");
-    return 0;
-  }
   if (a.Cs % 64 == 0) hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, true>), grid, dim3(256), 0, s, a);
   else hipLaunchKernelGGL((igemm_patch128_kernel<T, BN, false>), grid, dim3(256), 0, s, a);
   RN_CHECK_LAUNCH("igemm_patch128");
-  return 0;
-}
-
-template <typename T, int BN> int launch_patch(const IgemmArgs& a, hipStream_t s) {
-  rn_note_kernel("igemm_patch<256x%d>", BN);
-  if (rn_dry_run()) return 0;
-  hipLaunchKernelGGL((igemm_patch_kernel<T, BN>), dim3(cdiv(a.M, 256) * cdiv(a.Kd, BN)), dim3(512), 0, s, a);
-  RN_CHECK_LAUNCH("igemm_patch");
   return 0;
 }
 
@@ -1394,13 +1129,8 @@ template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   // step) is the default wherever the grid keeps two workgroups on every CU (>= 512 tiles): measured in one process against the im2col
   // kernel on the WRN-28-10 shapes, forward / dgrad: stage 1 (1,024 tiles) 84.5 / 84.1 vs 88.2 / 89.0 us, stage 2 (512 tiles) 65.7 / 67.3
   // vs 71.5 / 74.6 us; on a 256-tile grid the wave-specialised im2col kernel wins (79 vs 69 us).  rn_set_variant: 2 = never,
-  // 1 << 21 = wherever the geometry allows (with 16: any grid), 1 << 18 = the 256-pixel one-workgroup-per-CU variant (experimental:
-  // 2.9x fewer DMA bytes per FLOP, but its single workgroup exposes prologue, epilogue and per-step latencies: 0-20 % slower).
+  // 1 << 21 = wherever the geometry allows (with 16: any grid).
   if constexpr (sizeof(T) == 2) {
-    if (g_rn_variant & (1 << 18)) {
-      if (K % 160 == 0 && patch_ok(a, 160, 256)) return launch_patch<T, 160>(a, s);
-      if (K % 160 != 0 && K % 128 == 0 && patch_ok(a, 128, 256)) return launch_patch<T, 128>(a, s);
-    }
     const int bn = K % 160 == 0 ? 160 : (K % 128 == 0 ? 128 : 0);
     if (bn && patch_ok(a, bn, 128) && ((g_rn_variant & (1 << 21)) || (long)cdiv(a.M, 128) * cdiv(K, bn) >= 512))
       return bn == 160 ? launch_patch128<T, 160>(a, s) : launch_patch128<T, 128>(a, s);
@@ -1470,7 +1200,6 @@ static void fill_ep(IgemmArgs& a, const rn_conv_epilogue* ep, int tile_base) {
   a.probe_mask = (g_rn_variant & 64) ? 0x0000FFF0u : 0xFFFFFFFFu;
   a.stamps = reinterpret_cast<unsigned long long*>(g_rn_stamps);
   a.xcd_remap = (g_rn_variant & 8) ? 0 : 1;
-  a.patch_mode = ((g_rn_variant & (1 << 17)) ? 0 : 1) | ((g_rn_variant & (1 << 20)) ? 2 : 0);      // 1 << 17: lockstep DMA placement, 1 << 20: spread DMAs (A/B)
   a.probe_k = (g_rn_variant & 1024) ? 1 : ((g_rn_variant & 2048) ? 2 : ((g_rn_variant & 4096) ? 3 : 0));
   a.probe_ep = (g_rn_variant & 8192) ? 1 : ((g_rn_variant & 16384) ? 2 : ((g_rn_variant & 32768) ? 3 : ((g_rn_variant & 65536) ? 4 : 0)));
 }

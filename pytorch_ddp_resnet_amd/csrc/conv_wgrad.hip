@@ -283,193 +283,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     }
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Three taps per workgroup (3x3, stride 1, pad 1; 16-bit types).  wgrad_kernel gives every tap its own workgroup, so dy and x are
-// loaded once per tap: 40 KB per 3.3 MFLOP, and the kernel is bound by the per-CU load path (~25 B/clk), not by the matrix pipe
-// (MFMA busy 30 %).  Here a workgroup owns one ROW of taps (dh fixed, dw = -1, 0, +1) of a (K tile x 64-channel) block: the dy tile
-// is loaded once for the three taps and the x tile is ONE run of 66 consecutive pixels (the three taps read it shifted by 0/1/2
-// rows) -- 28 KB per 3.9 MFLOP.  Padding is not materialised: a tap whose source pixel is outside the image reads a ZERO ROW of
-// LDS instead (the transposed read takes a per-row address), and so does a pixel beyond the workgroup's range.
-// ---------------------------------------------------------------------------------------------------------------------
-template <typename T, int TI>
-__global__ __launch_bounds__(256, 2) void wgrad3_kernel(const WgradArgs a) {   // two workgroups per CU: <= 256 registers
-  constexpr int TJ = 2;                                  // 2 x 2 waves: BK = 32 TI output channels x BC = 64 input channels per workgroup
-  constexpr int CE = 8, ES = 2;
-  constexpr int BK_ = 2 * TI * 16, BC_ = 2 * TJ * 16;
-  constexpr int ROWA = padded_row(BK_ * ES), ROWB = padded_row(BC_ * ES);
-  constexpr int CHA = BK_ / CE, CHB = BC_ / CE;
-  constexpr int BP = 64, XR = BP + 2;                    // pixels per tile; rows of the x tile (one halo pixel each side)
-  constexpr int TPR = 256 / BP;
-  constexpr int NJA = (CHA + TPR - 1) / TPR, NJB = (CHB + TPR - 1) / TPR;
-  constexpr int ZROW = ROWA > ROWB ? ROWA : ROWB;
-  constexpr int BUF = BP * ROWA + XR * ROWB;
-  __shared__ __attribute__((aligned(16))) char lds[2 * BUF + ZROW];
-  typedef typename H16<T>::v8 v8;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < ZROW / 4; i += 256) reinterpret_cast<int*>(lds + 2 * BUF)[i] = 0;       // the zero row
-  int b = blockIdx.x;
-  if (a.xcd_remap) {
-    const int nwg = gridDim.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
-    b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
-  const int dhi = b % 3; b /= 3;                         // tap row 0..2 (dh = dhi - 1): fastest, the three rows re-read the same dy
-  const int ctile = b % a.ct; b /= a.ct;
-  const int ktile = b % a.kt;
-  const int split = b / a.kt;
-  const int dh = dhi - 1;
-  const int k0 = ktile * BK_, c0 = ctile * BC_;
-  const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
-  const T* __restrict__ DY = reinterpret_cast<const T*>(a.dy);
-  const int m_begin = split * a.rows_per_split;
-  const int m_end = min(a.M, m_begin + a.rows_per_split);
-  const int niter = m_end > m_begin ? (m_end - m_begin + BP - 1) / BP : 0;
-  const int pq = a.P * a.Q, W = a.Q, H = a.P;
-
-  // buffer descriptors rebased on this block's first image (32-bit offsets; out of range -> zeros in hardware)
-  const int n_first = max(0, m_begin / pq - 1);          // the x run starts up to W + 1 pixels before m_begin
-  const size_t ximg = (size_t)pq * a.C * ES, yimg = (size_t)pq * a.K * ES;
-  const size_t xleft = ((size_t)a.N - n_first) * ximg, yleft = ((size_t)a.N - n_first) * yimg;
-  const __amdgpu_buffer_rsrc_t xdesc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(X)) + (size_t)n_first * ximg, (short)0,
-                                                                        (int)(xleft > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (unsigned)xleft), 0x00020000);
-  const __amdgpu_buffer_rsrc_t ydesc = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(DY)) + (size_t)n_first * yimg, (short)0,
-                                                                        (int)(yleft > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (unsigned)yleft), 0x00020000);
-  constexpr unsigned OOB = 0xFFFFFFF0u;
-  typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
-  auto bload = [](__amdgpu_buffer_rsrc_t r, unsigned off) {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0);
-    return make_uint4(v[0], v[1], v[2], v[3]);
-  };
-  const int prow = tid / TPR, cl = tid % TPR;
-  unsigned cha_off[NJA], chb_off[NJB];
-#pragma unroll
-  for (int j = 0; j < NJA; ++j) { const int ch = cl + TPR * j; cha_off[j] = (ch < CHA && k0 + ch * CE < a.K) ? (unsigned)((k0 + ch * CE) * ES) : OOB; }
-#pragma unroll
-  for (int j = 0; j < NJB; ++j) { const int ch = cl + TPR * j; chb_off[j] = (ch < CHB && c0 + ch * CE < a.C) ? (unsigned)((c0 + ch * CE) * ES) : OOB; }
-  const int xr_extra = BP + (tid >> 3), xc_extra = tid & 7;                    // threads 0..15 also stage x rows 64, 65
-  const unsigned chx_off = (tid < 2 * CHB && c0 + xc_extra * CE < a.C) ? (unsigned)((c0 + xc_extra * CE) * ES) : OOB;
-  const long mtot = (long)a.N * pq;
-
-  uint4 ra[NJA], rb[NJB], rx;
-  auto load_tile = [&](int it) {
-    const int mb = m_begin + it * BP;
-    const int m = mb + prow;
-    const unsigned yoff = m < m_end ? (unsigned)(((size_t)(m - n_first * pq)) * a.K * ES) : OOB;
-#pragma unroll
-    for (int j = 0; j < NJA; ++j) ra[j] = bload(ydesc, (yoff != OOB && cha_off[j] != OOB) ? yoff + cha_off[j] : OOB);
-    // x tile row j holds flattened source pixel mb + dh * W - 1 + j (its content is only USED where the masks below allow)
-    const long sx = (long)mb + dh * W - 1 + prow;
-    const unsigned xoff = (sx >= (long)n_first * pq && sx < mtot) ? (unsigned)((size_t)(sx - (long)n_first * pq) * a.C * ES) : OOB;
-#pragma unroll
-    for (int j = 0; j < NJB; ++j) rb[j] = bload(xdesc, (xoff != OOB && chb_off[j] != OOB) ? xoff + chb_off[j] : OOB);
-    const long sx2 = (long)mb + dh * W - 1 + xr_extra;
-    const unsigned xoff2 = (tid < 2 * CHB && sx2 >= (long)n_first * pq && sx2 < mtot) ? (unsigned)((size_t)(sx2 - (long)n_first * pq) * a.C * ES) : OOB;
-    rx = bload(xdesc, (xoff2 != OOB && chx_off != OOB) ? xoff2 + chx_off : OOB);
-  };
-  auto store_tile = [&](int buf) {
-    char* ta = lds + buf * BUF;
-    char* tb = ta + BP * ROWA;
-    const int sw = ((prow >> 3) & 1) << 1;               // octet swap of the transposed-read layout, by LDS row index
-#pragma unroll
-    for (int j = 0; j < NJA; ++j) {
-      const int ch = cl + TPR * j;
-      if (ch < CHA) *reinterpret_cast<uint4*>(ta + prow * ROWA + (ch ^ sw) * 16) = ra[j];
-    }
-#pragma unroll
-    for (int j = 0; j < NJB; ++j) {
-      const int ch = cl + TPR * j;
-      if (ch < CHB) *reinterpret_cast<uint4*>(tb + prow * ROWB + (ch ^ sw) * 16) = rb[j];
-    }
-    if (tid < 2 * CHB) *reinterpret_cast<uint4*>(tb + xr_extra * ROWB + ((xc_extra ^ (((xr_extra >> 3) & 1) << 1)) * 16)) = rx;
-  };
-
-  f32x4 acc[3][TI][TJ];
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int j = 0; j < TJ; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int wi = wave >> 1, wj = wave & 1;
-  const int cha = wi * TI * 16, chb = wj * TJ * 16;
-  const int g = lane >> 4, qq = (lane & 15) >> 2, pp4 = lane & 3;
-  const char* zrow = lds + 2 * BUF;
-
-  // one transposed fragment (8 pixels x 16 channels per lane group) from two row addresses
-  auto frag2 = [&](const char* r0, const char* r1, int ch0, int row0, int row1) -> v8 {
-    const char* a0 = r0 + ((ch0 ^ (((row0 >> 3) & 1) << 4)) + 4 * pp4) * 2;
-    const char* a1 = r1 + ((ch0 ^ (((row1 >> 3) & 1) << 4)) + 4 * pp4) * 2;
-    typename H16<T>::v4 lo = H16<T>::tr(a0), hi = H16<T>::tr(a1);
-    v8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-  };
-
-  if (niter > 0) { load_tile(0); store_tile(0); }
-  __syncthreads();
-  for (int it = 0; it < niter; ++it) {
-    const int buf = it & 1;
-    if (it + 1 < niter) load_tile(it + 1);
-    const char* ta = lds + buf * BUF;
-    const char* tb = ta + BP * ROWA;
-    const int mb = m_begin + it * BP;
-#pragma unroll
-    for (int s = 0; s < BP / 32; ++s) {
-      // this lane's two pixel rows of the 32-pixel k-step and their validity
-      const int r0 = 32 * s + 8 * g + qq, r1 = r0 + 4;
-      bool yok[2], xm[2], xp[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int m = mb + (u ? r1 : r0);
-        int n = (int)__umulhi((unsigned)m, a.magic_pq);
-        int rem = m - n * pq;
-        if (rem >= pq) { ++n; rem -= pq; }
-        int p = (int)__umulhi((unsigned)rem, a.magic_q), w = rem - p * W;
-        if (w >= W) { ++p; w -= W; }
-        yok[u] = m < m_end && (unsigned)(p + dh) < (unsigned)H;
-        xm[u] = w > 0; xp[u] = w + 1 < W;
-      }
-      const char* ya0 = yok[0] ? ta + r0 * ROWA : zrow;
-      const char* ya1 = yok[1] ? ta + r1 * ROWA : zrow;
-      v8 fa[TI];
-#pragma unroll
-      for (int i = 0; i < TI; ++i) fa[i] = frag2(ya0, ya1, cha + 16 * i, yok[0] ? r0 : 0, yok[1] ? r1 : 0);
-#pragma unroll
-      for (int t = 0; t < 3; ++t) {                      // dw = t - 1: x tile row = pixel row + t
-        const bool ok0 = t == 1 || (t == 0 ? xm[0] : xp[0]), ok1 = t == 1 || (t == 0 ? xm[1] : xp[1]);
-        const char* xb0 = ok0 ? tb + (r0 + t) * ROWB : zrow;
-        const char* xb1 = ok1 ? tb + (r1 + t) * ROWB : zrow;
-        v8 fb[TJ];
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) fb[j] = frag2(xb0, xb1, chb + 16 * j, ok0 ? r0 + t : 0, ok1 ? r1 + t : 0);
-#pragma unroll
-        for (int i = 0; i < TI; ++i)
-#pragma unroll
-          for (int j = 0; j < TJ; ++j) acc[t][i][j] = H16<T>::mfma(fa[i], fb[j], acc[t][i][j]);
-      }
-    }
-    if (it + 1 < niter) store_tile(buf ^ 1);
-    __syncthreads();
-  }
-
-  float* __restrict__ out = a.out + (size_t)split * a.K * a.RS * a.C;
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int i = 0; i < TI; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int k = k0 + cha + 16 * i + (lane >> 4) * 4 + r;
-        if (k >= a.K) continue;
-#pragma unroll
-        for (int j = 0; j < TJ; ++j) {
-          const int c = c0 + chb + 16 * j + (lane & 15);
-          if (c < a.C) out[((size_t)k * a.RS + dhi * 3 + t) * a.C + c] = acc[t][i][j][r];
-        }
-      }
-}
+// (A three-taps-per-workgroup form -- dy loaded once for a row of taps, x as one run of 66 pixels read shifted, padding by redirecting
+// the transposed read to a zero row: 28-40 % fewer bytes per FLOP -- was built, parity-tested and measured 10-30 % SLOWER on the
+// WRN-28-10 shapes (253 registers, a pixel decode and address selects in every k-step); DESIGN.md 6e.  It is gone.)
 
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n, int splits, int accum) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -558,40 +374,6 @@ int wgrad_splits(const rn_conv_geom* g, int bk, int bc, bool im2col = false, int
   return splits;
 }
 
-// three-taps-per-workgroup kernel: which geometries take it, and its split count (one resident round of 512 workgroups)
-inline bool wgrad3_geom_ok(const rn_conv_geom* g) {
-  return g->R == 3 && g->S == 3 && g->stride == 1 && g->pad == 1 && g->P == g->H && g->Q == g->W && g->C >= 64 && g->Q >= 2;
-}
-inline bool use_wgrad3(const rn_conv_geom* g, int dtype) {
-  // EXPERIMENTAL, opt-in (rn_set_variant 1 << 22): parity-tested, 28-40 % fewer bytes per FLOP, but measured 10-30 % SLOWER than
-  // wgrad_kernel on the WRN-28-10 shapes (253 registers, per-k-step pixel decode and address selects for the zero-row masking)
-  if (!(g_rn_variant & (1 << 22))) return false;
-  return dtype != RN_F32 && wgrad3_geom_ok(g);
-}
-inline int wgrad3_splits(const rn_conv_geom* g, int bk) {
-  const long M = (long)g->N * g->P * g->Q;
-  const int tiles = cdiv(g->K, bk) * cdiv(g->C, 64) * 3;
-  int splits = 512 / tiles;
-  const int max_by_rows = (int)((M + 255) / 256);
-  if (splits > max_by_rows) splits = max_by_rows;
-  if (splits < 1) splits = 1;
-  if (splits > 256) splits = 256;
-  return splits;
-}
-template <typename T> int launch_w3(const WgradArgs& a, int bk, hipStream_t s) {
-  const int grid = a.kt * a.ct * 3 * a.splits;
-  rn_note_kernel("wgrad3<%dx64>", bk);
-  if (rn_dry_run()) return 0;
-  if constexpr (sizeof(T) == 2) {
-    if (bk == 160) hipLaunchKernelGGL((wgrad3_kernel<T, 5>), dim3(grid), dim3(256), 0, s, a);
-    else if (bk == 128) hipLaunchKernelGGL((wgrad3_kernel<T, 4>), dim3(grid), dim3(256), 0, s, a);
-    else if (bk == 64) hipLaunchKernelGGL((wgrad3_kernel<T, 2>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((wgrad3_kernel<T, 1>), dim3(grid), dim3(256), 0, s, a);
-  }
-  RN_CHECK_LAUNCH("wgrad3");
-  return 0;
-}
-
 template <typename T, int TI, int TJ, bool IC = false>
 int launch_w(const WgradArgs& a, hipStream_t s) {
   int grid = a.kt * a.ct * a.nt * a.splits;
@@ -630,10 +412,6 @@ extern "C" size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g) {
     const size_t need = (size_t)wgrad_splits(g, bk, bc, ic) * g->K * g->R * g->S * g->C * sizeof(float);
     if (need > best) best = need;
   }
-  if (wgrad3_geom_ok(g)) {                               // sized for either kernel, whatever the variant switch says at this moment
-    const size_t need = (size_t)wgrad3_splits(g, pick_tile(g->K)) * g->K * g->R * g->S * g->C * sizeof(float);
-    if (need > best) best = need;
-  }
   return best;
 }
 
@@ -645,9 +423,8 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   RN_CHECK_ARG(g->C % ce == 0 && g->K % ce == 0, "rn_conv_wgrad: C=%d, K=%d must be multiples of %d", g->C, g->K, ce);
   RN_CHECK_ARG(g->R == g->S && g->R * g->S <= MAX_TAPS, "rn_conv_wgrad: kernel %dx%d unsupported", g->R, g->S);
   RN_CHECK_ARG((long)g->N * g->P * g->Q < (1L << 31), "rn_conv_wgrad: too many pixels");
-  const bool w3 = use_wgrad3(g, dtype);
-  const bool ic = !w3 && use_im2col(g, ce);
-  const int bk = pick_tile(g->K), bc = w3 ? 64 : col_tile(g, ic);
+  const bool ic = use_im2col(g, ce);
+  const int bk = pick_tile(g->K), bc = col_tile(g, ic);
   WgradArgs a{};
   a.im2col = ic ? 1 : 0;
   a.xcd_remap = (g_rn_variant & 4) ? 0 : 1;
@@ -667,7 +444,7 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   // (26 per WRN-28-10 step); with an eighth of the slots left free they dispatch at once.  rn_set_variant 1 << 24: full round.
   static const int fork_cap = getenv("RN_WGRAD_FORK_CAP") ? atoi(getenv("RN_WGRAD_FORK_CAP")) : 448;      // tuning hook
   const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? fork_cap : 512;
-  a.splits = w3 ? wgrad3_splits(g, bk) : wgrad_splits(g, bk, bc, ic, capacity);
+  a.splits = wgrad_splits(g, bk, bc, ic, capacity);
   a.rows_per_split = ((a.M + a.splits - 1) / a.splits + 31) / 32 * 32;
   a.kt = cdiv(g->K, bk); a.ct = cdiv(ic ? g->R * g->S * g->C : g->C, bc);
   const size_t n = (size_t)g->K * a.RS * g->C;
@@ -678,8 +455,7 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   }
   a.out = direct ? dw_krsc : reinterpret_cast<float*>(ws);
   int e = 0;
-  if (w3) { RN_BY_DTYPE(dtype, e = launch_w3<T_>(a, bk, as_stream(s))); }
-  else { RN_BY_DTYPE(dtype, e = dispatch_w<T_>(a, bk, bc, as_stream(s))); }
+  RN_BY_DTYPE(dtype, e = dispatch_w<T_>(a, bk, bc, as_stream(s)));
   if (e) return e;
   if (!direct) {
     const long n4 = (long)(n / 4);

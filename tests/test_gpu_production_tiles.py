@@ -152,29 +152,23 @@ PATCH_SMALL = [
     (1, 16, 16, 320, 320, 3, 1, 1),      # two column tiles
     (9, 8, 8, 128, 128, 3, 1, 1),        # 9 images of 8x8: tile tail, BN = 128
 ]
-PATCH_KERNELS = {'128': 16 | (1 << 21), '256': 16 | (1 << 18)}      # rn_set_variant: 16 lifts the minimum-grid rule; 1 << 21 / 1 << 18 select a kernel
+PATCH = 16 | (1 << 21)               # rn_set_variant: 16 lifts the minimum-grid rule, 1 << 21 takes the LDS-patch kernel wherever the geometry allows
 
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
-@pytest.mark.parametrize('kern', list(PATCH_KERNELS))
 @pytest.mark.parametrize('g', PATCH_SMALL)
-def test_patch_kernels_on_small_geometries(g, kern, dtype):
-    """the (opt-in, experimental) LDS-patch 3x3 kernels, forward AND data gradient, on shapes that exercise their tails."""
-    if kern == '256' and g[1] * g[2] < 256:
-        pytest.skip('the 256-pixel kernel holds whole-row patches of 16- and 32-wide maps only')
-    ran = run_conv_case(g, dtype, variant=PATCH_KERNELS[kern], expect_same_names=False)
-    assert sum(n.startswith(f'igemm_patch<{kern}x') for n in ran) == 2, ran          # forward and dgrad both took it
+def test_patch_kernel_on_small_geometries(g, dtype):
+    """the LDS-patch 3x3 kernel (16x16x32 MFMA tiles), forward AND data gradient, on shapes that exercise its tails."""
+    ran = run_conv_case(g, dtype, variant=PATCH, expect_same_names=False)
+    assert sum(n.startswith('igemm_patch<128x') for n in ran) == 2, ran          # forward and dgrad both took it
 
 
-@pytest.mark.parametrize('kern', list(PATCH_KERNELS))
-@pytest.mark.parametrize('g', [(4, 16, 16, 72, 160, 3, 1, 1), (4, 16, 16, 96, 160, 3, 1, 1), (4, 16, 16, 40, 160, 3, 1, 1)])
-def test_patch_kernels_channel_tails(g, kern):
-    """forward only reaches the patch kernels here (the data gradient has 72 / 96 / 40 output channels): channel counts that end inside
-    a chunk (a k-step half empty, a chunk half empty)."""
-    if g[3] < 64:
-        pytest.skip('the patch kernels take layers with at least 64 input channels') if False else None
-    ran = run_conv_case(g, 'fp16', variant=PATCH_KERNELS[kern], expect_same_names=False)
-    assert ran[0].startswith(f'igemm_patch<{kern}x') or g[3] < 64, ran
+@pytest.mark.parametrize('g', [(4, 16, 16, 72, 160, 3, 1, 1), (4, 16, 16, 96, 160, 3, 1, 1), (4, 16, 16, 80, 160, 3, 1, 1)])
+def test_patch_kernel_channel_tails(g):
+    """forward only reaches the patch kernel here (the data gradient has 72 / 96 / 80 output channels): channel counts that end inside
+    a chunk (a 32-channel k-step half empty, a chunk half empty)."""
+    ran = run_conv_case(g, 'fp16', variant=PATCH, expect_same_names=False)
+    assert ran[0].startswith('igemm_patch<128x'), ran
 
 
 def test_production_set_reaches_every_instantiation():
@@ -188,62 +182,67 @@ def test_production_set_reaches_every_instantiation():
         assert need in names, (need, sorted(names))
 
 
-@pytest.mark.parametrize('kern', list(PATCH_KERNELS))
 @pytest.mark.parametrize('g', [PROD_GEOMS[0], PROD_GEOMS[3]])
-def test_patch_kernels_on_production_shapes(g, kern):
-    """WRN-28-10 stage 1 / stage 2 at batch 128 through the opt-in patch kernels (grids of 512-1024 workgroups, XCD remap, two column tiles)."""
-    ran = run_conv_case(g, 'fp16', variant=PATCH_KERNELS[kern] & ~16, expect_same_names=False)
-    assert sum(n.startswith(f'igemm_patch<{kern}x') for n in ran) == 2, ran
+def test_patch_kernel_on_production_shapes(g):
+    """WRN-28-10 stage 1 / stage 2 at batch 128 take the patch kernel by the shipped rule (grids of 512-1024 workgroups, XCD remap, two column tiles)."""
+    ran = run_conv_case(g, 'fp16', expect_same_names=False)
+    assert sum(n.startswith('igemm_patch<128x') for n in ran) == 2, ran
 
 
-WGRAD3_SMALL = [
-    (3, 8, 8, 64, 64, 3, 1, 1),          # one 64-channel tile, several images per 64-pixel step (image boundaries inside a k-step)
-    (2, 9, 7, 72, 48, 3, 1, 1),          # odd map (rows of 7 pixels), channel tail (72 = 64 + 8), K = 48
-    (5, 16, 16, 160, 160, 3, 1, 1),      # 2.5 channel tiles, K tile 160
-    (1, 32, 32, 64, 320, 3, 1, 1),       # two K tiles
-    (2, 5, 3, 64, 32, 3, 1, 1),          # 3-pixel rows: both halo taps masked on almost every pixel
-    (7, 8, 8, 128, 96, 3, 1, 1),         # 448 pixels: uneven pixel splits
-]
-
-
-@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
-@pytest.mark.parametrize('g', WGRAD3_SMALL)
-def test_wgrad_three_taps_per_workgroup(g, dtype):
-    """the (opt-in, experimental) 3x3 weight-gradient kernel that gives a workgroup a whole row of taps (zero-row masking of the
-    padding, shifted reads of one x tile), on shapes that exercise image boundaries, tails and splits."""
-    ran = run_conv_case(g, dtype, variant=1 << 22, expect_same_names=False)
-    assert any(n.startswith('wgrad3<') for n in ran), ran
-
-
-def test_wgrad3_exact_integers():
-    """integer-valued operands: every product and partial sum is exact in fp32, the result must equal the reference bit for bit
-    (catches a wrong pixel <-> fragment-element map or a mis-shifted tap, which a tolerance could blur)."""
+def _one_op_engine(kind, g, bufs_shapes, dtype=torch.float16):
     import gpu_harness as h
-    g = (4, 16, 16, 64, 64, 3, 1, 1)
-    gm = geom(*g)
-    N, Hh, W, C, K, k, s, p = g
-    b = h.PlanBuilder()
-    x = b.slot('x', (N, Hh, W, C)); dy = b.slot('dy', (N, Hh, W, K)); dw = b.slot('dw', (K, 3, 3, C), 'f32'); ws = b.slot('workspace', (0,), 'u8')
-    b.op(ir.OP_CONV_WGRAD, buf=dict(x=x, dy=dy, dw=dw, ws=ws), dim=dict(gm))
-    b.ws_need.append(('wgrad', gm))
-    plan = b.plan(False)
-    plan.slot_of['ws'] = ws
-    rng = np.random.RandomState(0)
-    xv = rng.randint(-3, 4, size=(N, Hh, W, C)).astype(np.float32)
-    dv = rng.randint(-2, 3, size=(N, Hh, W, K)).astype(np.float32)
     from pytorch_ddp_resnet_amd.engine.executor import Engine
-    eng = Engine(plan, h.DEV, torch.float16)
-    eng.tensors[x].copy_(torch.from_numpy(xv).to(torch.float16)); eng.tensors[dy].copy_(torch.from_numpy(dv).to(torch.float16))
+    gm = geom(*g)
+    b = h.PlanBuilder()
+    slots = {name: b.slot(name, shape, dt) for name, (shape, dt) in bufs_shapes.items()}
+    b.op(kind, buf={k: v for k, v in slots.items()}, dim=dict(gm, res_mode=0, res_C=0) if kind != ir.OP_CONV_WGRAD else dict(gm))
+    if kind == ir.OP_CONV_WGRAD:
+        b.ws_need.append(('wgrad', gm))
+    plan = b.plan(False)
+    if kind == ir.OP_CONV_WGRAD:
+        plan.slot_of['ws'] = slots['ws']
+    return Engine(plan, h.DEV, dtype), slots
+
+
+@pytest.mark.parametrize('g', [(4, 16, 16, 64, 160, 3, 1, 1), (2, 32, 32, 160, 160, 3, 1, 1), (3, 8, 8, 96, 128, 3, 1, 1)])
+def test_patch_kernel_exact_integers(g):
+    """integer-valued operands: every product and partial sum is exact in fp32, so the convolution must equal the reference BIT FOR BIT
+    (catches a wrong lane <-> pixel / channel map of the 16x16x32 fragments or a mis-shifted tap, which a tolerance could blur)."""
+    N, Hh, W, C, K, k, s_, p = g
+    eng, sl = _one_op_engine(ir.OP_CONV_FWD, g, dict(x=((N, Hh, W, C), 'T'), w_fwd=((K, 9, C), 'T'), y=((N, Hh, W, K), 'T')))
+    rng = np.random.RandomState(1)
+    xv = rng.randint(-2, 3, size=(N, Hh, W, C)).astype(np.float32)
+    wv = rng.randint(-1, 2, size=(K, 3, 3, C)).astype(np.float32)
+    eng.tensors[sl['x']].copy_(torch.from_numpy(xv).to(torch.float16))
+    eng.tensors[sl['w_fwd']].copy_(torch.from_numpy(wv).reshape(K, 9, C).to(torch.float16))
     eng.bind({})
     L = _lib.lib()
-    L.rn_set_variant(1 << 22)
+    L.rn_set_variant(PATCH)
     try:
         L.rn_kernel_log(1)
         eng.run(0, 1, 0)
         torch.cuda.synchronize()
-        assert 'wgrad3<' in L.rn_kernel_log_read().decode()
+        assert 'igemm_patch<128x' in L.rn_kernel_log_read().decode()
     finally:
         L.rn_kernel_log(0)
         L.rn_set_variant(0)
+    ref = torch.nn.functional.conv2d(_nchw(torch.from_numpy(xv)), torch.from_numpy(wv).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert float(ref.abs().max()) < 2048                     # representable in fp16: the stored output is exact too
+    assert torch.equal(eng.tensors[sl['y']].float().cpu(), ref.contiguous())
+
+
+def test_wgrad_exact_integers():
+    """the weight gradient on integer-valued operands equals the reference bit for bit (transposed fragment reads, tap shifts, split-K
+    slabs summed in fixed order)."""
+    g = (4, 16, 16, 64, 64, 3, 1, 1)
+    N, Hh, W, C, K, k, s_, p = g
+    eng, sl = _one_op_engine(ir.OP_CONV_WGRAD, g, dict(x=((N, Hh, W, C), 'T'), dy=((N, Hh, W, K), 'T'), dw=((K, 3, 3, C), 'f32'), ws=((0,), 'u8')))
+    rng = np.random.RandomState(0)
+    xv = rng.randint(-3, 4, size=(N, Hh, W, C)).astype(np.float32)
+    dv = rng.randint(-2, 3, size=(N, Hh, W, K)).astype(np.float32)
+    eng.tensors[sl['x']].copy_(torch.from_numpy(xv).to(torch.float16)); eng.tensors[sl['dy']].copy_(torch.from_numpy(dv).to(torch.float16))
+    eng.bind({})
+    eng.run(0, 1, 0)
+    torch.cuda.synchronize()
     ref = torch.nn.grad.conv2d_weight(_nchw(torch.from_numpy(xv)), (K, C, 3, 3), _nchw(torch.from_numpy(dv)), 1, 1).permute(0, 2, 3, 1)
-    assert torch.equal(eng.tensors[dw].cpu(), ref.contiguous())
+    assert torch.equal(eng.tensors[sl['dw']].cpu(), ref.contiguous())
