@@ -362,11 +362,25 @@ constexpr int IM2COL_BC = 160;
 inline int col_tile(const rn_conv_geom* g, bool ic) { return ic ? IM2COL_BC : pick_tile(g->C); }
 inline bool use_im2col(const rn_conv_geom* g, int dtype_ce) { return g->C == dtype_ce && g->R * g->S >= 4; }   // one-chunk inputs: the stem
 
-int wgrad_splits(const rn_conv_geom* g, int bk, int bc, bool im2col = false, int capacity = 512) {
+// workgroups of a (bk x bc) tile that are resident at once: 256 CUs x what LDS (two 64- / 16-pixel stages of both operands) and the
+// accumulator registers allow -- 2 per CU at 160 x 160, 8 at 32 x 32.  Thin layers (ResNet-20 / v2-164: 16..64 channels) are a chain of
+// ~1 us load -> LDS -> barrier steps per workgroup; sized for 512 workgroups like the wide tiles they ran 37 such steps each at an eighth
+// of the occupancy the tile allows (33 us for 8 MB of input).
+inline int wgrad_capacity(int bk, int bc, int ce) {
+  const int es = ce == 8 ? 2 : 4, bp = ce == 8 ? 64 : 16;
+  const int lds = 2 * bp * (padded_row(bk * es) + padded_row(bc * es));
+  const int tiles16 = (bk / 32) * (bc / 32);             // 16x16 accumulator tiles per wave
+  const int by_regs = tiles16 <= 1 ? 8 : (tiles16 <= 4 ? 5 : (tiles16 <= 10 ? 3 : 2));
+  int per_cu = 160 * 1024 / lds;
+  if (per_cu > by_regs) per_cu = by_regs;
+  if (per_cu < 1) per_cu = 1;
+  return 256 * per_cu;
+}
+
+int wgrad_splits(const rn_conv_geom* g, int bk, int bc, bool im2col, int capacity) {
   const long M = (long)g->N * g->P * g->Q;
   const int tiles = im2col ? cdiv(g->K, bk) * cdiv(g->R * g->S * g->C, bc) : cdiv(g->K, bk) * cdiv(g->C, bc) * g->R * g->S;
-  int splits = capacity / tiles;                         // one resident round: 2 workgroups per CU x 256 CUs (1 per CU for the
-                                                         // forked launches, to leave registers for the main stream: -1.5 %)
+  int splits = capacity / tiles;                         // one resident round (7/8 of one for the forked launches, see rn_conv_wgrad)
   const int max_by_rows = (int)((M + 255) / 256);      // at least 8 K-steps per block
   if (splits > max_by_rows) splits = max_by_rows;
   if (splits < 1) splits = 1;
@@ -409,7 +423,7 @@ extern "C" size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g) {
   for (int ce : {4, 8}) {                     // the workspace is sized before the dtype is known: take the larger need
     const bool ic = use_im2col(g, ce);
     const int bk = pick_tile(g->K), bc = col_tile(g, ic);
-    const size_t need = (size_t)wgrad_splits(g, bk, bc, ic) * g->K * g->R * g->S * g->C * sizeof(float);
+    const size_t need = (size_t)wgrad_splits(g, bk, bc, ic, wgrad_capacity(bk, bc, ce)) * g->K * g->R * g->S * g->C * sizeof(float);
     if (need > best) best = need;
   }
   return best;
@@ -442,8 +456,8 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   // A FORKED weight gradient (side stream, beside the data-gradient / BatchNorm chain) is sized to 7/8 of a resident round: a
   // one-round grid retires no workgroup until it ends, so the chain's tiny finalize kernels waited ~19 us each for a slot
   // (26 per WRN-28-10 step); with an eighth of the slots left free they dispatch at once.  rn_set_variant 1 << 24: full round.
-  static const int fork_cap = getenv("RN_WGRAD_FORK_CAP") ? atoi(getenv("RN_WGRAD_FORK_CAP")) : 448;      // tuning hook
-  const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? fork_cap : 512;
+  const int round = (g_rn_variant & (1 << 23)) ? 512 : wgrad_capacity(bk, bc, ce);       // 1 << 23: the fixed 512-workgroup round (A/B)
+  const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? round / 8 * 7 : round;
   a.splits = wgrad_splits(g, bk, bc, ic, capacity);
   a.rows_per_split = ((a.M + a.splits - 1) / a.splits + 31) / 32 * 32;
   a.kt = cdiv(g->K, bk); a.ct = cdiv(ic ? g->R * g->S * g->C : g->C, bc);
