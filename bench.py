@@ -129,6 +129,8 @@ def main():
                     help='also run the reference\'s SGD update (config.yaml:22-28) inside the timed step; the headline metric is fwd+bwd: none')
     ap.add_argument('--dropout', type=float, default=None, help='override the workload\'s dropout probability (diagnostics)')
     ap.add_argument('--per-op', type=int, default=0, help='with --breakdown: list the N slowest single ops with their geometry')
+    ap.add_argument('--host-input', action='store_true',
+                    help='diagnostic (never the headline): the batch starts in pinned host memory and crosses PCIe inside every timed step, as with the reference\'s DataLoader + x.to(device) (training.py:93-94)')
     args = ap.parse_args()
 
     cfg = dict(WORKLOADS[args.workload])
@@ -163,7 +165,7 @@ def main():
                        'preact': cfg['preact'], 'use_proj': cfg['use_proj'], 'dropout_prob': cfg['p'], 'batch_per_gpu': cfg['batch'],
                        'global_batch': cfg['batch'] * world, 'parallelism': f'dp{world}',
                        'timed_region': 'fwd + CE loss/top-k + bwd + grad all-reduce' + (' (no optimizer step)' if args.optimizer == 'none' else f' + SGD step ({args.optimizer})'),
-                       'sync_bn': bool(args.sync_bn), 'loss_scale': res['loss_scale']},
+                       'sync_bn': bool(args.sync_bn), 'loss_scale': res['loss_scale'], **({'host_input': True} if args.host_input else {})},
             'step_ms_spread': res['spread'],
             'roofline': res['roof'],
         }
@@ -216,9 +218,16 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
         else:
             opt = torch.optim.SGD(model.parameters(), **sgd_args)
 
+    x_host = y_host = None
+    if getattr(args, 'host_input', False):
+        x_host, y_host = x.cpu().pin_memory(), y.cpu().pin_memory()
+
     def step():
+        nonlocal x, y
         for p_ in params:
             p_.grad = None                                   # optimizer.zero_grad() of training.py:113 (set_to_none)
+        if x_host is not None:
+            x, y = x_host.to(dev, non_blocking=True), y_host.to(dev, non_blocking=True)
         logits = model(x)
         loss = compute_losses_and_metrics(logits, y)['loss']          # CE + top-1/top-5 as one launch (metrics.py:10-29)
         if dtype == 'fp16':

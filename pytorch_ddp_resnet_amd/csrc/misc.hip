@@ -141,7 +141,7 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x
     const int p = (int)(pix % P);
     const int nn = (int)(pix / P);
     float m[CE];
-    unsigned char am[CE];
+    __attribute__((aligned(8))) unsigned char am[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) { m[e] = -FLT_MAX; am[e] = 255; }
     for (int r = 0; r < k; ++r) {
@@ -162,9 +162,9 @@ __global__ __launch_bounds__(NT) void maxpool_fwd_kernel(const T* __restrict__ x
 #pragma unroll
     for (int e = 0; e < CE; ++e) o.e[e] = Elem<T>::from_f(m[e]);
     store_chunk<T>(y + i * CE, o);
-    if (idx) {
-#pragma unroll
-      for (int e = 0; e < CE; ++e) idx[i * CE + e] = am[e];
+    if (idx) {                                             // the chunk's argmax bytes leave in ONE store (the backward reads them the same way)
+      if constexpr (CE == 8) *reinterpret_cast<uint2*>(idx + i * CE) = *reinterpret_cast<const uint2*>(am);
+      else *reinterpret_cast<unsigned*>(idx + i * CE) = *reinterpret_cast<const unsigned*>(am);
     }
   }
 }
