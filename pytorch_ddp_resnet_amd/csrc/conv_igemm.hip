@@ -944,14 +944,14 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
   __syncthreads();
 
   const int l8 = lane >> 3, sl = lane & 7;
+  // the 16-byte chunk a lane copies: its slot `sl` XOR the row swizzle ((row >> 1) & 7).  Rows of one lane are 32 apart from one DMA
+  // piece to the next (row = 8 (4 t + wave) + l8), so the swizzle -- and the chunk -- is the SAME for every piece: one register, not one per piece
+  const int ch = sl ^ ((wave * 4 + (l8 >> 1)) & 7);
   unsigned aoff[AI];
-  int ach[AI];
 #pragma unroll
   for (int t = 0; t < AI; ++t) {
     const int idx = t * NW + wave;
     const int pp = idx * 8 + l8;
-    const int ch = sl ^ ((pp >> 1) & 7);
-    ach[t] = ch;
     aoff[t] = OOB;
     if (idx < nA && pp < PP) {
       const int prow = pp / W2, pcol = pp - prow * W2;
@@ -962,13 +962,10 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
     }
   }
   unsigned boff[BI];
-  int bch[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
     const int j = i * NW + wave;
     const int rn = j * 8 + l8;
-    const int ch = sl ^ ((rn >> 1) & 7);
-    bch[i] = ch;
     const int k = n0 + rn;
     boff[i] = k < a.Kd ? (unsigned)((size_t)k * a.wrs * a.Cs * ES + ch * 16) : OOB;
   }
@@ -996,7 +993,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
     for (int t = 0; t < AI; ++t) {
       const int idx = t * NW + wave;
       if (idx < nA) {                                    // wave-uniform
-        const bool ok = aoff[t] != OOB && chunk * 8 + ach[t] < a.cpt;
+        const bool ok = aoff[t] != OOB && chunk * 8 + ch < a.cpt;
         dma16(ra_desc, ok ? aoff[t] + (unsigned)(chunk * 128) : OOB, lds0 + (unsigned)(idx * 1024));
       }
     }
@@ -1014,7 +1011,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
       const int j = i * NW + wave;
-      const bool ok = boff[i] != OOB && chunk * 8 + bch[i] < a.cpt;
+      const bool ok = boff[i] != OOB && chunk * 8 + ch < a.cpt;
       dma16(rb_desc, ok ? boff[i] + (unsigned)(woff + chunk * 128) : OOB, lds0 + (unsigned)((ASZ + stg * BSZ) * 16 + j * 1024));
     }
   };
