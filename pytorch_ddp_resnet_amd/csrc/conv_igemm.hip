@@ -315,11 +315,18 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, AccT& acc, int m0, int
             if (a.bn_mask) r.cm = load_chunk<T>(reinterpret_cast<const T*>(a.bn_mask) + r.off);
           }
         };
-        Row nxt;
-        fetch(rl, nxt);
-        for (int srow = rl; srow < SR; srow += LANES) {
-          const Row cur = nxt;
-          fetch(srow + LANES, nxt);
+        // G rows in flight per thread: these epilogues are latency-bound on their operand loads (a 1x1 data gradient of WRN-50-2 is two
+        // K steps and then 128 x 128 outputs with 2-3 operand chunks each); registers allow 4 rows at up to 128 columns, 2 at 160
+        constexpr int RMAX = (SR + LANES - 1) / LANES;
+        constexpr int G = (RMAX >= 4 && BN <= 128) ? 4 : (RMAX >= 2 ? 2 : 1);
+        for (int base = rl; base < SR; base += G * LANES) {
+          Row rows[G];
+#pragma unroll
+          for (int u = 0; u < G; ++u) fetch(base + u * LANES, rows[u]);
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+          const int srow = base + u * LANES;
+          const Row& cur = rows[u];
           if (!cur.ok) continue;
           float v[CE];
           const float* cp = ctile + srow * LDC + cg * CE;
@@ -361,6 +368,7 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, AccT& acc, int m0, int
             for (int e = 0; e < CE; ++e)
 #pragma unroll
               for (int gg = 0; gg < NGRP; ++gg) if (gg == gi) { s0[gg][e] += d0[e]; s1[gg][e] += d1[e]; }
+          }
           }
         }
       }
