@@ -74,7 +74,8 @@ enum {
   RN_F_SKIP_FWD_PACK = 1 << 5,
   RN_F_NO_DX = 1 << 6,        /* pool_fc_bwd etc.: input gradient not needed                */
   RN_F_MASK_RECOMPUTE = 1 << 7, /* bn_bwd_*: mask = [x*scale+shift > 0] & dropout hash, recomputed instead of read (mask_src NULL) */
-  RN_F_FORK = 1 << 8          /* plan executor: run this weight-gradient op on the side stream (rn_plan_set_overlap) */
+  RN_F_FORK = 1 << 8,         /* plan executor: run this weight-gradient op on the side stream (rn_plan_set_overlap) */
+  RN_F_DEFER_REDUCE = 1 << 9  /* rn_conv_wgrad: write the split-K slabs only; the caller sums them later (rn_wgrad_reduce_batch) */
 };
 
 #define RN_OP_NBUF 8
@@ -124,6 +125,12 @@ int rn_plan_join(rn_plan* plan, rn_stream stream);
  * stream (rn_plan_join at the end of the range still does that) */
 int rn_plan_side_wait(rn_plan* plan, rn_stream stream);
 int rn_plan_num_ops(const rn_plan* plan);
+/* Deferred weight-gradient slab sums inside a plan: rn_plan_defer_reduce marks the (not forked) CONV_WGRAD ops whose reduction is of the
+ * deferrable kind, gives each its own slab region in an arena and returns the arena bytes (0: none); rn_plan_set_reduce_arena hands the
+ * arena over (NULL: off).  rn_plan_run then sums the slabs of a whole range in batched launches at the END of the range (and every
+ * RN_REDUCE_BATCH_MAX layers): a host-side consumer of the gradients (bucket hooks) sits between ranges and sees them complete. */
+size_t rn_plan_defer_reduce(rn_plan* plan);
+int rn_plan_set_reduce_arena(rn_plan* plan, void* arena, size_t bytes);
 /* per-op hipEvent pairs on the launch stream; rn_plan_profile_read blocks and returns ms per op (0 = not run) */
 int rn_plan_profile(rn_plan* plan, int enable);
 int rn_plan_profile_read(rn_plan* plan, float* ms, int n);
@@ -194,6 +201,21 @@ int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* res
 int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void* ws, size_t ws_bytes, int flags, int dtype,
                   const rn_conv_geom* g, rn_stream s);
 size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g);
+/* Deferred slab sums.  A thin layer's weight gradient is a ~10 us kernel followed by a ~5 us launch that only adds its split-K slabs;
+ * with RN_F_DEFER_REDUCE rn_conv_wgrad leaves the slabs in `ws` (which must then be a region of its OWN until they are summed) and
+ * rn_wgrad_reduce_batch sums the slabs of up to RN_REDUCE_BATCH_MAX layers in ONE launch -- same per-output summation order as the
+ * immediate reduction (bitwise identical results).  rn_conv_wgrad_splits: the slab count [splits][K*R*S*C] that launch writes
+ * (0: it writes dw directly, nothing to sum; < 0: this geometry's reduction is not of the deferrable kind). */
+#define RN_REDUCE_BATCH_MAX 32
+typedef struct rn_reduce_desc {
+  const float* slabs;   /* [splits][n] */
+  float* dw;            /* [n] */
+  int64_t n;
+  int32_t splits;
+  int32_t accumulate;   /* dw += sum */
+} rn_reduce_desc;
+int rn_conv_wgrad_splits(const rn_conv_geom* g, int dtype, int flags);
+int rn_wgrad_reduce_batch(const rn_reduce_desc* descs, int n, rn_stream s);
 
 /* BatchNorm over a [M, C] view.  partial: [nblk][2][C] fp32 (sum, sum of squares) of nblk row slabs; the caller picks
  * nblk (one workgroup per slab) */

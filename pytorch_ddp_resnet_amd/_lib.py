@@ -47,6 +47,9 @@ def lib():
     L.rn_plan_set_overlap.argtypes = [vp, i32]
     L.rn_plan_join.argtypes = [vp, vp]
     L.rn_plan_side_wait.argtypes = [vp, vp]
+    L.rn_plan_defer_reduce.argtypes = [vp]
+    L.rn_plan_defer_reduce.restype = C.c_size_t
+    L.rn_plan_set_reduce_arena.argtypes = [vp, vp, C.c_size_t]
     L.rn_plan_destroy.restype = None
     L.rn_conv_wgrad_ws_bytes.argtypes = [C.POINTER(RnConvGeom)]
     L.rn_conv_wgrad_ws_bytes.restype = sz

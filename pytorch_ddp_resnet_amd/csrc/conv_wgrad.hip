@@ -307,11 +307,11 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
 // Small outputs split many ways (1x1 convolutions of thin layers: 1,024 outputs x 512 slabs): one thread per output would walk
 // the slabs serially (measured 43 us).  Here 16 threads share an output chunk, each sums every 16th slab with 4 loads in
 // flight, and the 16 partial sums are combined through LDS in a fixed order (bitwise reproducible).
-__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n, int splits, int accum) {
-  __shared__ float4 part[16][17];
+__device__ inline void reduce_wide_body(const float* __restrict__ ws, float* __restrict__ dw, long n, int splits, int accum, int blk, int nblk,
+                                        float4 (*part)[17]) {
   const long n4 = n >> 2;
   const int o = threadIdx.x & 15, sl = threadIdx.x >> 4;
-  for (long base = (long)blockIdx.x * 16; base < n4; base += (long)gridDim.x * 16) {
+  for (long base = (long)blk * 16; base < n4; base += (long)nblk * 16) {
     const long i = base + o;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i < n4) {
@@ -343,6 +343,29 @@ __global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __r
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(256) void wgrad_reduce_wide_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n, int splits, int accum) {
+  __shared__ float4 part[16][17];
+  reduce_wide_body(ws, dw, n, splits, accum, (int)blockIdx.x, (int)gridDim.x, part);
+}
+// the same sums for several layers in one launch (deferred reductions of thin networks: 165 launches of ~5 us per ResNet-v2-164 step); a
+// workgroup finds its layer by the block prefix sums, like pack_w_batch_kernel.  Per output the summation order is that of the kernel above.
+struct ReduceBatch {
+  rn_reduce_desc d[RN_REDUCE_BATCH_MAX];
+  int first_block[RN_REDUCE_BATCH_MAX + 1];
+  int n;
+};
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(const ReduceBatch rb) {
+  __shared__ float4 part[16][17];
+  int l = 0;
+  while (l + 1 < rb.n && (int)blockIdx.x >= rb.first_block[l + 1]) ++l;
+  const rn_reduce_desc& d = rb.d[l];
+  reduce_wide_body(d.slabs, d.dw, (long)d.n, d.splits, d.accumulate, (int)blockIdx.x - rb.first_block[l], rb.first_block[l + 1] - rb.first_block[l], part);
+}
+inline int reduce_wide_blocks(long n4) {
+  int blocks = (int)((n4 + 15) / 16);
+  return blocks > 4096 ? 4096 : blocks;
+}
+inline bool reduce_is_wide(int splits, long n4) { return splits >= 32 && n4 < 65536; }      // few outputs, many slabs: the slab walk is split over 16 threads
 
 struct WCfg { int bk, bc; };
 
@@ -473,11 +496,14 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   if (e) return e;
   if (!direct) {
     const long n4 = (long)(n / 4);
-    rn_note_kernel((a.splits >= 32 && n4 < 65536) ? "wgrad_reduce_wide" : "wgrad_reduce");
+    rn_note_kernel(reduce_is_wide(a.splits, n4) ? "wgrad_reduce_wide" : "wgrad_reduce");
     if (rn_dry_run()) return 0;
-    if (a.splits >= 32 && n4 < 65536) {                  // few outputs, many slabs: split the slab walk over 16 threads
-      int blocks = (int)((n4 + 15) / 16);
-      if (blocks > 4096) blocks = 4096;
+    if (flags & RN_F_DEFER_REDUCE) {                     // the caller sums the slabs later (rn_wgrad_reduce_batch): only for the wide kind
+      RN_CHECK_ARG(reduce_is_wide(a.splits, n4), "rn_conv_wgrad: RN_F_DEFER_REDUCE on a geometry whose reduction is not deferrable (rn_conv_wgrad_splits < 0)");
+      return 0;
+    }
+    if (reduce_is_wide(a.splits, n4)) {
+      const int blocks = reduce_wide_blocks(n4);
       hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(blocks), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), dw_krsc, (long)n,
                          a.splits, (flags & RN_F_ACCUM) ? 1 : 0);
     } else {
@@ -489,5 +515,35 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
     }
     RN_CHECK_LAUNCH("wgrad_reduce");
   }
+  return 0;
+}
+
+extern "C" int rn_conv_wgrad_splits(const rn_conv_geom* g, int dtype, int flags) {
+  if (!g || !RN_DTYPE_OK(dtype)) return -1;
+  const int ce = dtype == RN_F32 ? 4 : 8;
+  const bool ic = use_im2col(g, ce);
+  const int bk = pick_tile(g->K), bc = col_tile(g, ic);
+  const int round = (g_rn_variant & (1 << 23)) ? 512 : wgrad_capacity(bk, bc, ce);
+  const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? round / 8 * 7 : round;
+  const int splits = wgrad_splits(g, bk, bc, ic, capacity);
+  if (splits == 1 && !(flags & RN_F_ACCUM)) return 0;
+  const long n4 = (long)g->K * g->R * g->S * g->C / 4;
+  return reduce_is_wide(splits, n4) ? splits : -1;
+}
+
+extern "C" int rn_wgrad_reduce_batch(const rn_reduce_desc* descs, int n, rn_stream s) {
+  RN_CHECK_ARG(descs && n > 0 && n <= RN_REDUCE_BATCH_MAX, "rn_wgrad_reduce_batch: n=%d out of range (1..%d)", n, RN_REDUCE_BATCH_MAX);
+  ReduceBatch rb;
+  rb.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    RN_CHECK_ARG(descs[i].slabs && descs[i].dw && descs[i].n > 0 && descs[i].n % 4 == 0 && descs[i].splits > 0, "rn_wgrad_reduce_batch: bad descriptor %d", i);
+    rb.d[i] = descs[i];
+    rb.first_block[i] = blocks;
+    blocks += reduce_wide_blocks(descs[i].n / 4);
+  }
+  rb.first_block[n] = blocks;
+  hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3(blocks), dim3(256), 0, as_stream(s), rb);
+  RN_CHECK_LAUNCH("wgrad_reduce_batch");
   return 0;
 }

@@ -73,6 +73,12 @@ struct rn_plan {
   // their results are consumed after rn_plan_join.  They overlap the data-gradient / BatchNorm chain, which is the critical
   // path of the backward and leaves matrix-pipe and HBM idle time in every kernel's prologue, epilogue and tail round.
   bool overlap = false, side_pending = false;
+  // Deferred weight-gradient slab sums (rn_plan_defer_reduce): marked CONV_WGRAD ops leave their slabs in a region of their own; the
+  // sums of a whole run of ops go out as batched launches (rn_wgrad_reduce_batch) at the end of the range / every 32 layers
+  std::vector<long> slab_off;      // per op: byte offset of its slab region in the arena, -1 = reduces immediately
+  std::vector<int> slab_splits;
+  size_t arena_bytes = 0;
+  char* arena = nullptr;           // deferral is on iff it is set
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_peek = nullptr;
   ~rn_plan() {
@@ -98,6 +104,32 @@ extern "C" int rn_plan_create(const rn_op* ops, int n_ops, int n_bufs, int dtype
   p->ws_bytes.assign(n_bufs, 0);
   p->dtype = dtype;
   *out = p;
+  return 0;
+}
+
+extern "C" size_t rn_plan_defer_reduce(rn_plan* plan) {
+  if (!plan) return 0;
+  const int n = (int)plan->ops.size();
+  plan->slab_off.assign(n, -1); plan->slab_splits.assign(n, 0);
+  size_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    const rn_op& o = plan->ops[i];
+    if (o.kind != RN_OP_CONV_WGRAD || (o.flags & RN_F_FORK)) continue;       // forked ops own a stream and a workspace: they reduce there
+    rn_conv_geom g;
+    g.N = o.dim[0]; g.H = o.dim[1]; g.W = o.dim[2]; g.C = o.dim[3]; g.P = o.dim[4]; g.Q = o.dim[5]; g.K = o.dim[6];
+    g.R = o.dim[7]; g.S = o.dim[8]; g.stride = o.dim[9]; g.pad = o.dim[10];
+    const int splits = rn_conv_wgrad_splits(&g, plan->dtype, o.flags);
+    if (splits <= 0) continue;
+    plan->slab_off[i] = (long)off; plan->slab_splits[i] = splits;
+    off += ((size_t)splits * g.K * g.R * g.S * g.C * sizeof(float) + 255) / 256 * 256;
+  }
+  plan->arena_bytes = off;
+  return off;
+}
+extern "C" int rn_plan_set_reduce_arena(rn_plan* plan, void* arena, size_t bytes) {
+  RN_CHECK_ARG(plan != nullptr, "rn_plan_set_reduce_arena: null plan");
+  RN_CHECK_ARG(!arena || (!plan->slab_off.empty() && bytes >= plan->arena_bytes), "rn_plan_set_reduce_arena: call rn_plan_defer_reduce first and pass at least the bytes it returned");
+  plan->arena = plan->arena_bytes ? reinterpret_cast<char*>(arena) : nullptr;
   return 0;
 }
 
@@ -286,7 +318,40 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
 extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_seed, rn_stream stream) {
   RN_CHECK_ARG(plan != nullptr, "rn_plan_run: null plan");
   RN_CHECK_ARG(first >= 0 && last <= (int)plan->ops.size() && first <= last, "rn_plan_run: bad range [%d, %d)", first, last);
+  rn_reduce_desc pending[RN_REDUCE_BATCH_MAX];
+  int pending_slot[RN_REDUCE_BATCH_MAX];                  // the dw buffer of each pending sum: an op that touches one forces the flush first
+  int n_pending = 0;
+  auto flush = [&]() -> int {
+    if (!n_pending) return 0;
+    const int e = rn_wgrad_reduce_batch(pending, n_pending, stream);
+    n_pending = 0;
+    return e;
+  };
   for (int i = first; i < last; ++i) {
+    if (plan->arena && !plan->profile && plan->slab_off[i] >= 0) {      // a weight gradient whose slab sum is deferred to the end of the range
+      const rn_op& o = plan->ops[i];
+      auto P = [&](int b) -> void* { return o.buf[b] >= 0 ? plan->bufs[o.buf[b]] : nullptr; };
+      rn_conv_geom g = geom_of(o);
+      const size_t nel = (size_t)g.K * g.R * g.S * g.C;
+      char* slabs = plan->arena + plan->slab_off[i];
+      int e = (P(0) && P(1) && P(2)) ? rn_conv_wgrad(P(0), P(1), (float*)P(2), slabs, (size_t)plan->slab_splits[i] * nel * sizeof(float), o.flags | RN_F_DEFER_REDUCE,
+                                                     plan->dtype, &g, stream)
+                                     : (rn_set_error("rn_plan_run: op %d (kind %d) uses an unbound buffer", i, o.kind), 1);
+      if (e) { std::string msg = g_err; rn_set_error("op %d (kind %d): %s", i, o.kind, msg.c_str()); return e; }
+      pending_slot[n_pending] = o.buf[2];
+      pending[n_pending++] = rn_reduce_desc{reinterpret_cast<const float*>(slabs), (float*)P(2), (int64_t)nel, plan->slab_splits[i], (o.flags & RN_F_ACCUM) ? 1 : 0};
+      if (n_pending == RN_REDUCE_BATCH_MAX)
+        if (int e2 = flush()) return e2;
+      continue;
+    }
+    if (n_pending) {                                       // e.g. the stem: UNPACK_STEM_DW reads the padded weight gradient right behind its CONV_WGRAD
+      bool touched = false;
+      for (int b = 0; b < RN_OP_NBUF && !touched; ++b)
+        for (int q = 0; q < n_pending; ++q)
+          if (plan->ops[i].buf[b] >= 0 && plan->ops[i].buf[b] == pending_slot[q]) { touched = true; break; }
+      if (touched)
+        if (int e2 = flush()) return e2;
+    }
     if (!plan->profile && plan->ops[i].kind == RN_OP_PACK_W) {         // a run of weight packs becomes one launch
       rn_pack_desc descs[RN_PACK_BATCH_MAX];
       int n = 0;
@@ -325,5 +390,5 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
       return e;
     }
   }
-  return 0;
+  return flush();
 }

@@ -81,6 +81,15 @@ class Engine:
         for i, sl in enumerate(plan.slots):
             if sl.role == 'ws':                     # the main-stream workspace and the side stream's own
                 _lib.check(self.L.rn_plan_set_bytes(self._h, i, max(ws_bytes, 16)))
+        # ---- deferred weight-gradient slab sums: on thin networks every weight gradient is a ~10 us kernel followed by a ~5 us launch that
+        # only adds its split-K slabs (165 of them per ResNet-v2-164 step); with slab regions of their own the sums of a whole range of ops
+        # go out as one batched launch at the end of the range (plan.cpp).  RN_NO_DEFER_REDUCE=1: off (A/B).
+        self._reduce_arena = None
+        if os.environ.get('RN_NO_DEFER_REDUCE', '0') != '1':
+            nbytes = int(self.L.rn_plan_defer_reduce(self._h))
+            if nbytes:
+                self._reduce_arena = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                _lib.check(self.L.rn_plan_set_reduce_arena(self._h, C.c_void_p(self._reduce_arena.data_ptr()), nbytes))
         self._ptrs = (C.c_void_p * len(plan.slots))()
         self._bound = None
         self._hooks = {}

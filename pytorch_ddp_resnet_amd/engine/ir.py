@@ -19,7 +19,7 @@ RES_NONE, RES_SAME, RES_DOWN2PAD, RES_UP2 = 0, 1, 2, 3
 
 OP_NAMES = {v: k for k, v in list(globals().items()) if k.startswith('OP_') and isinstance(v, int)}
 
-F_RELU, F_TRAIN, F_ACCUM, F_WRITE_G, F_NEED_DGRAD_PACK, F_SKIP_FWD_PACK, F_NO_DX, F_MASK_RECOMPUTE, F_FORK = (1 << i for i in range(9))
+F_RELU, F_TRAIN, F_ACCUM, F_WRITE_G, F_NEED_DGRAD_PACK, F_SKIP_FWD_PACK, F_NO_DX, F_MASK_RECOMPUTE, F_FORK, F_DEFER_REDUCE = (1 << i for i in range(10))
 
 OP_NBUF, OP_NDIM = 8, 20
 CONV_STATS_ROWS = 128      # RN_CONV_STATS_ROWS: output pixels per partial-sum row of a fused conv epilogue

@@ -355,3 +355,47 @@ def test_dropout_backward_recomputes_the_mask_from_the_hash(fp32):
     assert h.max_rel(hip['out'], ref['out']) < TOL[fp32] and h.max_rel(hip['din'], ref['din']) < TOL[fp32]
     kept_zero = (hip['din'] != 0) & (np.broadcast_to(xv == 0, hip['din'].shape))
     assert kept_zero.mean() > 0.3                     # ~70 % of the zero-input elements are kept and carry gradient
+
+
+def test_deferred_slab_sums_equal_the_immediate_reduction_bit_for_bit():
+    """rn_conv_wgrad(RN_F_DEFER_REDUCE) + ONE rn_wgrad_reduce_batch over three layers == three rn_conv_wgrad calls with their own
+    reduction launches (same per-output summation order), with and without accumulation into dw."""
+    import ctypes as C
+    from pytorch_ddp_resnet_amd import _lib
+    L = _lib.lib()
+    vp, i32 = C.c_void_p, C.c_int32
+
+    class Desc(C.Structure):
+        _fields_ = [('slabs', vp), ('dw', vp), ('n', C.c_int64), ('splits', i32), ('accumulate', i32)]
+    L.rn_conv_wgrad.argtypes = [vp, vp, vp, vp, C.c_size_t, i32, i32, C.POINTER(_lib.RnConvGeom), vp]
+    L.rn_conv_wgrad_splits.argtypes = [C.POINTER(_lib.RnConvGeom), i32, i32]
+    L.rn_wgrad_reduce_batch.argtypes = [C.POINTER(Desc), i32, vp]
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    geoms = [(64, 32, 32, 16, 16, 3, 1, 1), (64, 16, 16, 32, 32, 3, 1, 1), (64, 32, 32, 64, 16, 1, 1, 0)]
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    for accum in (0, ir.F_ACCUM):
+        descs = (Desc * len(geoms))()
+        keep, want, got = [], [], []
+        for j, (N, Hh, W, Cc, K, k, s_, p) in enumerate(geoms):
+            g = _lib.RnConvGeom(N, Hh, W, Cc, Hh, W, K, k, k, s_, p)
+            x = torch.randn(N, Hh, W, Cc, device='cuda', generator=gen).half()
+            dy = torch.randn(N, Hh, W, K, device='cuda', generator=gen).half()
+            splits = int(L.rn_conv_wgrad_splits(C.byref(g), 2, accum))
+            assert splits >= 32                                          # a thin layer: many slabs, the deferrable kind
+            n = K * k * k * Cc
+            ws = torch.empty(splits * n, device='cuda')
+            dw0 = torch.full((n,), 0.5, device='cuda')
+            dw1 = dw0.clone()
+            _lib.check(L.rn_conv_wgrad(vp(x.data_ptr()), vp(dy.data_ptr()), vp(dw0.data_ptr()), vp(ws.data_ptr()), ws.numel() * 4, accum, 2, C.byref(g), st))
+            ws2 = torch.empty(splits * n, device='cuda')
+            _lib.check(L.rn_conv_wgrad(vp(x.data_ptr()), vp(dy.data_ptr()), vp(dw1.data_ptr()), vp(ws2.data_ptr()), ws2.numel() * 4, accum | ir.F_DEFER_REDUCE, 2,
+                                       C.byref(g), st))
+            descs[j] = Desc(ws2.data_ptr(), dw1.data_ptr(), n, splits, 1 if accum else 0)
+            keep += [x, dy, ws, ws2]
+            want.append(dw0); got.append(dw1)
+        torch.cuda.synchronize()
+        assert all(torch.equal(b, torch.full_like(b, 0.5)) for b in got)       # nothing summed yet
+        _lib.check(L.rn_wgrad_reduce_batch(descs, len(geoms), st))
+        torch.cuda.synchronize()
+        for a_, b_ in zip(want, got):
+            assert torch.equal(a_, b_) and float(a_.abs().max()) > 1.0
