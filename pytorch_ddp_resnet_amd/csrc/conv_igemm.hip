@@ -162,7 +162,7 @@ __device__ inline void lds_barrier() {
 }
 
 // SR: staged rows per pass (64 or 32, whatever fits the K-loop's LDS next to the reduction scratch)
-// L16: the accumulators come from v_mfma_f32_16x16x32 tiles -- acc[2 TM][2 TN] of f32x4, element r of lane l = tile row 4 (l >> 4) + r,
+// L16: the accumulators come from v_mfma_f32_16x16x32 tiles -- acc[2 TM][TN] of f32x4 (TN then counts 16-column tiles), element r of lane l = tile row 4 (l >> 4) + r,
 // column l & 15 -- instead of 32x32 tiles (acc[TM][TN] of f32x16: row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31); only the parking
 // of the registers in LDS (phase 1) and the staged-row <-> tile-row map differ
 template <typename T, int BM, int BN, int WM, int WN, int TM, int TN, int NTH = WM * WN * 64, int SR = 64, bool L16 = false, typename AccT>
@@ -171,7 +171,7 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, AccT& acc, int m0, int
 #pragma unroll
     for (int i = 0; i < (L16 ? 2 * TM : TM); ++i)
 #pragma unroll
-      for (int j = 0; j < (L16 ? 2 * TN : TN); ++j)
+      for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < (L16 ? 4 : 16); ++r) asm volatile("" ::"v"(acc[i][j][r]));
     if (a.probe_ep == 2) return;
@@ -240,7 +240,7 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, AccT& acc, int m0, int
             for (int r = 0; r < 4; ++r) {
               const int srow = blk * RPB + (RPB == 16 ? 4 * lq + r : 4 * (lq & 1) + r);
 #pragma unroll
-              for (int j = 0; j < 2 * TN; ++j) ctile[srow * LDC + wn * (BN / WN) + 16 * j + l16] = acc[2 * i + it][j][r];
+              for (int j = 0; j < TN; ++j) ctile[srow * LDC + wn * (BN / WN) + 16 * j + l16] = acc[2 * i + it][j][r];
             }
           }
         }
@@ -908,9 +908,13 @@ int launch_cfg(const IgemmArgs& a, hipStream_t s) {
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int PATCH128_PP_MAX = 208;                     // 6x34 (W=32), 10x18 (W=16), 2 x 10x10 (W=8)
 // FULLC: the channel count is a multiple of 64 (every chunk runs both k-steps: no tail branches in the hot loop)
-template <typename T, int BN, bool FULLC>
+// WN: the four waves as 2 x 2 (a wave = 64 rows x BN/2 columns: 9 fragment reads per 20 MFMAs; 4 x 1 -- 32 rows x BN columns, 12 reads -- measured
+// equal on stage 1 and 2 % slower on stage 2)
+template <typename T, int BN, bool FULLC, int WN = 2>
 __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs a) {
-  constexpr int BM = 128, NW = 4, ES = (int)sizeof(T), TN = BN / 32;
+  constexpr int BM = 128, NW = 4, ES = (int)sizeof(T);
+  constexpr int WM = NW / WN, RT = BM / WM / 16, CT = BN / WN / 16;      // 16-row / 16-column MFMA tiles of a wave
+  static_assert((BN / WN) % 16 == 0 && RT % 2 == 0, "wave tile");
   constexpr int CHK = 128 / ES;                          // channels per chunk (one 128-byte LDS row per pixel)
   constexpr int ASZ = PATCH128_PP_MAX * 8;               // uint4 in the patch buffer
   constexpr int BIT = BN / 8;                            // weight-tile DMA instructions per step (8 rows of 128 bytes each)
@@ -984,15 +988,18 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
     const int h = rem / W, w = rem - h * W;
     return ((n - n_first) * (multi ? slab_rows : 0) + (h - h_first) + 1) * W2 + w + 1;
   };
-  int base_pp = patch_pixel(m0 + wave * 32 + l16);      // the wave's two 16-row tiles
-  int base_pp1 = patch_pixel(m0 + wave * 32 + 16 + l16);
+  const int wm = wave / WN, wn = wave % WN;
+  int base_pp[RT];                                       // the wave's 16-row tiles
+#pragma unroll
+  for (int i = 0; i < RT; ++i) base_pp[i] = patch_pixel(m0 + wm * (BM / WM) + 16 * i + l16);
   const int bsw = (l16 >> 1) & 7;
+  const int bcol0 = wn * (BN / WN);                      // first weight row (output column) of the wave; a multiple of 16: same swizzle
 
-  f32x4 acc16[2][2 * TN];
+  f32x4 acc16[RT][CT];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < RT; ++i)
 #pragma unroll
-    for (int j = 0; j < 2 * TN; ++j)
+    for (int j = 0; j < CT; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) acc16[i][j][r] = 0.f;
 
@@ -1041,8 +1048,8 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
     const int kcount = FULLC ? 4 : min(4, (a.cpt - chunk * 8 + 1) >> 1);    // 16-channel k-steps of this chunk that hold data
     const bool full = FULLC || kcount == 4;
     const uint4* Ab = &smem[0];
-    asm volatile("" : "+v"(base_pp));                    // the per-tap fragment addresses repeat in every chunk: left alone, hipcc computes
-    asm volatile("" : "+v"(base_pp1));                   // all 36 of them once and spills them
+#pragma unroll
+    for (int i = 0; i < RT; ++i) asm volatile("" : "+v"(base_pp[i]));   // the per-tap fragment addresses repeat in every chunk: left alone, hipcc computes them all once and spills them
     {
 #pragma unroll
       for (int t = 0; t < 9; ++t, ++step) {
@@ -1052,34 +1059,35 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
           load_weights(t == 8 ? chunk + 1 : chunk, woff_t[t == 8 ? 0 : t + 1], (step + 1) & 1);
           m0_restore(keep);
         }
-        const int pp = base_pp + poff_t[t];
-        const int pa = pp * 8, sa = (pp >> 1) & 7;
-        const int pp1 = base_pp1 + poff_t[t];
-        const int pa1 = pp1 * 8, sa1 = (pp1 >> 1) & 7;
-        const bool two = full || 2 < kcount;             // the chunk's second 32 channels hold data
-        uint4 ga0[2], ga1[2], gb[2 * TN];
-        ga0[0] = Ab[pa + (lq ^ sa)];
-        ga0[1] = Ab[pa1 + (lq ^ sa1)];
+        int pa[RT], sa[RT];
 #pragma unroll
-        for (int j = 0; j < 2 * TN; ++j) gb[j] = Bb[(l16 + 16 * j) * 8 + (lq ^ bsw)];
+        for (int i = 0; i < RT; ++i) {
+          const int pp = base_pp[i] + poff_t[t];
+          pa[i] = pp * 8; sa[i] = (pp >> 1) & 7;
+        }
+        const bool two = full || 2 < kcount;             // the chunk's second 32 channels hold data
+        uint4 ga0[RT], ga1[RT], gb[CT];
+#pragma unroll
+        for (int i = 0; i < RT; ++i) ga0[i] = Ab[pa[i] + (lq ^ sa[i])];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) gb[j] = Bb[(bcol0 + l16 + 16 * j) * 8 + (lq ^ bsw)];
         if (two) {
-          ga1[0] = Ab[pa + ((4 + lq) ^ sa)];
-          ga1[1] = Ab[pa1 + ((4 + lq) ^ sa1)];
+#pragma unroll
+          for (int i = 0; i < RT; ++i) ga1[i] = Ab[pa[i] + ((4 + lq) ^ sa[i])];
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int j = 0; j < 2 * TN; ++j) {
-          Mfma16<T>::run(ga0[0], gb[j], acc16[0][j]);
-          Mfma16<T>::run(ga0[1], gb[j], acc16[1][j]);
-          if (two) gb[j] = Bb[(l16 + 16 * j) * 8 + ((4 + lq) ^ bsw)];
+        for (int j = 0; j < CT; ++j) {
+#pragma unroll
+          for (int i = 0; i < RT; ++i) Mfma16<T>::run(ga0[i], gb[j], acc16[i][j]);
+          if (two) gb[j] = Bb[(bcol0 + l16 + 16 * j) * 8 + ((4 + lq) ^ bsw)];
           __builtin_amdgcn_sched_barrier(0);
         }
         if (two) {
 #pragma unroll
-          for (int j = 0; j < 2 * TN; ++j) {
-            Mfma16<T>::run(ga1[0], gb[j], acc16[0][j]);
-            Mfma16<T>::run(ga1[1], gb[j], acc16[1][j]);
-          }
+          for (int j = 0; j < CT; ++j)
+#pragma unroll
+            for (int i = 0; i < RT; ++i) Mfma16<T>::run(ga1[i], gb[j], acc16[i][j]);
         }
         __builtin_amdgcn_sched_barrier(0);
         wait_vmcnt<0>();                                 // next step's weight tile landed (own DMAs), then everybody's
@@ -1094,7 +1102,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
       __builtin_amdgcn_s_barrier();
     }
   }
-  igemm_epilogue<T, BM, BN, NW, 1, 1, TN, 256, 64, true>(a, acc16, m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
+  igemm_epilogue<T, BM, BN, WM, WN, RT / 2, CT, 256, 64, true>(a, acc16, m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
 }
 
 // geometry the LDS-patch kernel covers: 3x3 taps of a same-size stride-1 convolution (forward or data gradient), tiles of whole
