@@ -218,6 +218,10 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
         else:
             opt = torch.optim.SGD(model.parameters(), **sgd_args)
 
+    # with an optimizer in the step the fp16 engine runs under a real GradScaler (scaled backward, unscale + skip-on-inf inside the
+    # optimizer step, dynamic scale), i.e. training.py:100-110: applying the SCALED gradients would blow the weights up to inf within
+    # a few steps -- and a network full of inf / nan runs 6 % "faster" (the chip clocks higher on trivial data)
+    scaler = torch.amp.GradScaler('cuda') if (opt is not None and dtype == 'fp16') else None
     x_host = y_host = None
     if getattr(args, 'host_input', False):
         x_host, y_host = x.cpu().pin_memory(), y.cpu().pin_memory()
@@ -230,13 +234,18 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
             x, y = x_host.to(dev, non_blocking=True), y_host.to(dev, non_blocking=True)
         logits = model(x)
         loss = compute_losses_and_metrics(logits, y)['loss']          # CE + top-1/top-5 as one launch (metrics.py:10-29)
-        if dtype == 'fp16':
+        if scaler is not None:
+            scaler.scale(loss).backward()
+        elif dtype == 'fp16':
             (loss * loss_scale).backward()
         else:
             loss.backward()
         if reducer is not None:
             reducer.finish()
-        if opt is not None:
+        if scaler is not None:
+            scaler.step(opt)
+            scaler.update()
+        elif opt is not None:
             opt.step()
         return loss
 
@@ -247,7 +256,7 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
 
     for i in range(max(warmup, 1)):
         step()
-        if dtype == 'fp16' and i < 8:                        # loss-scale backoff, outside the timed region
+        if dtype == 'fp16' and scaler is None and i < 8:     # loss-scale backoff, outside the timed region
             eng0 = next(e for k, e in model._engines.items() if k[1] and k[2])
             bad = torch.logical_not(torch.isfinite(eng0.flat_grad).all()).float()
             if world > 1:
@@ -341,7 +350,7 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
                 print(f'    {ir.OP_NAMES[op.kind]:18s} {t * 1e3:9.1f} us  {geo}{extra}  [{op.note}]', file=sys.stderr)
     if world > 1:
         torch.distributed.barrier()
-    ls = float(loss_scale.item())
+    ls = float(scaler.get_scale()) if scaler is not None else float(loss_scale.item())
     del model, x, y
     torch.cuda.empty_cache()
     return dict(ms=ms, value=value, spread=spread, roof=roof, loss_scale=ls)
