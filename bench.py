@@ -221,7 +221,10 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
     # with an optimizer in the step the fp16 engine runs under a real GradScaler (scaled backward, unscale + skip-on-inf inside the
     # optimizer step, dynamic scale), i.e. training.py:100-110: applying the SCALED gradients would blow the weights up to inf within
     # a few steps -- and a network full of inf / nan runs 6 % "faster" (the chip clocks higher on trivial data)
-    scaler = torch.amp.GradScaler('cuda') if (opt is not None and dtype == 'fp16') else None
+    scaler = None
+    if opt is not None and dtype == 'fp16':
+        from pytorch_ddp_resnet_amd.utils.amp import GradScaler
+        scaler = torch.amp.GradScaler('cuda') if os.environ.get('RN_TORCH_SCALER', '0') == '1' else GradScaler('cuda')
     x_host = y_host = None
     if getattr(args, 'host_input', False):
         x_host, y_host = x.cpu().pin_memory(), y.cpu().pin_memory()

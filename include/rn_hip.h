@@ -279,6 +279,9 @@ int rn_augment_batch(const unsigned char* x_nhwc_u8, const float* mean_chw, cons
 /* fused multi-tensor SGD over one flat fp32 buffer (torch.optim.SGD rule; optim_util.py:11-18, config.yaml:22-28) */
 int rn_sgd_step(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum,
                 float dampening, float weight_decay, int nesterov, int first_step, float grad_scale, rn_stream s);
+/* GradScaler's gradient inspection over one flat buffer (training.py:104-110: scaler.step -> unscale_ / inf check): grads *= *inv_scale_dev
+ * (skipped when it is 1: the check-only call) and *found_inf_dev = 1 if any element is inf or nan (never reset here) */
+int rn_amp_check_unscale(float* grads, int64_t n, const float* inv_scale_dev, float* found_inf_dev, rn_stream s);
 /* the same under AMP (GradScaler.step, training.py:104-110): gradients are divided by *loss_scale_dev and the whole step is skipped
  * when *found_inf_dev != 0 (both device scalars, either may be NULL) */
 int rn_sgd_step_amp(float* param, const float* grad, float* momentum_buf, int64_t n, float lr, float momentum, float dampening,

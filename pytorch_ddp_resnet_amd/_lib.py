@@ -60,6 +60,7 @@ def lib():
     L.rn_sgd_step_amp.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, vp, vp, vp]
     L.rn_set_variant.argtypes = [i32]
     L.rn_augment_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
+    L.rn_amp_check_unscale.argtypes = [vp, C.c_int64, vp, vp, vp]
     L.rn_kernel_log.argtypes = [i32]
     L.rn_kernel_log.restype = None
     L.rn_kernel_log_read.restype = C.c_char_p

@@ -410,6 +410,27 @@ __global__ __launch_bounds__(NT) void augment_kernel(const unsigned char* __rest
   }
 }
 
+// ---- GradScaler's non-finite check (and unscale) over ONE flat gradient buffer (torch walks the parameter list and launches
+// _amp_foreach_non_finite_check_and_unscale_ per device / dtype group: the check alone re-WRITES every gradient) -------------------------
+__global__ __launch_bounds__(NT) void amp_check_unscale_kernel(float* __restrict__ g, long n, const float* __restrict__ inv_scale, float* __restrict__ found_inf) {
+  const float sc = *inv_scale;
+  const bool scale = sc != 1.f;                // the check-only call passes 1: nothing is written back
+  bool bad = false;
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n4; i += (long)gridDim.x * NT) {
+    float4 v = reinterpret_cast<float4*>(g)[i];
+    bad |= !(isfinite(v.x) && isfinite(v.y) && isfinite(v.z) && isfinite(v.w));
+    if (scale) { v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc; reinterpret_cast<float4*>(g)[i] = v; }
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (int)(n & 3)) {
+    const long i = (n4 << 2) + threadIdx.x;
+    const float v = g[i];
+    bad |= !isfinite(v);
+    if (scale) g[i] = v * sc;
+  }
+  if (bad) *found_inf = 1.f;                   // every writer stores the same value
+}
+
 inline int ew_grid(long n) {
   long b = (n + NT - 1) / NT;
   if (b > 4096) b = 4096;
@@ -549,6 +570,13 @@ extern "C" int rn_augment_batch(const unsigned char* x_nhwc_u8, const float* mea
                                           out_nchw, (T_*)out_nhwc, N, H, W, C, pad, pad_mirror ? 1 : 0, crop, CP));
   }
   RN_CHECK_LAUNCH("augment_batch");
+  return 0;
+}
+
+extern "C" int rn_amp_check_unscale(float* grads, int64_t n, const float* inv_scale_dev, float* found_inf_dev, rn_stream s) {
+  RN_CHECK_ARG(grads && n > 0 && inv_scale_dev && found_inf_dev, "rn_amp_check_unscale: bad argument");
+  hipLaunchKernelGGL(amp_check_unscale_kernel, dim3(ew_grid(n >> 2)), dim3(NT), 0, as_stream(s), grads, (long)n, inv_scale_dev, found_inf_dev);
+  RN_CHECK_LAUNCH("amp_check_unscale");
   return 0;
 }
 

@@ -20,6 +20,7 @@ from pytorch_ddp_resnet_amd import ResNet
 from pytorch_ddp_resnet_amd.algos.evaluation import evaluation_loop
 from pytorch_ddp_resnet_amd.algos.training import training_loop
 from pytorch_ddp_resnet_amd.ddp import GradReducer, broadcast_parameters
+from pytorch_ddp_resnet_amd.utils.amp import GradScaler
 from pytorch_ddp_resnet_amd.utils.config_util import ConfigParser
 from pytorch_ddp_resnet_amd.utils.optim_util import get_optimizer, get_scheduler
 
@@ -88,7 +89,7 @@ def setup(rank, config):
     # engine's counterpart is fp16 storage / f16 MFMA with fp32 accumulation, statistics and master weights, under the same
     # GradScaler.  `compute_dtype: fp32 | bf16 | fp16` in the YAML overrides it (neither fp32 nor bf16 needs a scaler).
     compute_dtype = dict(config).get('compute_dtype', 'fp16')
-    scaler = torch.amp.GradScaler('cuda') if (on_gpu and compute_dtype == 'fp16') else None
+    scaler = GradScaler('cuda') if (on_gpu and compute_dtype == 'fp16') else None      # torch.amp.GradScaler, inspecting the flat gradient buffer
     classifier = ResNet(architecture_spec=config.get('architecture_spec'), preact=config.get('preact'), use_proj=config.get('use_proj'),
                         dropout_prob=config.get('dropout_prob'), sync_bn=bool(dict(config).get('sync_bn', False)),
                         compute_dtype=compute_dtype).to(device)

@@ -241,8 +241,10 @@ def test_fused_loss_matches_torch_ops_and_carries_the_loss_scale():
         assert float((g_fused[k] / 64.0 - p.grad).abs().max()) <= 2e-5 * scale, k
 
 
-def test_fp16_training_with_grad_scaler_matches_fp32_steps():
-    """the reference's AMP branch (training.py:95-110) on the fp16 engine: scaler.scale(loss).backward(), scaler.step(FusedSGD),
+@pytest.mark.parametrize('which', ['torch', 'engine'])
+def test_fp16_training_with_grad_scaler_matches_fp32_steps(which):
+    """(both with torch.amp.GradScaler and with utils.amp.GradScaler, which inspects the flat gradient buffer in one launch)
+    the reference's AMP branch (training.py:95-110) on the fp16 engine: scaler.scale(loss).backward(), scaler.step(FusedSGD),
     scaler.update() -- three steps track the fp32 engine + torch.optim.SGD; an injected overflow skips the step on the device."""
     from pytorch_ddp_resnet_amd import ResNet
     from pytorch_ddp_resnet_amd.algos.training import train_step
@@ -260,7 +262,9 @@ def test_fp16_training_with_grad_scaler_matches_fp32_steps():
     m.load_state_dict({k: v.clone() for k, v in st.items()})
     m = m.cuda().train()
     opt = FusedSGD(m, **args)
-    scaler = torch.amp.GradScaler('cuda', init_scale=2.0 ** 12)
+    from pytorch_ddp_resnet_amd.utils.amp import GradScaler as EngineScaler
+    Scaler = torch.amp.GradScaler if which == 'torch' else EngineScaler
+    scaler = Scaler('cuda', init_scale=2.0 ** 12)
     for step in range(3):
         train_step(m, xc, yc, optimizer=opt, scaler=scaler)
         torch.nn.functional.cross_entropy(ref(xc), yc).backward()
@@ -273,11 +277,26 @@ def test_fp16_training_with_grad_scaler_matches_fp32_steps():
     assert num < 0.3 * den          # fp16 gradients of this 8-sample-statistics case carry ~10 % error (tests/test_gpu_model.py); the point here is the AMP control flow
     # overflow: a scale that drives the fp16 gradients to inf must skip the update and halve the scale
     before = {k: p.detach().clone() for k, p in m.named_parameters()}
-    big = torch.amp.GradScaler('cuda', init_scale=2.0 ** 40)
+    big = Scaler('cuda', init_scale=2.0 ** 40)
     train_step(m, xc, yc, optimizer=opt, scaler=big)
     assert big.get_scale() == 2.0 ** 39
     for k, p in m.named_parameters():
         assert torch.equal(p.detach(), before[k]), k
+    # explicit unscale_ (gradient clipping use): the gradients are divided in place once, the step does not divide again
+    for p_ in m.parameters():
+        p_.grad = None
+    logits = m(xc)
+    loss = torch.nn.functional.cross_entropy(logits, yc)
+    scaler.scale(loss).backward()
+    g_scaled = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+    scaler.unscale_(opt)
+    for k, p in m.named_parameters():
+        assert torch.allclose(p.grad, g_scaled[k] / scaler.get_scale(), rtol=1e-6, atol=0), k
+    w0 = {k: p.detach().clone() for k, p in m.named_parameters()}
+    scaler.step(opt)
+    scaler.update()
+    moved = sum(float((p.detach() - w0[k]).abs().sum()) for k, p in m.named_parameters())
+    assert moved > 0 and all(torch.isfinite(p).all() for p in m.parameters())
 
 
 @pytest.mark.parametrize('dtype', ['fp16', 'fp32'])
