@@ -61,7 +61,10 @@ enum {
   RN_OP_ADD_RES = 21,       /* dst += res (mapped): gradient merge behind a standalone v1 dropout                             */
   RN_OP_IMG_TO_NHWC = 22,   /* NCHW fp32 image -> NHWC compute dtype, channels zero-padded to one 16-byte chunk (MFMA stem)    */
   RN_OP_PACK_STEM_W = 23,   /* stem weights [K][RS][C] fp32 -> [K][RS][CP] compute dtype (padded)                              */
-  RN_OP_UNPACK_STEM_DW = 24 /* stem weight gradient [K][RS][CP] fp32 -> [K][RS][C] (drops the padding)                          */
+  RN_OP_UNPACK_STEM_DW = 24,/* stem weight gradient [K][RS][CP] fp32 -> [K][RS][C] (drops the padding)                          */
+  RN_OP_BN_POOL_FWD = 25,        /* y, argmax = maxpool([relu](x * scale + shift)): BN_APPLY + MAXPOOL_FWD of a top-level "n a mp" in one pass */
+  RN_OP_BN_POOL_BWD_REDUCE = 26, /* BN_BWD_REDUCE over g = [bn(x) > 0] * maxpool_bwd(dy, argmax), without materialising it */
+  RN_OP_BN_POOL_BWD_APPLY = 27   /* BN_BWD_APPLY over the same g */
 };
 
 /* flags */
@@ -253,6 +256,15 @@ int rn_maxpool_fwd(const void* x, void* y, unsigned char* argmax, int dtype, int
                    int pad, rn_stream s);
 int rn_maxpool_bwd(const void* dy, const unsigned char* argmax, void* dx, int dtype, int N, int H, int W, int C, int k,
                    int stride, int pad, rn_stream s);
+/* BatchNorm-apply (+ReLU with RN_F_RELU) + MaxPool fused (the "n a mp3,2,1" stem of the ImageNet nets, resnet.py:111-115, 83-87): the
+ * normalised activation and its gradient are never stored.  C / (16-byte chunk) must divide 256.  The backward pair replaces
+ * rn_maxpool_bwd + rn_bn_bwd_reduce / rn_bn_bwd_apply (mask recomputed from x and coef): partial = [nblk][2][C] rows for rn_bn_bwd_finalize. */
+int rn_bn_pool_fwd(const void* x, const float* coef, void* y, unsigned char* argmax, int dtype, int N, int H, int W, int C, int k, int stride,
+                   int pad, int flags, rn_stream s);
+int rn_bn_pool_bwd_reduce(const void* dy, const unsigned char* argmax, const void* x, const float* coef, float* partial, int nblk, int dtype, int N,
+                          int H, int W, int C, int k, int stride, int pad, int flags, rn_stream s);
+int rn_bn_pool_bwd_apply(const void* dy, const unsigned char* argmax, const void* x, const float* coef, const float* dsum, void* dx, int dtype, int N,
+                         int H, int W, int C, int k, int stride, int pad, int flags, double count, rn_stream s);
 
 /* logits[n,o] = b[o] + sum_c W[o,c] * mean_{hw} x[n,hw,c];  feat: [N][C] fp32 scratch kept for backward */
 int rn_pool_fc_fwd(const void* x, const float* w, const float* b, float* feat, float* logits, int dtype, int N, int HW,

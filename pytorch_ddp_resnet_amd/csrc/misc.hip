@@ -227,6 +227,162 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ d
   }
 }
 
+// ---- BatchNorm-apply + ReLU + MaxPool as ONE pass each way (the stem of the ImageNet nets, resnet.py:111-115 + 83-87: "n a mp3,2,1").
+// Unfused, the 112x112x512 activation of WRN-50-2-B (3.3 GB at batch 256) is written by bn_apply, read by maxpool, and in the backward
+// written by maxpool_bwd, read by bn_bwd_reduce and read again by bn_bwd_apply.  Here the normalised activation and its gradient never
+// exist in memory: the forward pools relu(x * scale + shift) on the fly (each value rounded to the compute dtype BEFORE the comparison,
+// so the argmax is the one the unfused pair picks), the backward gathers the pooled gradient through the stored argmax bytes where the
+// unfused pair would read maxpool_bwd's output.
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ coef, T* __restrict__ y, unsigned char* __restrict__ idx,
+                                                         int N, int H, int W, int C, int P, int Q, int k, int stride, int pad, int relu) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE;
+  const long n = (long)N * P * Q * CC;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const int cg = (int)(i % CC);
+    long pix = i / CC;
+    const int q = (int)(pix % Q); pix /= Q;
+    const int p = (int)(pix % P);
+    const int nn = (int)(pix / P);
+    float sc[CE], sh[CE], m[CE];
+    __attribute__((aligned(8))) unsigned char am[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { sc[e] = coef[cg * CE + e]; sh[e] = coef[C + cg * CE + e]; m[e] = -FLT_MAX; am[e] = 255; }
+    for (int r = 0; r < k; ++r) {
+      const int h = p * stride + r - pad;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int s = 0; s < k; ++s) {
+        const int w = q * stride + s - pad;
+        if ((unsigned)w >= (unsigned)W) continue;
+        Chunk<T> c = load_chunk<T>(x + (((size_t)nn * H + h) * W + w) * C + cg * CE);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+          float v = fmaf(Elem<T>::to_f(c.e[e]), sc[e], sh[e]);
+          if (relu) v = fmaxf(v, 0.f);
+          v = Elem<T>::to_f(Elem<T>::from_f(v));            // what bn_apply would have stored
+          if (v > m[e] || am[e] == 255) { m[e] = v; am[e] = (unsigned char)(r * k + s); }
+        }
+      }
+    }
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) o.e[e] = Elem<T>::from_f(m[e]);
+    store_chunk<T>(y + i * CE, o);
+    if (idx) {
+      if constexpr (CE == 8) *reinterpret_cast<uint2*>(idx + i * CE) = *reinterpret_cast<const uint2*>(am);
+      else *reinterpret_cast<unsigned*>(idx + i * CE) = *reinterpret_cast<const unsigned*>(am);
+    }
+  }
+}
+
+// backward, gather form (as maxpool_bwd_kernel: one workgroup walks image rows, threads walk (w, channel chunk); NT % (C / CE) == 0, so a
+// thread keeps ONE channel chunk).  g = [x * scale + shift > 0] * sum of dy over the windows whose argmax is this element.
+// APPLY 0: partial[blockIdx][2][C] = (sum g, sum g * xhat);   APPLY 1: dx = scale * (g - dsum0 / count - xhat * dsum1 / count)
+template <typename T, int APPLY>
+__global__ __launch_bounds__(NT) void bn_pool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx, const T* __restrict__ x,
+                                                         const float* __restrict__ coef, const float* __restrict__ dsum, float* __restrict__ partial,
+                                                         T* __restrict__ dx, int N, int H, int W, int C, int P, int Q, int k, int stride, int pad, int relu,
+                                                         int train, float inv_count) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE;
+  const int per_row = W * CC;
+  const int cg = threadIdx.x % CC;                         // fixed: NT is a multiple of CC
+  float sc[CE], sh[CE], mean[CE], invstd[CE], ka[CE], kb[CE], kc[CE], s0[CE], s1[CE];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) {
+    const int c = cg * CE + e;
+    sc[e] = coef[c]; sh[e] = coef[C + c]; mean[e] = coef[2 * C + c]; invstd[e] = coef[3 * C + c];
+    s0[e] = s1[e] = 0.f;
+    if (APPLY) {                                           // the coefficients of bn_bwd_apply_stream_kernel
+      const float m0 = train ? __fmul_rn(dsum[c], inv_count) : 0.f, m1 = train ? __fmul_rn(dsum[C + c], inv_count) : 0.f;
+      const float im1 = __fmul_rn(invstd[e], m1);
+      ka[e] = sc[e];
+      kb[e] = train ? -__fmul_rn(sc[e], im1) : 0.f;        // eval-mode BatchNorm: dx = scale * g
+      kc[e] = train ? __fmul_rn(sc[e], __fmaf_rn(im1, mean[e], -m0)) : 0.f;
+    }
+  }
+  for (int row = blockIdx.x; row < N * H; row += gridDim.x) {
+    const int nn = row / H, h = row - nn * H;
+    const int p_lo = max(0, (h + pad - k + stride) / stride), p_hi = min(P - 1, (h + pad) / stride);
+    for (int j = threadIdx.x; j < per_row; j += NT) {
+      const int w = j / CC;
+      const int q_lo = max(0, (w + pad - k + stride) / stride), q_hi = min(Q - 1, (w + pad) / stride);
+      const size_t xo = ((size_t)row * W + w) * C + cg * CE;
+      const Chunk<T> cx = load_chunk<T>(x + xo);
+      float g[CE];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) g[e] = 0.f;
+      auto fetch = [&](int p, int q, Chunk<T>& d, unsigned char* ib) {
+        const size_t o = (((size_t)nn * P + p) * Q + q) * C + cg * CE;
+        d = load_chunk<T>(dy + o);
+        if constexpr (CE == 8) *reinterpret_cast<uint2*>(ib) = *reinterpret_cast<const uint2*>(idx + o);
+        else *reinterpret_cast<unsigned*>(ib) = *reinterpret_cast<const unsigned*>(idx + o);
+      };
+      auto take = [&](int p, int q, const Chunk<T>& d, const unsigned char* ib) {
+        const unsigned me = (unsigned)((h - (p * stride - pad)) * k + (w - (q * stride - pad)));
+#pragma unroll
+        for (int e = 0; e < CE; ++e) if (ib[e] == me) g[e] += Elem<T>::to_f(d.e[e]);
+      };
+      if (p_hi - p_lo <= 1 && q_hi - q_lo <= 1) {            // <= 2 x 2 windows (3x3 stride 2): every load is issued before the first use
+        Chunk<T> d[4];
+        __attribute__((aligned(8))) unsigned char ib[4][CE];
+        bool ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int p = p_lo + (u >> 1), q = q_lo + (u & 1);
+          ok[u] = p <= p_hi && q <= q_hi;
+          if (ok[u]) fetch(p, q, d[u], ib[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (ok[u]) take(p_lo + (u >> 1), q_lo + (u & 1), d[u], ib[u]);
+      } else {
+        for (int p = p_lo; p <= p_hi; ++p)
+          for (int q = q_lo; q <= q_hi; ++q) {
+            Chunk<T> d;
+            __attribute__((aligned(8))) unsigned char ib[CE];
+            fetch(p, q, d, ib);
+            take(p, q, d, ib);
+          }
+      }
+      Chunk<T> co;
+#pragma unroll
+      for (int e = 0; e < CE; ++e) {
+        const float xv = Elem<T>::to_f(cx.e[e]);
+        // maxpool_bwd stores its output in the compute dtype before bn_bwd reads it: the same rounding here
+        float gg = Elem<T>::to_f(Elem<T>::from_f(g[e]));
+        if (relu && !(fmaf(xv, sc[e], sh[e]) > 0.f)) gg = 0.f;
+        if (APPLY) {
+          co.e[e] = Elem<T>::from_f(__fmaf_rn(ka[e], gg, __fmaf_rn(kb[e], xv, kc[e])));
+        } else {
+          const float xh = (xv - mean[e]) * invstd[e];
+          s0[e] += gg; s1[e] += gg * xh;
+        }
+      }
+      if (APPLY) store_chunk<T>(dx + xo, co);
+    }
+  }
+  if (!APPLY) {                                            // the workgroup's row of partial sums: lanes of one channel chunk through LDS
+    __shared__ float red[2][NT][CE + 1];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { red[0][threadIdx.x][e] = s0[e]; red[1][threadIdx.x][e] = s1[e]; }
+    __syncthreads();
+    if ((int)threadIdx.x < CC) {
+      float t0[CE], t1[CE];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) t0[e] = t1[e] = 0.f;
+      for (int l = threadIdx.x; l < NT; l += CC) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { t0[e] += red[0][l][e]; t1[e] += red[1][l][e]; }
+      }
+      float* p0 = partial + ((size_t)blockIdx.x * 2) * C + cg * CE;
+#pragma unroll
+      for (int e = 0; e < CE; ++e) { p0[e] = t0[e]; p0[C + e] = t1[e]; }
+    }
+  }
+}
+
 // ---- global average pool: feat[n][c] = mean_{hw} x[n][hw][c] ------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(NT) void gap_kernel(const T* __restrict__ x, float* __restrict__ feat, int HW, int C) {
@@ -528,6 +684,49 @@ extern "C" int rn_maxpool_bwd(const void* dy, const unsigned char* argmax, void*
   RN_BY_DTYPE(dtype, hipLaunchKernelGGL((maxpool_bwd_kernel<T_>), dim3(rows_grid), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (T_*)dx, N, H, W, C, P, Q, k, stride, pad));
   RN_CHECK_LAUNCH("maxpool_bwd");
   return 0;
+}
+
+// fused BatchNorm-apply (+ReLU) + MaxPool: C / CE must divide 256; nblk (backward reduce) = workgroups = partial rows
+extern "C" int rn_bn_pool_fwd(const void* x, const float* coef, void* y, unsigned char* argmax, int dtype, int N, int H, int W, int C, int k, int stride,
+                              int pad, int flags, rn_stream s) {
+  if (int e = check_pool(dtype, N, H, W, C, k, stride, pad, "rn_bn_pool_fwd")) return e;
+  RN_CHECK_ARG(x && coef && y && k * k < 255, "rn_bn_pool_fwd: bad argument");
+  const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
+  const long n = (long)N * P * Q * (C / (dtype == RN_F32 ? 4 : 8));
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_fwd_kernel<T_>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const T_*)x, coef, (T_*)y, argmax, N, H, W, C, P, Q, k,
+                                        stride, pad, (flags & RN_F_RELU) ? 1 : 0));
+  RN_CHECK_LAUNCH("bn_pool_fwd");
+  return 0;
+}
+static int bn_pool_bwd(const void* dy, const unsigned char* argmax, const void* x, const float* coef, const float* dsum, float* partial, int nblk, void* dx,
+                       int dtype, int N, int H, int W, int C, int k, int stride, int pad, int flags, double count, rn_stream s, const char* who) {
+  if (int e = check_pool(dtype, N, H, W, C, k, stride, pad, who)) return e;
+  const int cc = C / (dtype == RN_F32 ? 4 : 8);
+  RN_CHECK_ARG(dy && argmax && x && coef && NT % cc == 0, "%s: bad argument (C / chunk = %d must divide %d)", who, cc, NT);
+  const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
+  const int relu = (flags & RN_F_RELU) ? 1 : 0;
+  if (partial) {
+    RN_CHECK_ARG(nblk > 0 && nblk <= N * H, "%s: nblk out of range", who);
+    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_kernel<T_, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, nullptr, partial,
+                                          (T_*)nullptr, N, H, W, C, P, Q, k, stride, pad, relu, 1, 0.f));
+  } else {
+    const int train = (flags & RN_F_TRAIN) ? 1 : 0;
+    RN_CHECK_ARG((dsum || !train) && dx && count > 0, "%s: bad argument", who);
+    const int grid = (int)std::min<long>((long)N * H, 8192);
+    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_kernel<T_, 1>), dim3(grid), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, dsum, nullptr,
+                                          (T_*)dx, N, H, W, C, P, Q, k, stride, pad, relu, train, (float)(1.0 / count)));
+  }
+  RN_CHECK_LAUNCH(who);
+  return 0;
+}
+extern "C" int rn_bn_pool_bwd_reduce(const void* dy, const unsigned char* argmax, const void* x, const float* coef, float* partial, int nblk, int dtype, int N,
+                                     int H, int W, int C, int k, int stride, int pad, int flags, rn_stream s) {
+  RN_CHECK_ARG(partial != nullptr, "rn_bn_pool_bwd_reduce: null partial");
+  return bn_pool_bwd(dy, argmax, x, coef, nullptr, partial, nblk, nullptr, dtype, N, H, W, C, k, stride, pad, flags, 1.0, s, "rn_bn_pool_bwd_reduce");
+}
+extern "C" int rn_bn_pool_bwd_apply(const void* dy, const unsigned char* argmax, const void* x, const float* coef, const float* dsum, void* dx, int dtype, int N,
+                                    int H, int W, int C, int k, int stride, int pad, int flags, double count, rn_stream s) {
+  return bn_pool_bwd(dy, argmax, x, coef, dsum, nullptr, 0, dx, dtype, N, H, W, C, k, stride, pad, flags, count, s, "rn_bn_pool_bwd_apply");
 }
 
 extern "C" int rn_pool_fc_fwd(const void* x, const float* w, const float* b, float* feat, float* logits, int dtype, int N, int HW, int C, int O, rn_stream s) {

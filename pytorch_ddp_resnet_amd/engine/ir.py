@@ -15,7 +15,7 @@ RES_NONE, RES_SAME, RES_DOWN2PAD, RES_UP2 = 0, 1, 2, 3
 (OP_STEM_FWD, OP_PACK_W, OP_CONV_FWD, OP_BN_STATS, OP_BN_FINALIZE, OP_BN_APPLY, OP_DROPOUT_FWD, OP_MAXPOOL_FWD,
  OP_POOL_FC_FWD, OP_POOL_FC_BWD, OP_MAXPOOL_BWD, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE, OP_BN_BWD_APPLY,
  OP_CONV_DGRAD, OP_CONV_WGRAD, OP_STEM_WGRAD, OP_DROPOUT_BWD, OP_SOFTMAX_CE, OP_ZERO, OP_ADD_RES, OP_IMG_TO_NHWC,
- OP_PACK_STEM_W, OP_UNPACK_STEM_DW) = range(1, 25)
+ OP_PACK_STEM_W, OP_UNPACK_STEM_DW, OP_BN_POOL_FWD, OP_BN_POOL_BWD_REDUCE, OP_BN_POOL_BWD_APPLY) = range(1, 28)
 
 OP_NAMES = {v: k for k, v in list(globals().items()) if k.startswith('OP_') and isinstance(v, int)}
 
@@ -50,6 +50,9 @@ OP_FIELDS = {
     OP_IMG_TO_NHWC:     ('x out', 'N C H W CP', ''),
     OP_PACK_STEM_W:     ('w w_padded', 'K RS C CP', ''),
     OP_UNPACK_STEM_DW:  ('dw_padded dw', 'K RS C CP', ''),
+    OP_BN_POOL_FWD:     ('x coef y argmax', 'N H W C k stride pad', ''),
+    OP_BN_POOL_BWD_REDUCE: ('dy argmax x coef partial', 'N H W C k stride pad nblk', ''),
+    OP_BN_POOL_BWD_APPLY:  ('dy argmax x coef dsum dx', 'N H W C k stride pad count', ''),
 }
 
 GEOM = 'N H W C P Q K R S stride pad'.split()

@@ -106,6 +106,8 @@ class Lowering:
         # BN-backward sums reduced in the dgrad epilogue (its operands are read as 16-byte chunks by the LDS-staged epilogue):
         # removes the bn_bwd_reduce pass (-1.15 ms) for +0.36 ms of dgrad per WRN-28-10 step (measured)
         self.fuse_dgrad = fuse_dgrad
+        # a top-level "n [a] mp" as ONE pass forward and two gather passes backward (RN_NO_POOL_FUSION=1: the separate ops, A/B)
+        self.fuse_pool = os.environ.get('RN_NO_POOL_FUSION', '0') != '1'
 
     # ---- slots ------------------------------------------------------------------------------------------
     def slot(self, name, role, shape, dtype, key=None):
@@ -487,6 +489,38 @@ class Lowering:
                 cur = y
             elif c.kind == 'norm':
                 relu = idx + 1 < len(comps) and comps[idx + 1].kind == 'act'
+                nxt = comps[idx + (2 if relu else 1)] if idx + (2 if relu else 1) < len(comps) else None
+                ce = 4 if self.fp32 else 8
+                if (nxt is not None and nxt.kind == 'maxpool' and not self.sync and self.fuse_pool and cur.C % ce == 0 and 256 % (cur.C // ce) == 0):
+                    # "n [a] mp": BatchNorm-apply (+ReLU) + MaxPool as one pass each way (the ImageNet stems): the normalised activation
+                    # (WRN-50-2-B: 3.3 GB at batch 256) and its gradient are never stored
+                    k, s, pd = nxt.args
+                    mpre = f'_architecture.{idx + (2 if relu else 1)}'
+                    coef = self.bn_coef(cur, pre)
+                    P, Q = (cur.H + 2 * pd - k) // s + 1, (cur.W + 2 * pd - k) // s + 1
+                    y = self.act(mpre + ':y', cur.N, P, Q, cur.C)
+                    d = dict(N=cur.N, H=cur.H, W=cur.W, C=cur.C, k=k, stride=s, pad=pd)
+                    am = self.slot(mpre + ':argmax', 'u8', (cur.N, P, Q, cur.C), 'u8') if self.need_grad else -1
+                    fl = ir.F_RELU if relu else 0
+                    self.fwd.append(Op(ir.OP_BN_POOL_FWD, buf=dict(x=cur.s, coef=coef, y=y.s, argmax=am), dim=d, flags=fl, note=pre))
+
+                    def norm_pool_back(dy: T, ops, x=cur, coef=coef, pre=pre, d=d, am=am, fl=fl):
+                        C = x.C
+                        nblk = min(x.N * x.H, 2048)
+                        part = self.f32(pre + ':dpartial', (nblk, 2, C))
+                        dsum = self.f32(pre + ':dsum', (2, C))
+                        flt = fl | (ir.F_TRAIN if self.train else 0)
+                        ops.append(Op(ir.OP_BN_POOL_BWD_REDUCE, buf=dict(dy=dy.s, argmax=am, x=x.s, coef=coef, partial=part), dim=dict(d, nblk=nblk), flags=flt, note=pre))
+                        dg, db = self.grad(pre + '.weight', (C,)), self.grad(pre + '.bias', (C,))
+                        ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=dsum, dgamma=dg, dbeta=db), dim=dict(nblk=nblk, C=C), note=pre))
+                        self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
+                        dx = self.act(pre + ':dx', x.N, x.H, x.W, C)
+                        ops.append(Op(ir.OP_BN_POOL_BWD_APPLY, buf=dict(dy=dy.s, argmax=am, x=x.s, coef=coef, dsum=dsum, dx=dx.s), dim=dict(d, count=x.M), flags=flt, note=pre))
+                        return dx
+                    self._back.append(norm_pool_back)
+                    cur = y
+                    idx += 3 if relu else 2
+                    continue
                 coef = self.bn_coef(cur, pre)
                 out, _ = self.bn_apply(cur, coef, pre + ':out', relu=relu)
                 self._tail_bn[out.s] = dict(x=cur, mask=out if relu else None, coef=coef, p=0.0)

@@ -181,6 +181,33 @@ class NumpyPlan:
             if op.buf.get('argmax', -1) >= 0:
                 # window-local flat index r*k+s of the FIRST maximum among the in-bounds taps (padding is -inf)
                 put('argmax', arg.astype(np.uint8))
+        elif k == ir.OP_BN_POOL_FWD:                  # maxpool([relu](bn(x))) without storing the normalised activation
+            coef = B('coef')
+            a = B('x') * coef[0] + coef[1]
+            if op.flags & ir.F_RELU:
+                a = np.maximum(a, 0)
+            y, arg = ops.maxpool_fwd(a, d['k'], d['stride'], d['pad'])
+            put('y', y)
+            if op.buf.get('argmax', -1) >= 0:
+                put('argmax', arg.astype(np.uint8))
+        elif k in (ir.OP_BN_POOL_BWD_REDUCE, ir.OP_BN_POOL_BWD_APPLY):
+            coef = B('coef')
+            g = ops.maxpool_bwd(B('dy'), B('argmax').astype(np.int64), d['k'], d['stride'], d['pad'], d['H'], d['W'])
+            if op.flags & ir.F_RELU:
+                g = g * ((B('x') * coef[0] + coef[1]) > 0)
+            xhat = (B('x') - coef[2]) * coef[3]
+            C = d['C']
+            if k == ir.OP_BN_POOL_BWD_REDUCE:
+                nblk, rows_total = d['nblk'], d['N'] * d['H']
+                gm, xm = g.reshape(rows_total, -1, C), xhat.reshape(rows_total, -1, C)
+                part = np.zeros((nblk, 2, C), dtype=self.dtype)
+                for b in range(nblk):                     # workgroup b walks image rows b, b + nblk, ...
+                    part[b, 0] = gm[b::nblk].sum((0, 1))
+                    part[b, 1] = (gm[b::nblk] * xm[b::nblk]).sum((0, 1))
+                put('partial', part)
+            else:
+                dsum = B('dsum')
+                put('dx', coef[0] * (g - dsum[0] / d['count'] - xhat * (dsum[1] / d['count'])) if op.flags & ir.F_TRAIN else coef[0] * g)
         elif k == ir.OP_MAXPOOL_BWD:
             put('dx', ops.maxpool_bwd(B('dy'), B('argmax').astype(np.int64), d['k'], d['stride'], d['pad'], d['H'], d['W']))
         elif k == ir.OP_POOL_FC_FWD:

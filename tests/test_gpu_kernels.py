@@ -399,3 +399,50 @@ def test_deferred_slab_sums_equal_the_immediate_reduction_bit_for_bit():
         torch.cuda.synchronize()
         for a_, b_ in zip(want, got):
             assert torch.equal(a_, b_) and float(a_.abs().max()) > 1.0
+
+
+@pytest.mark.parametrize('fp32', DT)
+@pytest.mark.parametrize('shape', [(3, 12, 12, 32, 3, 2, 1), (2, 9, 7, 64, 3, 2, 1), (2, 8, 8, 16, 2, 2, 0)])
+def test_bn_relu_maxpool_fused(shape, fp32):
+    """BN_POOL_FWD / BN_POOL_BWD_REDUCE / BN_POOL_BWD_APPLY (the "n a mp" stem in one pass each way) against the interpreter's
+    composition of bn-apply, relu, maxpool and their backward, AND against the unfused op chain on the device (same pooled output and
+    argmax bit for bit: the fused forward rounds the normalised value to the compute dtype before comparing, as the stored tensor would be)."""
+    h = H()
+    N, Hh, W, C, k, st, pd = shape
+    P, Q = (Hh + 2 * pd - k) // st + 1, (W + 2 * pd - k) // st + 1
+    M = N * Hh * W
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, Hh, W, C)); coef = b.slot('coef', (4, C), 'f32')
+    y = b.slot('y', (N, P, Q, C)); am = b.slot('am', (N, P, Q, C), 'u8', role='u8')
+    a2 = b.slot('a2', (N, Hh, W, C)); y2 = b.slot('y2', (N, P, Q, C)); am2 = b.slot('am2', (N, P, Q, C), 'u8', role='u8')
+    dy = b.slot('dy', (N, P, Q, C)); nblk = min(N * Hh, 5)
+    part = b.slot('part', (nblk, 2, C), 'f32'); dsum = b.slot('dsum', (2, C), 'f32'); dg = b.slot('dg', (C,), 'f32'); db = b.slot('db', (C,), 'f32')
+    dx = b.slot('dx', (N, Hh, W, C))
+    da2 = b.slot('da2', (N, Hh, W, C)); part2 = b.slot('part2', (nblk, 2, C), 'f32'); dsum2 = b.slot('dsum2', (2, C), 'f32')
+    dg2 = b.slot('dg2', (C,), 'f32'); db2 = b.slot('db2', (C,), 'f32'); dx2 = b.slot('dx2', (N, Hh, W, C))
+    dpool = dict(N=N, H=Hh, W=W, C=C, k=k, stride=st, pad=pd)
+    fl = ir.F_RELU | ir.F_TRAIN
+    b.op(ir.OP_BN_POOL_FWD, buf=dict(x=x, coef=coef, y=y, argmax=am), dim=dpool, flags=ir.F_RELU)
+    b.op(ir.OP_BN_POOL_BWD_REDUCE, buf=dict(dy=dy, argmax=am, x=x, coef=coef, partial=part), dim=dict(dpool, nblk=nblk), flags=fl)
+    b.op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=dsum, dgamma=dg, dbeta=db), dim=dict(nblk=nblk, C=C))
+    b.op(ir.OP_BN_POOL_BWD_APPLY, buf=dict(dy=dy, argmax=am, x=x, coef=coef, dsum=dsum, dx=dx), dim=dict(dpool, count=M), flags=fl)
+    # the unfused chain on the same inputs
+    b.op(ir.OP_BN_APPLY, buf=dict(x=x, coef=coef, res=-1, out=a2), dim=dict(N=N, H=Hh, W=W, C=C, res_mode=0, res_C=0), fp=dict(p=0.0), flags=ir.F_RELU)
+    b.op(ir.OP_MAXPOOL_FWD, buf=dict(x=a2, y=y2, argmax=am2), dim=dpool)
+    b.op(ir.OP_MAXPOOL_BWD, buf=dict(dy=dy, argmax=am2, dx=da2), dim=dpool)
+    b.op(ir.OP_BN_BWD_REDUCE, buf=dict(dout=da2, x=x, mask=-1, coef=coef, partial=part2), dim=dict(M=M, C=C, nblk=nblk), fp=dict(gscale=1.0, p=0.0),
+         flags=fl | ir.F_MASK_RECOMPUTE)
+    b.op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part2, dsum=dsum2, dgamma=dg2, dbeta=db2), dim=dict(nblk=nblk, C=C))
+    b.op(ir.OP_BN_BWD_APPLY, buf=dict(dout=da2, x=x, mask=-1, coef=coef, dsum=dsum2, add=-1, dx=dx2, g_out=-1),
+         dim=dict(N=N, H=Hh, W=W, C=C, add_mode=0, add_C=0, count=M), fp=dict(gscale=1.0, p=0.0), flags=fl | ir.F_MASK_RECOMPUTE)
+    plan = b.plan(fp32)
+    xv = fill((N, Hh, W, C), 51)
+    cv = np.stack([np.abs(fill((C,), 52)) + 0.5, fill((C,), 53, 0.3), fill((C,), 54, 0.2), np.abs(fill((C,), 55)) + 0.7])
+    hip, ref = h.run_both(plan, dict(x=xv, coef=cv, dy=fill((N, P, Q, C), 56)), fp32)
+    tol = TOL[fp32]
+    assert h.max_rel(hip['y'], ref['y']) < tol
+    assert np.array_equal(hip['y'], hip['y2']) and np.array_equal(hip['am'], hip['am2'])          # fused == unfused, bit for bit
+    for a_, b_ in (('dsum', 'dsum2'), ('dg', 'dg2'), ('db', 'db2'), ('dx', 'dx2')):
+        assert h.max_rel(hip[a_], hip[b_]) < 1e-5 if fp32 else h.max_rel(hip[a_], hip[b_]) < 2e-2, a_
+    if fp32:       # in 16 bits a window's winner can differ from the float64 interpreter's after rounding (near-ties): the device-side unfused chain above is the reference there
+        assert h.max_rel(hip['dsum'], ref['dsum']) < tol and h.max_rel(hip['dx'], ref['dx']) < tol
