@@ -471,38 +471,152 @@ __global__ __launch_bounds__(NT) void fc_dgrad_kernel(const float* __restrict__ 
   }
 }
 
+// ---- wide classifier heads (ImageNet: O = 1000, C = 2048): the three products above as one LDS-tiled fp32 GEMM --------------------
+// D[m][n] = sum_k A(m, k) * B(n, k), 64 x 64 tile per workgroup, 4 x 4 per thread, 16-deep k steps through LDS with a register prefetch
+// of the next step.  AK / BK: the operand is k-contiguous (row stride ld over m / n) or m- / n-contiguous (row stride ld over k).
+// The wave-per-output kernels above re-read an operand per output (4 GB of L2 traffic for 256 x 1000 x 2048) and stay for O < 128.
+constexpr int FG_T = 64, FG_K = 16, FG_LD = FG_T + 4;
+template <bool KC>
+__device__ inline void fg_load(const float* __restrict__ p, int ld, int t0, int k0, int TD, int K, float (&r)[4]) {
+  if constexpr (KC) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int k = k0 + (threadIdx.x & 15), t = t0 + (threadIdx.x >> 4) + 16 * i;
+      r[i] = (t < TD && k < K) ? p[(size_t)t * ld + k] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int t = t0 + (threadIdx.x & 63), k = k0 + (threadIdx.x >> 6) + 4 * i;
+      r[i] = (t < TD && k < K) ? p[(size_t)k * ld + t] : 0.f;
+    }
+  }
+}
+template <bool KC>
+__device__ inline void fg_store(float (*sm)[FG_LD], const float (&r)[4]) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    if constexpr (KC) sm[threadIdx.x & 15][(threadIdx.x >> 4) + 16 * i] = r[i];
+    else sm[(threadIdx.x >> 6) + 4 * i][threadIdx.x & 63] = r[i];
+  }
+}
+template <typename T> struct alignas(sizeof(T) * 4) Quad { T e[4]; };
+// MODE 0: logits[m][n] = D + bias[n]          (A = feat [N][C], B = W [O][C]; M = batch, N = O, K = C)
+// MODE 1: dx[m][p][n] = D / HW for all p      (A = dl [N][O],  B = W [O][C] n-contiguous; M = batch, N = C, K = O)
+// MODE 2: dw[m][n] (+)= D, db[m] (+)= sum_k A (A = dl m-contiguous, B = feat n-contiguous; M = O, N = C, K = batch)
+template <typename T, int MODE, bool AK, bool BK>
+__global__ __launch_bounds__(NT) void fc_gemm_kernel(const float* __restrict__ A, const float* __restrict__ B, int M, int N, int K, int lda, int ldb,
+                                                     void* __restrict__ out, const float* __restrict__ bias, float* __restrict__ db, int HW, int accum) {
+  __shared__ float As[FG_K][FG_LD], Bs[FG_K][FG_LD];
+  const int m0 = blockIdx.y * FG_T, n0 = blockIdx.x * FG_T;
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  float acc[4][4] = {};
+  float ra[4], rb[4];
+  fg_load<AK>(A, lda, m0, 0, M, K, ra);
+  fg_load<BK>(B, ldb, n0, 0, N, K, rb);
+  for (int k0 = 0; k0 < K; k0 += FG_K) {
+    __syncthreads();
+    fg_store<AK>(As, ra);
+    fg_store<BK>(Bs, rb);
+    __syncthreads();
+    if (k0 + FG_K < K) {
+      fg_load<AK>(A, lda, m0, k0 + FG_K, M, K, ra);
+      fg_load<BK>(B, ldb, n0, k0 + FG_K, N, K, rb);
+    }
+#pragma unroll
+    for (int k = 0; k < FG_K; ++k) {
+      const float4 a = *reinterpret_cast<const float4*>(&As[k][ty * 4]);
+      const float4 b = *reinterpret_cast<const float4*>(&Bs[k][tx * 4]);
+      const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], bv[j], acc[i][j]);
+    }
+  }
+  const int n = n0 + tx * 4;                    // N % 4 == 0 (checked by the launcher): a thread's four columns are all in or all out
+  if (n < N) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + ty * 4 + i;
+      if (m >= M) continue;
+      if constexpr (MODE == 0) {
+        float* o = reinterpret_cast<float*>(out) + (size_t)m * N + n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = acc[i][j] + bias[n + j];
+      } else if constexpr (MODE == 1) {
+        Quad<T> q;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q.e[j] = Elem<T>::from_f(acc[i][j] / (float)HW);
+        T* o = reinterpret_cast<T*>(out) + (size_t)m * HW * N + n;
+        for (int p = 0; p < HW; ++p) *reinterpret_cast<Quad<T>*>(o + (size_t)p * N) = q;
+      } else {
+        float* o = reinterpret_cast<float*>(out) + (size_t)m * N + n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = accum ? o[j] + acc[i][j] : acc[i][j];
+      }
+    }
+  }
+  if constexpr (MODE == 2) {
+    if (blockIdx.x == 0 && threadIdx.x < FG_T && m0 + (int)threadIdx.x < M) {      // db[o] = sum_n dl[n][o], rows of A in order
+      const int m = m0 + threadIdx.x;
+      float sb = 0.f;
+      for (int k = 0; k < K; ++k) sb += A[(size_t)k * lda + m];
+      db[m] = accum ? db[m] + sb : sb;
+    }
+  }
+}
+static inline bool fc_wide(int C, int O) { return O >= 128 && C % 4 == 0; }   // CIFAR heads (O = 10, 100) are a few microseconds either way
+
 // ---- softmax cross-entropy, top-1 / top-5 error counts, dlogits (single block: N is a batch, a few hundred rows) ----
 // rank rule for ties (torch.topk leaves it implementation-defined): an entry outranks the label iff it is strictly
 // greater, or equal with a lower index.
-__global__ __launch_bounds__(NT) void softmax_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, float* __restrict__ out3,
-                                                        float* __restrict__ dlogits, int N, int O, float scale, const float* __restrict__ scale_dev) {
-  __shared__ float red[3][NT];
+constexpr int SM_NT = 1024, SM_NW = SM_NT / 64;
+template <typename V> __device__ inline V wave_all(V v, V (*f)(V, V)) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = f(v, __shfl_xor(v, off, 64));
+  return v;
+}
+__device__ inline float f_add(float a, float b) { return a + b; }
+__device__ inline float f_max(float a, float b) { return fmaxf(a, b); }
+__device__ inline int i_add(int a, int b) { return a + b; }
+// one workgroup of 16 waves, a wave per row (lanes stride the classes: coalesced; a row of 1000 logits is read from L1 after the first
+// pass); sums over rows stay in one workgroup, in a fixed order, so the three outputs are deterministic
+__global__ __launch_bounds__(SM_NT) void softmax_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, float* __restrict__ out3,
+                                                           float* __restrict__ dlogits, int N, int O, float scale, const float* __restrict__ scale_dev) {
+  __shared__ float red[3][SM_NW];
   if (scale_dev) scale *= scale_dev[0];          // loss scale (AMP) / upstream gradient of the loss, a device scalar: no host sync
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float nll = 0.f, e1 = 0.f, e5 = 0.f;
-  for (int n = threadIdx.x; n < N; n += NT) {
+  for (int n = wave; n < N; n += SM_NW) {
     const float* row = logits + (size_t)n * O;
     const int lab = (int)labels[n];
-    float mx = -FLT_MAX;
-    for (int o = 0; o < O; ++o) mx = fmaxf(mx, row[o]);
-    float se = 0.f;
-    for (int o = 0; o < O; ++o) se += expf(row[o] - mx);
-    const float lse = logf(se);
     const float zl = row[lab];
-    nll += lse - (zl - mx);
+    float mx = -FLT_MAX;
+    for (int o = lane; o < O; o += 64) mx = fmaxf(mx, row[o]);
+    mx = wave_all(mx, f_max);
+    float se = 0.f;
     int ahead = 0;
-    for (int o = 0; o < O; ++o) ahead += (row[o] > zl) || (row[o] == zl && o < lab);
+    for (int o = lane; o < O; o += 64) {
+      const float z = row[o];
+      se += expf(z - mx);
+      ahead += (z > zl) || (z == zl && o < lab);
+    }
+    se = wave_all(se, f_add);
+    ahead = wave_all(ahead, i_add);
+    nll += logf(se) - (zl - mx);
     e1 += ahead >= 1 ? 1.f : 0.f;
     e5 += ahead >= (O < 5 ? O : 5) ? 1.f : 0.f;
     if (dlogits) {
       const float inv = 1.f / se;
-      for (int o = 0; o < O; ++o) dlogits[(size_t)n * O + o] = (expf(row[o] - mx) * inv - (o == lab ? 1.f : 0.f)) * scale;
+      for (int o = lane; o < O; o += 64) dlogits[(size_t)n * O + o] = (expf(row[o] - mx) * inv - (o == lab ? 1.f : 0.f)) * scale;
     }
   }
-  red[0][threadIdx.x] = nll; red[1][threadIdx.x] = e1; red[2][threadIdx.x] = e5;
+  if (lane == 0) { red[0][wave] = nll; red[1][wave] = e1; red[2][wave] = e5; }
   __syncthreads();
   if (threadIdx.x < 3) {
     float s = 0.f;
-    for (int i = 0; i < NT; ++i) s += red[threadIdx.x][i];
+    for (int i = 0; i < SM_NW; ++i) s += red[threadIdx.x][i];
     out3[threadIdx.x] = s;
   }
 }
@@ -734,7 +848,11 @@ extern "C" int rn_pool_fc_fwd(const void* x, const float* w, const float* b, flo
   RN_CHECK_ARG(RN_DTYPE_OK(dtype) && C % (dtype == RN_F32 ? 4 : 8) == 0, "rn_pool_fc_fwd: bad dtype / C=%d", C);
   RN_BY_DTYPE(dtype, hipLaunchKernelGGL((gap_kernel<T_>), dim3(N), dim3(NT), 0, as_stream(s), (const T_*)x, feat, HW, C));
   RN_CHECK_LAUNCH("gap");
-  hipLaunchKernelGGL(fc_fwd_kernel, dim3(cdiv((long)N * O * 64, NT)), dim3(NT), 0, as_stream(s), feat, w, b, logits, N, C, O);
+  if (fc_wide(C, O) && O % 4 == 0)
+    hipLaunchKernelGGL((fc_gemm_kernel<float, 0, true, true>), dim3(cdiv(O, FG_T), cdiv(N, FG_T)), dim3(NT), 0, as_stream(s), feat, w, N, O, C, C, C,
+                       (void*)logits, b, (float*)nullptr, 1, 0);
+  else
+    hipLaunchKernelGGL(fc_fwd_kernel, dim3(cdiv((long)N * O * 64, NT)), dim3(NT), 0, as_stream(s), feat, w, b, logits, N, C, O);
   RN_CHECK_LAUNCH("fc_fwd");
   return 0;
 }
@@ -743,11 +861,21 @@ extern "C" int rn_pool_fc_bwd(const float* dlogits, const float* feat, const flo
                               int O, int flags, rn_stream s) {
   RN_CHECK_ARG(dlogits && feat && w && dw && db && N > 0 && HW > 0 && O > 0, "rn_pool_fc_bwd: bad argument");
   RN_CHECK_ARG(RN_DTYPE_OK(dtype) && C % (dtype == RN_F32 ? 4 : 8) == 0, "rn_pool_fc_bwd: bad dtype / C=%d", C);
-  hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv((long)O * C, NT)), dim3(NT), 0, as_stream(s), dlogits, feat, dw, db, N, C, O, (flags & RN_F_ACCUM) ? 1 : 0);
+  const bool wide = fc_wide(C, O);
+  if (wide)
+    hipLaunchKernelGGL((fc_gemm_kernel<float, 2, false, false>), dim3(cdiv(C, FG_T), cdiv(O, FG_T)), dim3(NT), 0, as_stream(s), dlogits, feat, O, C, N, O, C,
+                       (void*)dw, (const float*)nullptr, db, 1, (flags & RN_F_ACCUM) ? 1 : 0);
+  else
+    hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv((long)O * C, NT)), dim3(NT), 0, as_stream(s), dlogits, feat, dw, db, N, C, O, (flags & RN_F_ACCUM) ? 1 : 0);
   RN_CHECK_LAUNCH("fc_wgrad");
   if (!(flags & RN_F_NO_DX)) {
     RN_CHECK_ARG(dx != nullptr, "rn_pool_fc_bwd: dx is null");
-    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((fc_dgrad_kernel<T_>), dim3(N), dim3(NT), 0, as_stream(s), dlogits, w, (T_*)dx, HW, C, O));
+    if (wide) {
+      RN_BY_DTYPE(dtype, hipLaunchKernelGGL((fc_gemm_kernel<T_, 1, true, false>), dim3(cdiv(C, FG_T), cdiv(N, FG_T)), dim3(NT), 0, as_stream(s), dlogits, w, N, C,
+                                            O, O, C, dx, (const float*)nullptr, (float*)nullptr, HW, 0));
+    } else {
+      RN_BY_DTYPE(dtype, hipLaunchKernelGGL((fc_dgrad_kernel<T_>), dim3(N), dim3(NT), 0, as_stream(s), dlogits, w, (T_*)dx, HW, C, O));
+    }
     RN_CHECK_LAUNCH("fc_dgrad");
   }
   return 0;
@@ -782,7 +910,7 @@ extern "C" int rn_amp_check_unscale(float* grads, int64_t n, const float* inv_sc
 extern "C" int rn_softmax_ce(const float* logits, const int64_t* labels, float* out3, float* dlogits, int N, int O, float scale, const float* scale_dev,
                              rn_stream s) {
   RN_CHECK_ARG(logits && labels && out3 && N > 0 && O > 0, "rn_softmax_ce: bad argument");
-  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(NT), 0, as_stream(s), logits, (const long long*)labels, out3, dlogits, N, O, scale, scale_dev);
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(SM_NT), 0, as_stream(s), logits, (const long long*)labels, out3, dlogits, N, O, scale, scale_dev);
   RN_CHECK_LAUNCH("softmax_ce");
   return 0;
 }

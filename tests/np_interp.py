@@ -216,6 +216,8 @@ class NumpyPlan:
             put('logits', ops.linear_fwd(feat, B('w'), B('b')))
         elif k == ir.OP_POOL_FC_BWD:
             df, dw, db = ops.linear_bwd(B('dlogits'), B('feat'), B('w'))
+            if op.flags & ir.F_ACCUM:
+                dw = dw + B('dw').reshape(dw.shape); db = db + B('db').reshape(db.shape)
             put('dw', dw); put('db', db)
             if not (op.flags & ir.F_NO_DX):
                 dx = np.repeat(df[:, None, :] / d['HW'], d['HW'], axis=1)

@@ -309,6 +309,35 @@ def test_pools_fc_loss(fp32):
     assert h.max_rel(hip['out3'][:3], ref['out3'][:3]) < 1e-5
 
 
+@pytest.mark.parametrize('fp32', DT)
+@pytest.mark.parametrize('shape', [(70, 4, 136, 1000), (64, 1, 64, 128), (5, 49, 264, 130)])
+def test_wide_classifier_head(fp32, shape):
+    """ImageNet-sized heads (O >= 128) take the LDS-tiled fp32 GEMM for logits, dW/db and the broadcast dx, and the loss kernel reads a
+    1000-class row a wave at a time: ragged tiles in every dimension (batch, C and O off the 64 x 64 x 16 tiling), accumulate on and off."""
+    h = H()
+    N, HW, C, O = shape
+    for accum in (0, ir.F_ACCUM):
+        b = h.PlanBuilder()
+        x = b.slot('x', (N, HW, 1, C)); w = b.slot('w', (O, C), 'f32'); bias = b.slot('bias', (O,), 'f32'); feat = b.slot('feat', (N, C), 'f32')
+        logits = b.slot('logits', (N, O), 'f32'); labels = b.slot('labels', (N,), 'i64'); out3 = b.slot('out3', (4,), 'f32'); dl = b.slot('dl', (N, O), 'f32')
+        dxf = b.slot('dxf', (N, HW, 1, C)); dwf = b.slot('dwf', (O, C), 'f32'); dbf = b.slot('dbf', (O,), 'f32')
+        dfc = dict(N=N, HW=HW, C=C, O=O)
+        b.op(ir.OP_POOL_FC_FWD, buf=dict(x=x, w=w, b=bias, feat=feat, logits=logits), dim=dfc)
+        b.op(ir.OP_SOFTMAX_CE, buf=dict(logits=logits, labels=labels, out3=out3, dlogits=dl), dim=dict(N=N, O=O), fp=dict(scale=1.0 / N))
+        b.op(ir.OP_POOL_FC_BWD, buf=dict(dlogits=dl, feat=feat, w=w, dx=dxf, dw=dwf, db=dbf), dim=dfc, flags=accum)
+        plan = b.plan(fp32)
+        rng = np.random.default_rng(7)
+        wv = fill((O, C), 43, 0.3)
+        labs = rng.integers(0, O, N)
+        xv = fill((N, HW, 1, C), 41)
+        hip, ref = h.run_both(plan, dict(x=xv, w=wv, bias=fill((O,), 44, 0.1), labels=labs, dwf=fill((O, C), 45), dbf=fill((O,), 46)), fp32)
+        for name in ('feat', 'logits', 'dl', 'dwf', 'dbf'):
+            assert h.max_rel(hip[name], ref[name]) < 2e-5, (name, accum)
+        assert h.max_rel(hip['dxf'], ref['dxf']) < TOL[fp32], accum
+        assert h.max_rel(hip['out3'][:1], ref['out3'][:1]) < 1e-5
+        assert (hip['out3'][1:3] == ref['out3'][1:3]).all()
+
+
 def test_softmax_ce_matches_golden(golden):
     """metrics.py:10-29 pinned by G6 (no-tie rows): loss, top-1/top-5, dlogits."""
     h = H()
