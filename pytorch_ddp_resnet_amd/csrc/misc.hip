@@ -5,6 +5,8 @@
 #include <algorithm>
 #include <float.h>
 
+extern int g_rn_variant;   // conv_igemm.hip (rn_set_variant): 1 << 25 = per-pixel gather in the fused stem backward (A/B)
+
 namespace {
 
 constexpr int NT = 256;
@@ -280,90 +282,42 @@ __global__ __launch_bounds__(NT) void bn_pool_fwd_kernel(const T* __restrict__ x
 // thread keeps ONE channel chunk).  g = [x * scale + shift > 0] * sum of dy over the windows whose argmax is this element.
 // APPLY 0: partial[blockIdx][2][C] = (sum g, sum g * xhat);   APPLY 1: dx = scale * (g - dsum0 / count - xhat * dsum1 / count)
 template <typename T, int APPLY>
-__global__ __launch_bounds__(NT) void bn_pool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx, const T* __restrict__ x,
-                                                         const float* __restrict__ coef, const float* __restrict__ dsum, float* __restrict__ partial,
-                                                         T* __restrict__ dx, int N, int H, int W, int C, int P, int Q, int k, int stride, int pad, int relu,
-                                                         int train, float inv_count) {
-  constexpr int CE = Elem<T>::CE;
-  const int CC = C / CE;
-  const int per_row = W * CC;
-  const int cg = threadIdx.x % CC;                         // fixed: NT is a multiple of CC
+struct BnPoolBack {                                         // what a thread does with one input pixel's chunk once its gathered gradient is known
+  static constexpr int CE = Elem<T>::CE;
   float sc[CE], sh[CE], mean[CE], invstd[CE], ka[CE], kb[CE], kc[CE], s0[CE], s1[CE];
+  __device__ void init(const float* __restrict__ coef, const float* __restrict__ dsum, int C, int cg, int train, float inv_count) {
 #pragma unroll
-  for (int e = 0; e < CE; ++e) {
-    const int c = cg * CE + e;
-    sc[e] = coef[c]; sh[e] = coef[C + c]; mean[e] = coef[2 * C + c]; invstd[e] = coef[3 * C + c];
-    s0[e] = s1[e] = 0.f;
-    if (APPLY) {                                           // the coefficients of bn_bwd_apply_stream_kernel
-      const float m0 = train ? __fmul_rn(dsum[c], inv_count) : 0.f, m1 = train ? __fmul_rn(dsum[C + c], inv_count) : 0.f;
-      const float im1 = __fmul_rn(invstd[e], m1);
-      ka[e] = sc[e];
-      kb[e] = train ? -__fmul_rn(sc[e], im1) : 0.f;        // eval-mode BatchNorm: dx = scale * g
-      kc[e] = train ? __fmul_rn(sc[e], __fmaf_rn(im1, mean[e], -m0)) : 0.f;
+    for (int e = 0; e < CE; ++e) {
+      const int c = cg * CE + e;
+      sc[e] = coef[c]; sh[e] = coef[C + c]; mean[e] = coef[2 * C + c]; invstd[e] = coef[3 * C + c];
+      s0[e] = s1[e] = 0.f;
+      if (APPLY) {                                         // the coefficients of bn_bwd_apply_stream_kernel
+        const float m0 = train ? __fmul_rn(dsum[c], inv_count) : 0.f, m1 = train ? __fmul_rn(dsum[C + c], inv_count) : 0.f;
+        const float im1 = __fmul_rn(invstd[e], m1);
+        ka[e] = sc[e];
+        kb[e] = train ? -__fmul_rn(sc[e], im1) : 0.f;      // eval-mode BatchNorm: dx = scale * g
+        kc[e] = train ? __fmul_rn(sc[e], __fmaf_rn(im1, mean[e], -m0)) : 0.f;
+      }
     }
   }
-  for (int row = blockIdx.x; row < N * H; row += gridDim.x) {
-    const int nn = row / H, h = row - nn * H;
-    const int p_lo = max(0, (h + pad - k + stride) / stride), p_hi = min(P - 1, (h + pad) / stride);
-    for (int j = threadIdx.x; j < per_row; j += NT) {
-      const int w = j / CC;
-      const int q_lo = max(0, (w + pad - k + stride) / stride), q_hi = min(Q - 1, (w + pad) / stride);
-      const size_t xo = ((size_t)row * W + w) * C + cg * CE;
-      const Chunk<T> cx = load_chunk<T>(x + xo);
-      float g[CE];
+  __device__ void pixel(const Chunk<T>& cx, const float (&g)[CE], int relu, T* __restrict__ dx_at) {
+    Chunk<T> co;
 #pragma unroll
-      for (int e = 0; e < CE; ++e) g[e] = 0.f;
-      auto fetch = [&](int p, int q, Chunk<T>& d, unsigned char* ib) {
-        const size_t o = (((size_t)nn * P + p) * Q + q) * C + cg * CE;
-        d = load_chunk<T>(dy + o);
-        if constexpr (CE == 8) *reinterpret_cast<uint2*>(ib) = *reinterpret_cast<const uint2*>(idx + o);
-        else *reinterpret_cast<unsigned*>(ib) = *reinterpret_cast<const unsigned*>(idx + o);
-      };
-      auto take = [&](int p, int q, const Chunk<T>& d, const unsigned char* ib) {
-        const unsigned me = (unsigned)((h - (p * stride - pad)) * k + (w - (q * stride - pad)));
-#pragma unroll
-        for (int e = 0; e < CE; ++e) if (ib[e] == me) g[e] += Elem<T>::to_f(d.e[e]);
-      };
-      if (p_hi - p_lo <= 1 && q_hi - q_lo <= 1) {            // <= 2 x 2 windows (3x3 stride 2): every load is issued before the first use
-        Chunk<T> d[4];
-        __attribute__((aligned(8))) unsigned char ib[4][CE];
-        bool ok[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int p = p_lo + (u >> 1), q = q_lo + (u & 1);
-          ok[u] = p <= p_hi && q <= q_hi;
-          if (ok[u]) fetch(p, q, d[u], ib[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-          if (ok[u]) take(p_lo + (u >> 1), q_lo + (u & 1), d[u], ib[u]);
+    for (int e = 0; e < CE; ++e) {
+      const float xv = Elem<T>::to_f(cx.e[e]);
+      // maxpool_bwd stores its output in the compute dtype before bn_bwd reads it: the same rounding here
+      float gg = Elem<T>::to_f(Elem<T>::from_f(g[e]));
+      if (relu && !(fmaf(xv, sc[e], sh[e]) > 0.f)) gg = 0.f;
+      if (APPLY) {
+        co.e[e] = Elem<T>::from_f(__fmaf_rn(ka[e], gg, __fmaf_rn(kb[e], xv, kc[e])));
       } else {
-        for (int p = p_lo; p <= p_hi; ++p)
-          for (int q = q_lo; q <= q_hi; ++q) {
-            Chunk<T> d;
-            __attribute__((aligned(8))) unsigned char ib[CE];
-            fetch(p, q, d, ib);
-            take(p, q, d, ib);
-          }
+        const float xh = (xv - mean[e]) * invstd[e];
+        s0[e] += gg; s1[e] += gg * xh;
       }
-      Chunk<T> co;
-#pragma unroll
-      for (int e = 0; e < CE; ++e) {
-        const float xv = Elem<T>::to_f(cx.e[e]);
-        // maxpool_bwd stores its output in the compute dtype before bn_bwd reads it: the same rounding here
-        float gg = Elem<T>::to_f(Elem<T>::from_f(g[e]));
-        if (relu && !(fmaf(xv, sc[e], sh[e]) > 0.f)) gg = 0.f;
-        if (APPLY) {
-          co.e[e] = Elem<T>::from_f(__fmaf_rn(ka[e], gg, __fmaf_rn(kb[e], xv, kc[e])));
-        } else {
-          const float xh = (xv - mean[e]) * invstd[e];
-          s0[e] += gg; s1[e] += gg * xh;
-        }
-      }
-      if (APPLY) store_chunk<T>(dx + xo, co);
     }
+    if (APPLY) store_chunk<T>(dx_at, co);
   }
-  if (!APPLY) {                                            // the workgroup's row of partial sums: lanes of one channel chunk through LDS
+  __device__ void flush(float* __restrict__ partial, int C, int CC, int cg) {      // the workgroup's row of partial sums: lanes of one chunk through LDS
     __shared__ float red[2][NT][CE + 1];
 #pragma unroll
     for (int e = 0; e < CE; ++e) { red[0][threadIdx.x][e] = s0[e]; red[1][threadIdx.x][e] = s1[e]; }
@@ -381,6 +335,103 @@ __global__ __launch_bounds__(NT) void bn_pool_bwd_kernel(const T* __restrict__ d
       for (int e = 0; e < CE; ++e) { p0[e] = t0[e]; p0[C + e] = t1[e]; }
     }
   }
+};
+template <typename T> struct PoolTap {                      // a pooled position's gradient chunk and argmax bytes
+  static constexpr int CE = Elem<T>::CE;
+  Chunk<T> d;
+  __attribute__((aligned(8))) unsigned char ib[CE];
+  __device__ void fetch(const T* __restrict__ dy, const unsigned char* __restrict__ idx, size_t o) {
+    d = load_chunk<T>(dy + o);
+    if constexpr (CE == 8) *reinterpret_cast<uint2*>(ib) = *reinterpret_cast<const uint2*>(idx + o);
+    else *reinterpret_cast<unsigned*>(ib) = *reinterpret_cast<const unsigned*>(idx + o);
+  }
+  __device__ void take(unsigned me, float (&g)[CE]) const {
+#pragma unroll
+    for (int e = 0; e < CE; ++e) if (ib[e] == me) g[e] += Elem<T>::to_f(d.e[e]);
+  }
+};
+
+template <typename T, int APPLY>
+__global__ __launch_bounds__(NT) void bn_pool_bwd_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx, const T* __restrict__ x,
+                                                         const float* __restrict__ coef, const float* __restrict__ dsum, float* __restrict__ partial,
+                                                         T* __restrict__ dx, int N, int H, int W, int C, int P, int Q, int k, int stride, int pad, int relu,
+                                                         int train, float inv_count) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE;
+  const int per_row = W * CC;
+  const int cg = threadIdx.x % CC;                         // fixed: NT is a multiple of CC
+  BnPoolBack<T, APPLY> bk;
+  bk.init(coef, dsum, C, cg, train, inv_count);
+  for (int row = blockIdx.x; row < N * H; row += gridDim.x) {
+    const int nn = row / H, h = row - nn * H;
+    const int p_lo = max(0, (h + pad - k + stride) / stride), p_hi = min(P - 1, (h + pad) / stride);
+    for (int j = threadIdx.x; j < per_row; j += NT) {
+      const int w = j / CC;
+      const int q_lo = max(0, (w + pad - k + stride) / stride), q_hi = min(Q - 1, (w + pad) / stride);
+      const size_t xo = ((size_t)row * W + w) * C + cg * CE;
+      const Chunk<T> cx = load_chunk<T>(x + xo);
+      float g[CE];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) g[e] = 0.f;
+      for (int p = p_lo; p <= p_hi; ++p)
+        for (int q = q_lo; q <= q_hi; ++q) {
+          PoolTap<T> t;
+          t.fetch(dy, idx, (((size_t)nn * P + p) * Q + q) * C + cg * CE);
+          t.take((unsigned)((h - (p * stride - pad)) * k + (w - (q * stride - pad))), g);
+        }
+      bk.pixel(cx, g, relu, dx + xo);
+    }
+  }
+  if (!APPLY) bk.flush(partial, C, CC, cg);
+}
+
+// the geometry every shipped spec has ("mp3,2,1" on an even map): a thread owns the 2 x 2 input pixels (2a..2a+1, 2b..2b+1) of one channel
+// chunk, which are covered by exactly the pooled positions (a..a+1, b..b+1) -- 4 gradient + 4 argmax loads for 4 pixels where the
+// per-pixel gather issues up to 4 for one, and all 12 loads are in flight before the first use.  A pixel adds its windows in the same
+// order (p major, q minor) as the per-pixel kernel, so both give the same bits.
+template <typename T, int APPLY>
+__global__ __launch_bounds__(NT) void bn_pool_bwd_quad_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx, const T* __restrict__ x,
+                                                              const float* __restrict__ coef, const float* __restrict__ dsum, float* __restrict__ partial,
+                                                              T* __restrict__ dx, int N, int H, int W, int C, int relu, int train, float inv_count) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE, P = H >> 1, Q = W >> 1;
+  const int per_row = Q * CC;
+  const int cg = threadIdx.x % CC;
+  BnPoolBack<T, APPLY> bk;
+  bk.init(coef, dsum, C, cg, train, inv_count);
+  for (int row = blockIdx.x; row < N * P; row += gridDim.x) {
+    const int nn = row / P, a = row - nn * P;
+    const bool down = a + 1 < P;
+    for (int j = threadIdx.x; j < per_row; j += NT) {
+      const int b = j / CC;
+      const bool right = b + 1 < Q;
+      const size_t x00 = (((size_t)nn * H + 2 * a) * W + 2 * b) * C + cg * CE, x10 = x00 + (size_t)W * C;
+      const size_t o00 = ((size_t)row * Q + b) * C + cg * CE, o10 = o00 + (size_t)Q * C;
+      Chunk<T> cx[4] = {load_chunk<T>(x + x00), load_chunk<T>(x + x00 + C), load_chunk<T>(x + x10), load_chunk<T>(x + x10 + C)};
+      PoolTap<T> t[4];
+      t[0].fetch(dy, idx, o00);
+      if (right) t[1].fetch(dy, idx, o00 + C);
+      if (down) t[2].fetch(dy, idx, o10);
+      if (down && right) t[3].fetch(dy, idx, o10 + C);
+      float g[4][CE];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < CE; ++e) g[u][e] = 0.f;
+      // position of a pixel inside a 3 x 3 window whose top-left is (2p - 1, 2q - 1): row 2a -> r = 1 in p = a; row 2a + 1 -> r = 2 in a, r = 0 in a + 1
+      t[0].take(4, g[0]);
+      t[0].take(5, g[1]); if (right) t[1].take(3, g[1]);
+      t[0].take(7, g[2]); if (down) t[2].take(1, g[2]);
+      t[0].take(8, g[3]); if (right) t[1].take(6, g[3]);
+      if (down) t[2].take(2, g[3]);
+      if (down && right) t[3].take(0, g[3]);
+      bk.pixel(cx[0], g[0], relu, dx + x00);
+      bk.pixel(cx[1], g[1], relu, dx + x00 + C);
+      bk.pixel(cx[2], g[2], relu, dx + x10);
+      bk.pixel(cx[3], g[3], relu, dx + x10 + C);
+    }
+  }
+  if (!APPLY) bk.flush(partial, C, CC, cg);
 }
 
 // ---- global average pool: feat[n][c] = mean_{hw} x[n][hw][c] ------------------------------------------------
@@ -580,27 +631,47 @@ template <typename V> __device__ inline V wave_all(V v, V (*f)(V, V)) {
 __device__ inline float f_add(float a, float b) { return a + b; }
 __device__ inline float f_max(float a, float b) { return fmaxf(a, b); }
 __device__ inline int i_add(int a, int b) { return a + b; }
-// one workgroup of 16 waves, a wave per row (lanes stride the classes: coalesced; a row of 1000 logits is read from L1 after the first
-// pass); sums over rows stay in one workgroup, in a fixed order, so the three outputs are deterministic
+// one workgroup of 16 waves, a wave per row, lanes stride the classes (coalesced).  Rows of up to 1024 classes are held in registers: one
+// batch of 16 independent loads, then the maximum, the exponentials, the rank of the label and dlogits all come from registers.  The sums
+// over rows stay in one workgroup, in a fixed order, so the three outputs are deterministic.
+constexpr int SM_R = 16;
 __global__ __launch_bounds__(SM_NT) void softmax_ce_kernel(const float* __restrict__ logits, const long long* __restrict__ labels, float* __restrict__ out3,
                                                            float* __restrict__ dlogits, int N, int O, float scale, const float* __restrict__ scale_dev) {
   __shared__ float red[3][SM_NW];
   if (scale_dev) scale *= scale_dev[0];          // loss scale (AMP) / upstream gradient of the loss, a device scalar: no host sync
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool in_regs = O <= 64 * SM_R;
   float nll = 0.f, e1 = 0.f, e5 = 0.f;
   for (int n = wave; n < N; n += SM_NW) {
     const float* row = logits + (size_t)n * O;
     const int lab = (int)labels[n];
     const float zl = row[lab];
-    float mx = -FLT_MAX;
-    for (int o = lane; o < O; o += 64) mx = fmaxf(mx, row[o]);
-    mx = wave_all(mx, f_max);
-    float se = 0.f;
+    float z[SM_R];
+    float mx = -FLT_MAX, se = 0.f;
     int ahead = 0;
-    for (int o = lane; o < O; o += 64) {
-      const float z = row[o];
-      se += expf(z - mx);
-      ahead += (z > zl) || (z == zl && o < lab);
+    if (in_regs) {
+#pragma unroll
+      for (int i = 0; i < SM_R; ++i) { const int o = lane + 64 * i; z[i] = o < O ? row[o] : -FLT_MAX; }
+#pragma unroll
+      for (int i = 0; i < SM_R; ++i) mx = fmaxf(mx, z[i]);
+      mx = wave_all(mx, f_max);
+#pragma unroll
+      for (int i = 0; i < SM_R; ++i) {
+        const int o = lane + 64 * i;
+        if (o < O) {
+          ahead += (z[i] > zl) || (z[i] == zl && o < lab);
+          z[i] = expf(z[i] - mx);
+          se += z[i];
+        }
+      }
+    } else {
+      for (int o = lane; o < O; o += 64) mx = fmaxf(mx, row[o]);
+      mx = wave_all(mx, f_max);
+      for (int o = lane; o < O; o += 64) {
+        const float v = row[o];
+        se += expf(v - mx);
+        ahead += (v > zl) || (v == zl && o < lab);
+      }
     }
     se = wave_all(se, f_add);
     ahead = wave_all(ahead, i_add);
@@ -609,7 +680,15 @@ __global__ __launch_bounds__(SM_NT) void softmax_ce_kernel(const float* __restri
     e5 += ahead >= (O < 5 ? O : 5) ? 1.f : 0.f;
     if (dlogits) {
       const float inv = 1.f / se;
-      for (int o = lane; o < O; o += 64) dlogits[(size_t)n * O + o] = (expf(row[o] - mx) * inv - (o == lab ? 1.f : 0.f)) * scale;
+      if (in_regs) {
+#pragma unroll
+        for (int i = 0; i < SM_R; ++i) {
+          const int o = lane + 64 * i;
+          if (o < O) dlogits[(size_t)n * O + o] = (z[i] * inv - (o == lab ? 1.f : 0.f)) * scale;
+        }
+      } else {
+        for (int o = lane; o < O; o += 64) dlogits[(size_t)n * O + o] = (expf(row[o] - mx) * inv - (o == lab ? 1.f : 0.f)) * scale;
+      }
     }
   }
   if (lane == 0) { red[0][wave] = nll; red[1][wave] = e1; red[2][wave] = e5; }
@@ -819,16 +898,28 @@ static int bn_pool_bwd(const void* dy, const unsigned char* argmax, const void* 
   RN_CHECK_ARG(dy && argmax && x && coef && NT % cc == 0, "%s: bad argument (C / chunk = %d must divide %d)", who, cc, NT);
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
   const int relu = (flags & RN_F_RELU) ? 1 : 0;
+  const bool quad = k == 3 && stride == 2 && pad == 1 && H % 2 == 0 && W % 2 == 0 && !(g_rn_variant & (1 << 25));
   if (partial) {
     RN_CHECK_ARG(nblk > 0 && nblk <= N * H, "%s: nblk out of range", who);
-    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_kernel<T_, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, nullptr, partial,
-                                          (T_*)nullptr, N, H, W, C, P, Q, k, stride, pad, relu, 1, 0.f));
+    if (quad) {
+      RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_quad_kernel<T_, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, nullptr,
+                                            partial, (T_*)nullptr, N, H, W, C, relu, 1, 0.f));
+    } else {
+      RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_kernel<T_, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, nullptr,
+                                            partial, (T_*)nullptr, N, H, W, C, P, Q, k, stride, pad, relu, 1, 0.f));
+    }
   } else {
     const int train = (flags & RN_F_TRAIN) ? 1 : 0;
     RN_CHECK_ARG((dsum || !train) && dx && count > 0, "%s: bad argument", who);
-    const int grid = (int)std::min<long>((long)N * H, 8192);
-    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_kernel<T_, 1>), dim3(grid), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, dsum, nullptr,
-                                          (T_*)dx, N, H, W, C, P, Q, k, stride, pad, relu, train, (float)(1.0 / count)));
+    if (quad) {
+      const int grid = (int)std::min<long>((long)N * (H / 2), 8192);
+      RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_quad_kernel<T_, 1>), dim3(grid), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, dsum,
+                                            nullptr, (T_*)dx, N, H, W, C, relu, train, (float)(1.0 / count)));
+    } else {
+      const int grid = (int)std::min<long>((long)N * H, 8192);
+      RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_kernel<T_, 1>), dim3(grid), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, dsum, nullptr,
+                                            (T_*)dx, N, H, W, C, P, Q, k, stride, pad, relu, train, (float)(1.0 / count)));
+    }
   }
   RN_CHECK_LAUNCH(who);
   return 0;

@@ -431,7 +431,7 @@ def test_deferred_slab_sums_equal_the_immediate_reduction_bit_for_bit():
 
 
 @pytest.mark.parametrize('fp32', DT)
-@pytest.mark.parametrize('shape', [(3, 12, 12, 32, 3, 2, 1), (2, 9, 7, 64, 3, 2, 1), (2, 8, 8, 16, 2, 2, 0)])
+@pytest.mark.parametrize('shape', [(3, 12, 12, 32, 3, 2, 1), (2, 9, 7, 64, 3, 2, 1), (2, 8, 8, 16, 2, 2, 0), (1, 4, 6, 32, 3, 2, 1), (2, 2, 2, 8, 3, 2, 1)])
 def test_bn_relu_maxpool_fused(shape, fp32):
     """BN_POOL_FWD / BN_POOL_BWD_REDUCE / BN_POOL_BWD_APPLY (the "n a mp" stem in one pass each way) against the interpreter's
     composition of bn-apply, relu, maxpool and their backward, AND against the unfused op chain on the device (same pooled output and
