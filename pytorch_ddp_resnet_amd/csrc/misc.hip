@@ -484,20 +484,32 @@ __global__ __launch_bounds__(NT) void fc_fwd_kernel(const float* __restrict__ fe
   if (lane == 0) logits[(size_t)n * O + o] = s + b[o];
 }
 
-// dW[o][c] = sum_n dl[n][o] * feat[n][c]; db[o] = sum_n dl[n][o]   (thread per (o, c); c fastest -> coalesced)
+// dW[o][c] = sum_n dl[n][o] * feat[n][c]; db[o] = sum_n dl[n][o].  A workgroup owns 64 (o, c) outputs (c fastest -> coalesced); its four
+// waves each take a quarter of the batch, eight rows in flight at a time, and meet in LDS in wave order (a CIFAR head is 640-6400 outputs:
+// one thread per output walking the whole batch left the chip idle for 28 us, waiting on 128 dependent round trips)
 __global__ __launch_bounds__(NT) void fc_wgrad_kernel(const float* __restrict__ dl, const float* __restrict__ feat, float* __restrict__ dw,
                                                       float* __restrict__ db, int N, int C, int O, int accum) {
-  const long i = (long)blockIdx.x * NT + threadIdx.x;
-  if (i >= (long)O * C) return;
-  const int o = (int)(i / C), c = (int)(i - (long)o * C);
+  __shared__ float red[2][NT / 64][64];
+  const int lane = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const long i = (long)blockIdx.x * 64 + lane;
+  const bool live = i < (long)O * C;
+  const int o = live ? (int)(i / C) : 0, c = live ? (int)(i - (long)o * C) : 0;
+  const int per = (N + NT / 64 - 1) / (NT / 64), n_lo = part * per, n_hi = min(N, n_lo + per);
   float s = 0.f, sb = 0.f;
-  for (int n = 0; n < N; ++n) {
+#pragma unroll 8
+  for (int n = n_lo; n < n_hi; ++n) {
     const float d = dl[(size_t)n * O + o];
     s = fmaf(d, feat[(size_t)n * C + c], s);
     sb += d;
   }
-  dw[i] = accum ? dw[i] + s : s;
-  if (c == 0) db[o] = accum ? db[o] + sb : sb;
+  red[0][part][lane] = s; red[1][part][lane] = sb;
+  __syncthreads();
+  if (part == 0 && live) {
+#pragma unroll
+    for (int w = 1; w < NT / 64; ++w) { s += red[0][w][lane]; sb += red[1][w][lane]; }
+    dw[i] = accum ? dw[i] + s : s;
+    if (c == 0) db[o] = accum ? db[o] + sb : sb;
+  }
 }
 
 // dx[n][hw][c] = (sum_o dl[n][o] * W[o][c]) / HW, broadcast over hw
@@ -642,6 +654,34 @@ __global__ __launch_bounds__(SM_NT) void softmax_ce_kernel(const float* __restri
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const bool in_regs = O <= 64 * SM_R;
   float nll = 0.f, e1 = 0.f, e5 = 0.f;
+  if (O <= 32) {                                 // CIFAR heads: a row takes G = 4..32 lanes, a wave holds 64 / G rows at once
+    int G = 4;
+    while (G < O) G <<= 1;
+    const int sub = lane & (G - 1), per_wave = 64 / G;
+    for (int n0 = wave * per_wave; n0 < N; n0 += SM_NW * per_wave) {
+      const int n = n0 + lane / G;
+      const bool live = n < N, mine = live && sub < O;
+      const int lab = live ? (int)labels[n] : 0;
+      const float zl = live ? logits[(size_t)n * O + lab] : 0.f;
+      const float z = mine ? logits[(size_t)n * O + sub] : -FLT_MAX;
+      float mx = z;
+      for (int off = G >> 1; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+      const float ez = mine ? expf(z - mx) : 0.f;
+      float se = ez;
+      int ahead = mine && ((z > zl) || (z == zl && sub < lab));
+      for (int off = G >> 1; off > 0; off >>= 1) { se += __shfl_xor(se, off, 64); ahead += __shfl_xor(ahead, off, 64); }
+      if (live && sub == 0) {
+        nll += logf(se) - (zl - mx);
+        e1 += ahead >= 1 ? 1.f : 0.f;
+        e5 += ahead >= (O < 5 ? O : 5) ? 1.f : 0.f;
+      }
+      if (dlogits && mine) dlogits[(size_t)n * O + sub] = (ez / se - (sub == lab ? 1.f : 0.f)) * scale;
+    }
+    for (int off = 32; off >= G; off >>= 1) {    // the rows of a wave: only lanes with sub == 0 carry a value, and xor by a multiple of G keeps sub
+      nll += __shfl_xor(nll, off, 64); e1 += __shfl_xor(e1, off, 64); e5 += __shfl_xor(e5, off, 64);
+    }
+    N = 0;                                       // the wide loop below has nothing left
+  }
   for (int n = wave; n < N; n += SM_NW) {
     const float* row = logits + (size_t)n * O;
     const int lab = (int)labels[n];
@@ -957,7 +997,7 @@ extern "C" int rn_pool_fc_bwd(const float* dlogits, const float* feat, const flo
     hipLaunchKernelGGL((fc_gemm_kernel<float, 2, false, false>), dim3(cdiv(C, FG_T), cdiv(O, FG_T)), dim3(NT), 0, as_stream(s), dlogits, feat, O, C, N, O, C,
                        (void*)dw, (const float*)nullptr, db, 1, (flags & RN_F_ACCUM) ? 1 : 0);
   else
-    hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv((long)O * C, NT)), dim3(NT), 0, as_stream(s), dlogits, feat, dw, db, N, C, O, (flags & RN_F_ACCUM) ? 1 : 0);
+    hipLaunchKernelGGL(fc_wgrad_kernel, dim3(cdiv((long)O * C, 64)), dim3(NT), 0, as_stream(s), dlogits, feat, dw, db, N, C, O, (flags & RN_F_ACCUM) ? 1 : 0);
   RN_CHECK_LAUNCH("fc_wgrad");
   if (!(flags & RN_F_NO_DX)) {
     RN_CHECK_ARG(dx != nullptr, "rn_pool_fc_bwd: dx is null");

@@ -310,10 +310,12 @@ def test_pools_fc_loss(fp32):
 
 
 @pytest.mark.parametrize('fp32', DT)
-@pytest.mark.parametrize('shape', [(70, 4, 136, 1000), (64, 1, 64, 128), (5, 49, 264, 130)])
-def test_wide_classifier_head(fp32, shape):
+@pytest.mark.parametrize('shape', [(70, 4, 136, 1000), (64, 1, 64, 128), (5, 49, 264, 130), (130, 2, 64, 10), (37, 1, 32, 5), (33, 1, 16, 32), (9, 1, 8, 100),
+                                   (3, 1, 8, 1100)])
+def test_classifier_head_shapes(fp32, shape):
     """ImageNet-sized heads (O >= 128) take the LDS-tiled fp32 GEMM for logits, dW/db and the broadcast dx, and the loss kernel reads a
-    1000-class row a wave at a time: ragged tiles in every dimension (batch, C and O off the 64 x 64 x 16 tiling), accumulate on and off."""
+    1000-class row a wave at a time: ragged tiles in every dimension (batch, C and O off the 64 x 64 x 16 tiling), accumulate on and off.
+    CIFAR heads (O <= 32: several rows of the loss per wave; batch split over the waves of the dW kernel) and a row too long for registers."""
     h = H()
     N, HW, C, O = shape
     for accum in (0, ir.F_ACCUM):
