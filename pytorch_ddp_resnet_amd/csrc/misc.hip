@@ -229,19 +229,23 @@ __global__ __launch_bounds__(NT) void maxpool_bwd_kernel(const T* __restrict__ d
   }
 }
 
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  A pooling pass re-reads its neighbours' rows (windows overlap),
+// so give every XCD a contiguous band of the launch's work instead of every 8th piece: the re-read then hits the L2 that fetched it.
+__device__ inline int xcd_band(int b, int G) { return (G & 7) ? b : (b & 7) * (G >> 3) + (b >> 3); }
+
 // ---- BatchNorm-apply + ReLU + MaxPool as ONE pass each way (the stem of the ImageNet nets, resnet.py:111-115 + 83-87: "n a mp3,2,1").
 // Unfused, the 112x112x512 activation of WRN-50-2-B (3.3 GB at batch 256) is written by bn_apply, read by maxpool, and in the backward
 // written by maxpool_bwd, read by bn_bwd_reduce and read again by bn_bwd_apply.  Here the normalised activation and its gradient never
 // exist in memory: the forward pools relu(x * scale + shift) on the fly (each value rounded to the compute dtype BEFORE the comparison,
 // so the argmax is the one the unfused pair picks), the backward gathers the pooled gradient through the stored argmax bytes where the
 // unfused pair would read maxpool_bwd's output.
-template <typename T>
+template <typename T, int KS>                               // KS = 3: the 3 x 3 window unrolled, its nine loads issued before the first comparison
 __global__ __launch_bounds__(NT) void bn_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ coef, T* __restrict__ y, unsigned char* __restrict__ idx,
                                                          int N, int H, int W, int C, int P, int Q, int k, int stride, int pad, int relu) {
   constexpr int CE = Elem<T>::CE;
   const int CC = C / CE;
   const long n = (long)N * P * Q * CC;
-  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+  for (long i = (long)xcd_band(blockIdx.x, gridDim.x) * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
     const int cg = (int)(i % CC);
     long pix = i / CC;
     const int q = (int)(pix % Q); pix /= Q;
@@ -251,19 +255,35 @@ __global__ __launch_bounds__(NT) void bn_pool_fwd_kernel(const T* __restrict__ x
     __attribute__((aligned(8))) unsigned char am[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) { sc[e] = coef[cg * CE + e]; sh[e] = coef[C + cg * CE + e]; m[e] = -FLT_MAX; am[e] = 255; }
-    for (int r = 0; r < k; ++r) {
-      const int h = p * stride + r - pad;
-      if ((unsigned)h >= (unsigned)H) continue;
-      for (int s = 0; s < k; ++s) {
-        const int w = q * stride + s - pad;
-        if ((unsigned)w >= (unsigned)W) continue;
-        Chunk<T> c = load_chunk<T>(x + (((size_t)nn * H + h) * W + w) * C + cg * CE);
+    auto offer = [&](const Chunk<T>& c, int pos) {
 #pragma unroll
-        for (int e = 0; e < CE; ++e) {
-          float v = fmaf(Elem<T>::to_f(c.e[e]), sc[e], sh[e]);
-          if (relu) v = fmaxf(v, 0.f);
-          v = Elem<T>::to_f(Elem<T>::from_f(v));            // what bn_apply would have stored
-          if (v > m[e] || am[e] == 255) { m[e] = v; am[e] = (unsigned char)(r * k + s); }
+      for (int e = 0; e < CE; ++e) {
+        float v = fmaf(Elem<T>::to_f(c.e[e]), sc[e], sh[e]);
+        if (relu) v = fmaxf(v, 0.f);
+        v = Elem<T>::to_f(Elem<T>::from_f(v));              // what bn_apply would have stored
+        if (v > m[e] || am[e] == 255) { m[e] = v; am[e] = (unsigned char)pos; }
+      }
+    };
+    if constexpr (KS == 3) {
+      Chunk<T> c[9];
+      bool ok[9];
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int h = p * stride + t / 3 - pad, w = q * stride + t % 3 - pad;
+        ok[t] = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+        if (ok[t]) c[t] = load_chunk<T>(x + (((size_t)nn * H + h) * W + w) * C + cg * CE);
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        if (ok[t]) offer(c[t], t);
+    } else {
+      for (int r = 0; r < k; ++r) {
+        const int h = p * stride + r - pad;
+        if ((unsigned)h >= (unsigned)H) continue;
+        for (int s = 0; s < k; ++s) {
+          const int w = q * stride + s - pad;
+          if ((unsigned)w >= (unsigned)W) continue;
+          offer(load_chunk<T>(x + (((size_t)nn * H + h) * W + w) * C + cg * CE), r * k + s);
         }
       }
     }
@@ -399,7 +419,7 @@ __global__ __launch_bounds__(NT) void bn_pool_bwd_quad_kernel(const T* __restric
   const int cg = threadIdx.x % CC;
   BnPoolBack<T, APPLY> bk;
   bk.init(coef, dsum, C, cg, train, inv_count);
-  for (int row = blockIdx.x; row < N * P; row += gridDim.x) {
+  for (int row = xcd_band(blockIdx.x, gridDim.x); row < N * P; row += gridDim.x) {
     const int nn = row / P, a = row - nn * P;
     const bool down = a + 1 < P;
     for (int j = threadIdx.x; j < per_row; j += NT) {
@@ -926,8 +946,13 @@ extern "C" int rn_bn_pool_fwd(const void* x, const float* coef, void* y, unsigne
   RN_CHECK_ARG(x && coef && y && k * k < 255, "rn_bn_pool_fwd: bad argument");
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
   const long n = (long)N * P * Q * (C / (dtype == RN_F32 ? 4 : 8));
-  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_fwd_kernel<T_>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const T_*)x, coef, (T_*)y, argmax, N, H, W, C, P, Q, k,
-                                        stride, pad, (flags & RN_F_RELU) ? 1 : 0));
+  if (k == 3) {
+    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_fwd_kernel<T_, 3>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const T_*)x, coef, (T_*)y, argmax, N, H, W, C, P, Q,
+                                          k, stride, pad, (flags & RN_F_RELU) ? 1 : 0));
+  } else {
+    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_fwd_kernel<T_, 0>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const T_*)x, coef, (T_*)y, argmax, N, H, W, C, P, Q,
+                                          k, stride, pad, (flags & RN_F_RELU) ? 1 : 0));
+  }
   RN_CHECK_LAUNCH("bn_pool_fwd");
   return 0;
 }
