@@ -647,14 +647,17 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
   const int lr = lane & 31, lh = lane >> 5;
   const int arow0 = wm * (BM / WM) + lr, brow0 = wn * (BN / WN) + lr;
 
-  // prologue: tiles 0 .. NSTG-2 in flight, tile 0 landed
+  // prologue: EVERY ring slot is free, so tiles 0 .. NSTG-1 are issued before the wait for tile 0 (iteration 0 issues nothing).  Issuing
+  // tile NSTG-1 at the head of iteration 0 instead, behind that wait, exposed its latency on every workgroup: 1 us of the 8.5 us a
+  // 128 x 128 tile of a 1x1 convolution with C = 128 lives (two K steps; in-kernel stamps, WRN-50-2's 56 x 56 expansions)
 #pragma unroll
-  for (int t = 0; t < NSTG - 1; ++t)
+  for (int t = 0; t < NSTG; ++t)
     if (t < a.nk) dma_tile(t);
   stamp(a.stamps, 8);
   {
-    const int inflight = min(a.nk, NSTG - 1) - 1;      // groups allowed to stay outstanding behind tile 0
-    if (inflight >= 2) wait_vmcnt<2 * PER>(); else if (inflight == 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+    const int inflight = min(a.nk, NSTG) - 1;          // groups allowed to stay outstanding behind tile 0
+    static_assert(3 * PER < 64, "vmcnt range");
+    if (inflight >= 3) wait_vmcnt<3 * PER>(); else if (inflight == 2) wait_vmcnt<2 * PER>(); else if (inflight == 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
   }
   __builtin_amdgcn_s_barrier();
   stamp(a.stamps, 1);
@@ -662,7 +665,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
   for (int it = 0; it < a.nk; ++it) {
     const uint4* cur_s = &smem[stg * STAGE];
     int nstg = stg + (NSTG - 1); if (nstg >= NSTG) nstg -= NSTG;
-    if (it + NSTG - 1 < a.nk) dma_tile(nstg);          // ring slot read last in iteration it-1: free since the barrier
+    if (it >= 1 && it + NSTG - 1 < a.nk) dma_tile(nstg);          // ring slot read last in iteration it-1: free since the barrier
     if (a.probe_k != 1) {
     uint4 fa[2][TM], fb[2][TN];
 #pragma unroll
@@ -805,18 +808,20 @@ __global__ __launch_bounds__(512, BM >= 256 ? 1 : 2) void igemm_ws_kernel(const 
 #pragma unroll
       for (int k = 0; k < NST; ++k) walk[k].advance(a, taps);
     };
-    // ring of NSTG stages: tiles it+1 .. it+NSTG-1 are in flight while the consumers multiply tile it
+    // ring of NSTG stages: tiles it+1 .. it+NSTG-1 are in flight while the consumers multiply tile it; the whole ring is free at the
+    // start, so tile NSTG-1 is issued with the others, before the wait for tile 0 (iteration 0 issues nothing)
 #pragma unroll
-    for (int t = 0; t < NSTG - 1; ++t)
+    for (int t = 0; t < NSTG; ++t)
       if (t < a.nk) dma_tile(t);
     {
-      const int behind = min(a.nk, NSTG - 1) - 1;
-      if (behind >= 2) wait_vmcnt<2 * PER>(); else if (behind == 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
+      const int behind = min(a.nk, NSTG) - 1;
+      static_assert(3 * PER < 64, "vmcnt range");
+      if (behind >= 3) wait_vmcnt<3 * PER>(); else if (behind == 2) wait_vmcnt<2 * PER>(); else if (behind == 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
     }
     __builtin_amdgcn_s_barrier();
     int wstg = NSTG - 1;
     for (int it = 0; it < a.nk; ++it) {
-      if (it + NSTG - 1 < a.nk) dma_tile(wstg);            // the slot the consumers finished with in iteration it-1
+      if (it >= 1 && it + NSTG - 1 < a.nk) dma_tile(wstg);            // the slot the consumers finished with in iteration it-1
       if (++wstg == NSTG) wstg = 0;
       const int later = min(a.nk - 2 - it, NSTG - 2);      // DMA groups issued after tile it+1
       if (later >= 2) wait_vmcnt<2 * PER>(); else if (later == 1) wait_vmcnt<PER>(); else wait_vmcnt<0>();
@@ -1031,13 +1036,14 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
     }
   };
 
-  {
-    const unsigned keep = m0_save();
+  {                                                      // both weight slots are free: step 1's tile is issued here too, behind step 0's, and
+    const unsigned keep = m0_save();                     // may still be in flight when step 0 starts (step 0 then issues nothing)
     load_patch(0);
     load_weights(0, woff_t[0], 0);
+    if (nstep > 1) load_weights(0, woff_t[1], 1);
     m0_restore(keep);
   }
-  wait_vmcnt<0>();
+  if (nstep > 1) wait_vmcnt<BI>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
 
   // One step = (chunk, tap): two 32-channel k-steps of 2 x 2TN MFMAs per wave.  The weight fragments live in ONE buffer: fragment j of
@@ -1054,7 +1060,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
 #pragma unroll
       for (int t = 0; t < 9; ++t, ++step) {
         const uint4* Bb = &smem[ASZ + (step & 1) * BSZ];
-        if (step + 1 < nstep) {
+        if (step + 1 < nstep && step > 0) {
           const unsigned keep = m0_save();
           load_weights(t == 8 ? chunk + 1 : chunk, woff_t[t == 8 ? 0 : t + 1], (step + 1) & 1);
           m0_restore(keep);
