@@ -262,15 +262,30 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, AccT& acc, int m0, int
     // ---- phase 2: column-fixed threads, 16-byte chunks ----
     if (colok && a.probe_ep != 4) {
       if (simple) {
-        for (int srow = rl; srow < SR; srow += LANES) {
+        // all of a thread's staged rows are read from LDS first (independent ds_reads in flight), then converted and stored: row by row,
+        // each row paid its own LDS round trip
+        constexpr int RS = (SR + LANES - 1) / LANES;
+        float4 tv[RS][CE / 4];
+#pragma unroll
+        for (int u = 0; u < RS; ++u) {
+          const int srow = rl + u * LANES;
+          if (srow < SR) {
+            const float* cp = ctile + srow * LDC + cg * CE;
+#pragma unroll
+            for (int e = 0; e < CE; e += 4) tv[u][e / 4] = *reinterpret_cast<const float4*>(cp + e);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < RS; ++u) {
+          const int srow = rl + u * LANES;
+          if (srow >= SR) continue;
           const int trow = tile_row(srow, pass);
           const int m = m0 + trow;
           if (m >= a.M) continue;
-          const float* cp = ctile + srow * LDC + cg * CE;
           Chunk<T> st;
 #pragma unroll
           for (int e = 0; e < CE; e += 4) {
-            const float4 t = *reinterpret_cast<const float4*>(cp + e);
+            const float4 t = tv[u][e / 4];
             st.e[e] = Elem<T>::from_f(t.x); st.e[e + 1] = Elem<T>::from_f(t.y); st.e[e + 2] = Elem<T>::from_f(t.z); st.e[e + 3] = Elem<T>::from_f(t.w);
           }
           if (a.probe_ep != 1 || st.u.x == 0x12345678u) store_chunk<T>(dst + (size_t)m * a.Kd + k0, st);
