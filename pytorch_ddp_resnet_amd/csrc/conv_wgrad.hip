@@ -287,20 +287,47 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 // the transposed read to a zero row: 28-40 % fewer bytes per FLOP -- was built, parity-tested and measured 10-30 % SLOWER on the
 // WRN-28-10 shapes (253 registers, a pixel decode and address selects in every k-step); DESIGN.md 6e.  It is gone.)
 
+__device__ inline void add4(float4& s, const float4& v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+
+// dw = slab 0 + slab 1 + ... in slab order.  (Issuing the loads of eight slabs together made this SLOWER, 14.7 -> 22 us on WRN-28-10's
+// 320 -> 320 layers: the slabs of one output are a multiple of 16 KiB apart and land on the same memory channels.)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n, int splits, int accum) {
   long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long n4 = n >> 2;
   for (; i < n4; i += (long)gridDim.x * blockDim.x) {
     float4 s = reinterpret_cast<const float4*>(ws)[i];
-    for (int k = 1; k < splits; ++k) {
-      float4 v = reinterpret_cast<const float4*>(ws + (size_t)k * n)[i];
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
-    }
-    if (accum) {
-      float4 o = reinterpret_cast<float4*>(dw)[i];
-      s.x += o.x; s.y += o.y; s.z += o.z; s.w += o.w;
-    }
+    for (int k = 1; k < splits; ++k) add4(s, reinterpret_cast<const float4*>(ws + (size_t)k * n)[i]);
+    if (accum) add4(s, reinterpret_cast<float4*>(dw)[i]);
     reinterpret_cast<float4*>(dw)[i] = s;
+  }
+}
+
+// The sums of reduce_wide_body below (sixteen interleaved partial sums per output, then those in order: the SAME bits) by ONE thread per
+// output chunk with sixteen accumulators: sixteen independent, fully coalesced loads per step.  For outputs large enough to fill the chip
+// with a thread each (WRN-28-10's 160 -> 160 3x3: 57,600 chunks x 43 slabs took 34 us as 3,600 workgroups of 16 x 16 threads with two
+// barriers each).
+__global__ __launch_bounds__(256) void wgrad_reduce_lanes_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n, int splits, int accum) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+    float4 acc[16];
+#pragma unroll
+    for (int l = 0; l < 16; ++l) acc[l] = make_float4(0.f, 0.f, 0.f, 0.f);
+    int k = 0;
+    for (; k + 15 < splits; k += 16) {
+      float4 v[16];
+#pragma unroll
+      for (int l = 0; l < 16; ++l) v[l] = reinterpret_cast<const float4*>(ws + (size_t)(k + l) * n)[i];
+#pragma unroll
+      for (int l = 0; l < 16; ++l) add4(acc[l], v[l]);
+    }
+#pragma unroll
+    for (int l = 0; l < 16; ++l)
+      if (k + l < splits) add4(acc[l], reinterpret_cast<const float4*>(ws + (size_t)(k + l) * n)[i]);
+    float4 t = acc[0];
+#pragma unroll
+    for (int l = 1; l < 16; ++l) add4(t, acc[l]);
+    if (accum) add4(t, reinterpret_cast<float4*>(dw)[i]);
+    reinterpret_cast<float4*>(dw)[i] = t;
   }
 }
 
@@ -502,7 +529,10 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
       RN_CHECK_ARG(reduce_is_wide(a.splits, n4), "rn_conv_wgrad: RN_F_DEFER_REDUCE on a geometry whose reduction is not deferrable (rn_conv_wgrad_splits < 0)");
       return 0;
     }
-    if (reduce_is_wide(a.splits, n4)) {
+    if (reduce_is_wide(a.splits, n4) && n4 >= 16384) {   // a thread per output chunk fills the chip: same sums, no LDS step
+      hipLaunchKernelGGL(wgrad_reduce_lanes_kernel, dim3((int)((n4 + 255) / 256)), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), dw_krsc, (long)n,
+                         a.splits, (flags & RN_F_ACCUM) ? 1 : 0);
+    } else if (reduce_is_wide(a.splits, n4)) {
       const int blocks = reduce_wide_blocks(n4);
       hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(blocks), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), dw_krsc, (long)n,
                          a.splits, (flags & RN_F_ACCUM) ? 1 : 0);

@@ -402,7 +402,9 @@ def test_deferred_slab_sums_equal_the_immediate_reduction_bit_for_bit():
     L.rn_conv_wgrad_splits.argtypes = [C.POINTER(_lib.RnConvGeom), i32, i32]
     L.rn_wgrad_reduce_batch.argtypes = [C.POINTER(Desc), i32, vp]
     st = vp(torch.cuda.current_stream().cuda_stream)
-    geoms = [(64, 32, 32, 16, 16, 3, 1, 1), (64, 16, 16, 32, 32, 3, 1, 1), (64, 32, 32, 64, 16, 1, 1, 0)]
+    # the last geometry has >= 16,384 output chunks: its immediate reduction is the thread-per-chunk kernel (sixteen accumulators), which
+    # must give the bits of the sixteen-lane LDS form the batch launch uses
+    geoms = [(64, 32, 32, 16, 16, 3, 1, 1), (64, 16, 16, 32, 32, 3, 1, 1), (64, 32, 32, 64, 16, 1, 1, 0), (128, 32, 32, 160, 160, 3, 1, 1)]
     gen = torch.Generator(device='cuda').manual_seed(3)
     for accum in (0, ir.F_ACCUM):
         descs = (Desc * len(geoms))()
