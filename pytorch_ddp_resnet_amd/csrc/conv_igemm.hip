@@ -947,6 +947,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  stamp(a.stamps, 0);
   const int nmt = (a.M + BM - 1) / BM;
   int bid = blockIdx.x;
   if (a.xcd_remap) {
@@ -979,18 +980,28 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
   // the 16-byte chunk a lane copies: its slot `sl` XOR the row swizzle ((row >> 1) & 7).  Rows of one lane are 32 apart from one DMA
   // piece to the next (row = 8 (4 t + wave) + l8), so the swizzle -- and the chunk -- is the SAME for every piece: one register, not one per piece
   const int ch = sl ^ ((wave * 4 + (l8 >> 1)) & 7);
+  // piece t of a lane is patch pixel pp = 8 (NW t + wave) + l8: its (image, slab row, column) is divided out ONCE and then walked
+  // 8 NW pixels at a time (two runtime integer divisions per piece, 26 pieces: 2.5 us of ALU in front of every tile's first DMA --
+  // in-kernel stamps, setup 4.1 us of a 33 us tile)
   unsigned aoff[AI];
+  {
+    int pp = wave * 8 + l8;
+    int prow = pp / W2, pcol = pp - prow * W2;
+    int img = prow / slab_rows, hr = prow - img * slab_rows;
 #pragma unroll
-  for (int t = 0; t < AI; ++t) {
-    const int idx = t * NW + wave;
-    const int pp = idx * 8 + l8;
-    aoff[t] = OOB;
-    if (idx < nA && pp < PP) {
-      const int prow = pp / W2, pcol = pp - prow * W2;
-      const int img = prow / slab_rows, hr = prow - img * slab_rows;
-      const int h = h_first - 1 + hr, n = n_first + img;
-      if (pcol >= 1 && pcol <= W && h >= 0 && h < H && n < a.N)
-        aoff[t] = (unsigned)((((size_t)img * H + h) * W + (pcol - 1)) * a.Cs * ES + ch * 16);
+    for (int t = 0; t < AI; ++t) {
+      const int idx = t * NW + wave;
+      aoff[t] = OOB;
+      if (idx < nA && pp < PP) {
+        const int h = h_first - 1 + hr, n = n_first + img;
+        if (pcol >= 1 && pcol <= W && h >= 0 && h < H && n < a.N)
+          aoff[t] = ((unsigned)((img * H + h) * W + (pcol - 1))) * (unsigned)(a.Cs * ES) + (unsigned)(ch * 16);    // < 4 GiB: check_geom
+      }
+      pp += NW * 8; pcol += NW * 8;
+      while (pcol >= W2) {
+        pcol -= W2;
+        if (++hr == slab_rows) { hr = 0; ++img; }
+      }
     }
   }
   unsigned boff[BI];
@@ -1051,6 +1062,7 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
     }
   };
 
+  stamp(a.stamps, 7);
   {                                                      // both weight slots are free: step 1's tile is issued here too, behind step 0's, and
     const unsigned keep = m0_save();                     // may still be in flight when step 0 starts (step 0 then issues nothing)
     load_patch(0);
@@ -1058,8 +1070,10 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
     if (nstep > 1) load_weights(0, woff_t[1], 1);
     m0_restore(keep);
   }
+  stamp(a.stamps, 8);
   if (nstep > 1) wait_vmcnt<BI>(); else wait_vmcnt<0>();
   __builtin_amdgcn_s_barrier();
+  stamp(a.stamps, 1);
 
   // One step = (chunk, tap): two 32-channel k-steps of 2 x 2TN MFMAs per wave.  The weight fragments live in ONE buffer: fragment j of
   // the second k-step is read into the registers the first k-step's MFMAs on column j have just consumed.
@@ -1115,12 +1129,14 @@ __global__ __launch_bounds__(256, 2) void igemm_patch128_kernel(const IgemmArgs 
         __builtin_amdgcn_s_barrier();
       }
     }
+    if (chunk < 2) stamp(a.stamps, 11 + 2 * chunk);     // diagnostic: end of the chunk's nine steps / patch reloaded
     if (chunk + 1 < nchunk) {                            // every wave is done with the patch: reload it for the next chunk
       const unsigned keep = m0_save();
       load_patch(chunk + 1);
       m0_restore(keep);
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
+      if (chunk < 2) stamp(a.stamps, 12 + 2 * chunk);
     }
   }
   igemm_epilogue<T, BM, BN, WM, WN, RT / 2, CT, 256, 64, true>(a, acc16, m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
