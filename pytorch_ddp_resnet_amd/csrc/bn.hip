@@ -94,9 +94,25 @@ __device__ inline void reduce_partials(const float* __restrict__ partial, int nb
   // fixed-order tree (bitwise reproducible): rows b = bl, bl+64, ... per thread; the 4 row lanes of a wave by shuffles; the 16
   // waves through LDS, 4 per lane group of wave 0, then shuffles again.  The result is valid in threads 0..15 (bl == 0).
   // (a serial 64-step LDS loop here cost ~2.8 us of a 6 us kernel)
+  // a thread's rows in row order (bitwise reproducible), the loads of eight rows issued together: one row at a time, every row was a
+  // memory round trip of its own (16 rows per thread on the 16-channel layers of ResNet-v2-164: 8.1 us for a one-workgroup launch)
   s = 0.0; ss = 0.0;
-  if (c < C)
-    for (int b = bl; b < nblk; b += FL) { s += (double)partial[((size_t)b * 2) * C + c]; ss += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+  if (c < C) {
+    int b = bl;
+    for (; b + 7 * FL < nblk; b += 8 * FL) {
+      float v0[8], v1[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { v0[u] = partial[((size_t)(b + u * FL) * 2) * C + c]; v1[u] = partial[((size_t)(b + u * FL) * 2 + 1) * C + c]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s += (double)v0[u]; ss += (double)v1[u]; }
+    }
+    for (; b + FL < nblk; b += 2 * FL) {
+      const float a0 = partial[((size_t)b * 2) * C + c], a1 = partial[((size_t)b * 2 + 1) * C + c];
+      const float b0 = partial[((size_t)(b + FL) * 2) * C + c], b1 = partial[((size_t)(b + FL) * 2 + 1) * C + c];
+      s += (double)a0; ss += (double)a1; s += (double)b0; ss += (double)b1;
+    }
+    for (; b < nblk; b += FL) { s += (double)partial[((size_t)b * 2) * C + c]; ss += (double)partial[((size_t)b * 2 + 1) * C + c]; }
+  }
   static_assert(FC == 16 && FL == 64, "reduction tree is written for 16 channels x 64 row lanes");
   const int tid = threadIdx.x, cl = tid % FC, wave = tid >> 6, lane = tid & 63;
   s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
