@@ -468,7 +468,8 @@ __global__ __launch_bounds__(NT) void gap_kernel(const T* __restrict__ x, float*
 #pragma unroll
     for (int e = 0; e < CE; ++e) s[e] = 0.f;
     if (rl < lanes && cg < CC)
-      for (int p = rl; p < HW; p += lanes) {
+#pragma unroll 8
+      for (int p = rl; p < HW; p += lanes) {               // unrolled: the loads of eight pixels in flight (adds stay in pixel order)
         Chunk<T> c = load_chunk<T>(x + ((size_t)n * HW + p) * C + cg * CE);
 #pragma unroll
         for (int e = 0; e < CE; ++e) s[e] += Elem<T>::to_f(c.e[e]);
@@ -498,6 +499,7 @@ __global__ __launch_bounds__(NT) void fc_fwd_kernel(const float* __restrict__ fe
   if (wid >= (long)N * O) return;
   const int n = (int)(wid / O), o = (int)(wid - (long)n * O);
   float s = 0.f;
+#pragma unroll 4
   for (int c = lane; c < C; c += 64) s = fmaf(feat[(size_t)n * C + c], w[(size_t)o * C + c], s);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
@@ -542,6 +544,7 @@ __global__ __launch_bounds__(NT) void fc_dgrad_kernel(const float* __restrict__ 
     float s[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) s[e] = 0.f;
+#pragma unroll 4
     for (int o = 0; o < O; ++o) {
       const float d = dl[(size_t)n * O + o];
 #pragma unroll
