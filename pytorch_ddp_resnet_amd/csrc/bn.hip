@@ -202,15 +202,12 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, c
     float sc[CE], sh[CE];
 #pragma unroll
     for (int e = 0; e < CE; ++e) { sc[e] = coef[c0 + e]; sh[e] = coef[C + c0 + e]; }
-#pragma unroll 2
-    for (int r = s.r_begin + s.rl; r < s.r_end; r += s.lanes) {
-      const size_t off = (size_t)r * C + c0;
-      Chunk<T> cx = load_chunk<T>(x + off);
+    const bool res_same = res.mode == RN_RES_SAME;
+    auto one = [&](int r, size_t off, const Chunk<T>& cx, const Chunk<T>& cr) {
       float v[CE];
 #pragma unroll
       for (int e = 0; e < CE; ++e) v[e] = fmaf(Elem<T>::to_f(cx.e[e]), sc[e], sh[e]);
-      if (res.mode == RN_RES_SAME) {
-        Chunk<T> cr = load_chunk<T>(reinterpret_cast<const T*>(res.ptr) + off);
+      if (res_same) {
 #pragma unroll
         for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cr.e[e]);
       } else if (res.mode != RN_RES_NONE) {
@@ -231,6 +228,25 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, c
 #pragma unroll
       for (int e = 0; e < CE; ++e) co.e[e] = Elem<T>::from_f(v[e]);
       store_chunk<T>(out + off, co);
+    };
+    // four rows of loads in flight (a thread streams >= 4 rows: slab_rows): row by row, every row was a memory round trip of its own
+    int r = s.r_begin + s.rl;
+    for (; r + 3 * s.lanes < s.r_end; r += 4 * s.lanes) {
+      Chunk<T> cx[4], cr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t off = (size_t)(r + u * s.lanes) * C + c0;
+        cx[u] = load_chunk<T>(x + off);
+        if (res_same) cr[u] = load_chunk<T>(reinterpret_cast<const T*>(res.ptr) + off);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) one(r + u * s.lanes, (size_t)(r + u * s.lanes) * C + c0, cx[u], cr[u]);
+    }
+    for (; r < s.r_end; r += s.lanes) {
+      const size_t off = (size_t)r * C + c0;
+      Chunk<T> cx = load_chunk<T>(x + off), cr;
+      if (res_same) cr = load_chunk<T>(reinterpret_cast<const T*>(res.ptr) + off);
+      one(r, off, cx, cr);
     }
   }
 }
