@@ -185,7 +185,7 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, AccT& acc, int m0, int
   constexpr int RPB = 32 / NPASS;              // rows of a block per pass
   constexpr int NR = 16 / NPASS;               // accumulator registers of a lane per pass (registers NR*pass .. NR*pass+NR-1)
   constexpr int NGRP = BM / RN_CONV_STATS_ROWS;          // partial-sum rows this tile writes (one per 128 output rows)
-  static_assert(BM % RN_CONV_STATS_ROWS == 0 && BN % CE == 0 && (NPASS == 2 || NPASS == 4 || NPASS == 8) && RPB * NBLK == SR, "epilogue tile");
+  static_assert(BM % RN_CONV_STATS_ROWS == 0 && BN % CE == 0 && (NPASS == 1 || NPASS == 2 || NPASS == 4 || NPASS == 8) && RPB * NBLK == SR, "epilogue tile");
   // staged row s = blk*RPB + lh*NR + j  <->  accumulator register r = NR*pass + j of lane half lh in block blk
   //                                     <->  tile row blk*32 + (r&3) + 8*(r>>2) + 4*lh
   float* ctile = lds_f;                        // [SR][LDC]
@@ -714,7 +714,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
     if (++stg == NSTG) stg = 0;
   }
 
-  constexpr int SR = CPRT == 4 ? 32 : 64;              // 64-byte K rows: the ring is half as large, so is the staged slab
+  // 32-column tiles (thin layers) stage the whole tile at once: their kernels are a chain of latencies, and every pass is two barriers
+  constexpr int SR = CPRT == 4 ? 32 : (BN == 32 ? BM : 64);              // 64-byte K rows: the ring is half as large, so is the staged slab
+  static_assert((size_t)SR * (BN + 4) * 4 + (size_t)(NW * 64 / (BN / Elem<T>::CE)) * 2 * BN * 4 <= sizeof(smem), "epilogue staging exceeds the ring");
   igemm_epilogue<T, BM, BN, WM, WN, TM, TN, NW * 64, SR>(a, acc, m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
 }
 
@@ -883,7 +885,9 @@ __global__ __launch_bounds__(512, BM >= 256 ? 1 : 2) void igemm_ws_kernel(const 
       __builtin_amdgcn_s_barrier();
     }
   }
-  igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 512>(a, acc, m0, n0, loader ? 0 : wave, lane, reinterpret_cast<float*>(&smem[0]), !loader);
+  constexpr int SR = BN == 32 ? BM : 64;               // as in igemm_dma_kernel
+  static_assert((size_t)SR * (BN + 4) * 4 + (size_t)(512 / (BN / Elem<T>::CE)) * 2 * BN * 4 <= sizeof(smem), "epilogue staging exceeds the ring");
+  igemm_epilogue<T, BM, BN, WM, WN, TM, TN, 512, SR>(a, acc, m0, n0, loader ? 0 : wave, lane, reinterpret_cast<float*>(&smem[0]), !loader);
 }
 
 template <typename T, int BM, int BN, int WM, int WN>
