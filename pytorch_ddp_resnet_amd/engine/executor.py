@@ -211,7 +211,10 @@ class Engine:
             return
         if g == 'warm':
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: a collective backend's own threads (gloo's device-to-host copies, the RCCL watchdog's event queries) may call
+            # synchronising HIP APIs while this thread captures; in the default (global) mode that invalidates the capture -- seen as a
+            # timing-dependent hipErrorStreamCaptureInvalidated in the two-rank test.  This thread itself only launches kernels.
+            with torch.cuda.graph(g, capture_error_mode='thread_local'):
                 stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
                 _lib.check(self.L.rn_plan_run(self._h, a, b, step_seed, stream))
             self._graphs[key] = g
