@@ -1,0 +1,523 @@
+// Pieces shared by the implicit-GEMM convolution kernels (conv_igemm.hip: 128-row tiles, two schedules + the LDS-patch kernel;
+// conv_igemm8.hip: 256-row tiles on the eight-phase schedule): kernel arguments, tap tables, LDS-DMA helpers and the fused epilogue.
+#pragma once
+#include "common.h"
+#include <type_traits>
+
+extern int g_rn_variant;          // tuning switch (rn_set_variant), defined in conv_igemm.hip
+extern void* g_rn_stamps;         // diagnostic stamp buffer (rn_set_stamp_buffer)
+
+constexpr int MAX_TAPS = 49;        // 7x7 stem
+constexpr int CPR = 8;  // 16-byte chunks per LDS row (128 bytes of K per row)
+
+// Kernel arguments.  Every scalar a kernel reads sits in the first 200 bytes and is fetched by ONE batch of scalar loads at
+// kernel entry (preload_args): left to the compiler, the fields were loaded one by one at first use, each a dependent
+// s_load + s_waitcnt out of kernarg memory -- ~2 us of a 9 us tile on 1x1 convolutions.  The tap arrays come last.
+struct IgemmArgs {
+  const void* src;
+  const void* wt;
+  void* dst;
+  ResDesc res;
+  int N, Hs, Ws, Cs;
+  int Pc, Qc, M;
+  int Hd, Wd, Kd;
+  int ss, ds, oh, ow;
+  int nt, wrs, cpt, nk;
+  int nth, ntw;            // the taps form an nth x ntw grid (tap = i * ntw + j): validity is separable in (dh_i, dw_j)
+  unsigned magic_pq, magic_q;   // floor(2^32 / (Pc*Qc)), floor(2^32 / Qc): division by multiply-high + one correction (fill_magic)
+  int accum;
+  // fused epilogues (rn_conv_epilogue): per-M-tile partial sums written to stats[(tile_base + m-tile)][2][Kd]
+  int tile_base;
+  float* stats;            // forward: (sum y, sum y^2) of the stored output
+  const void* bn_x;        // dgrad: (sum g, sum g*xhat), g = dx * gscale * [mask > 0], xhat = (bn_x - mean) * invstd
+  const void* bn_mask;
+  const float* bn_coef;
+  const float* bias;       // per-output-channel bias added in the epilogue (stem convolution), or NULL
+  float gscale;
+  unsigned probe_mask;     // timing probe (rn_set_variant bit6): AND-mask on DMA source offsets, 0xFFFFFFFF in production
+  unsigned long long* stamps;   // diagnostic: per-workgroup s_memtime stamps [grid][16] (rn_set_stamp_buffer), NULL in production
+  int probe_ep;            // timing probes: 1 = skip the global stores of the epilogue, 2 = skip the epilogue
+  int probe_k;             // K-loop timing probes (igemm_dma_kernel): 1 = DMA only (no fragment reads / MFMA), 2 = no DMA, 3 = every DMA out of range
+  int xcd_remap;           // 1: blockIdx -> tile through the bijective XCD remap, column tiles fastest
+  int dense_src;           // 1: one tap at offset (0,0), unit stride, source grid == compute grid (1x1 convolutions): row m reads pixel m
+  // eight-phase kernels (conv_igemm8.hip): the taps as a separable arithmetic progression, walked with scalar adds.  K tile g = (tap (i, j),
+  // 64-channel chunk cc): source byte offset w8_src0 + i w8_si + j w8_sj + 128 cc, weight byte offset w8_wt0 + i w8_wi + j w8_wj + 128 cc
+  int w8_src0, w8_si, w8_sj, w8_wt0, w8_wi, w8_wj, w8_cpc;
+  int dh[MAX_TAPS], dw[MAX_TAPS], widx[MAX_TAPS];
+};
+
+namespace {
+
+// materialise every scalar argument in SGPRs now: the loads are adjacent, hipcc merges them into a few wide s_loads + one wait
+__device__ inline void preload_args(const IgemmArgs& a) {
+#define RN_TOUCH(x) asm volatile("" ::"s"(x))
+  RN_TOUCH(a.src); RN_TOUCH(a.wt); RN_TOUCH(a.dst); RN_TOUCH(a.res.ptr); RN_TOUCH(a.res.mode); RN_TOUCH(a.res.C); RN_TOUCH(a.res.H); RN_TOUCH(a.res.W);
+  RN_TOUCH(a.N); RN_TOUCH(a.Hs); RN_TOUCH(a.Ws); RN_TOUCH(a.Cs); RN_TOUCH(a.Pc); RN_TOUCH(a.Qc); RN_TOUCH(a.M);
+  RN_TOUCH(a.Hd); RN_TOUCH(a.Wd); RN_TOUCH(a.Kd); RN_TOUCH(a.ss); RN_TOUCH(a.ds); RN_TOUCH(a.oh); RN_TOUCH(a.ow);
+  RN_TOUCH(a.nt); RN_TOUCH(a.wrs); RN_TOUCH(a.cpt); RN_TOUCH(a.nk); RN_TOUCH(a.nth); RN_TOUCH(a.ntw);
+  RN_TOUCH(a.magic_pq); RN_TOUCH(a.magic_q); RN_TOUCH(a.accum); RN_TOUCH(a.tile_base);
+  RN_TOUCH(a.stats); RN_TOUCH(a.bn_x); RN_TOUCH(a.bn_mask); RN_TOUCH(a.bn_coef); RN_TOUCH(a.bias); RN_TOUCH(a.gscale);
+  RN_TOUCH(a.probe_mask); RN_TOUCH(a.stamps); RN_TOUCH(a.probe_ep); RN_TOUCH(a.xcd_remap); RN_TOUCH(a.dense_src); RN_TOUCH(a.probe_k);
+#undef RN_TOUCH
+}
+
+__device__ inline void stamp(const unsigned long long* base_c, int slot) {
+  unsigned long long* base = const_cast<unsigned long long*>(base_c);
+  if (base && threadIdx.x == 0) base[(size_t)blockIdx.x * 16 + slot] = __builtin_amdgcn_s_memrealtime();   // 100 MHz
+}
+
+template <typename T> struct Mfma;
+template <> struct Mfma<float> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    const float* af = reinterpret_cast<const float*>(&a);
+    const float* bf = reinterpret_cast<const float*>(&b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) c = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<bf16_t> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  }
+};
+// v_mfma_f32_16x16x32: A = 16 rows x 32 k (lane l: row l & 15, k 8 (l >> 4) .. + 7), B likewise by column, D = 4 registers (row 4 (l >> 4) + r,
+// column l & 15).  Same FLOPs per pipe cycle as 32x32x16, but the chip holds a higher clock on it under load (measured here as a timing
+// probe on the WRN-28-10 shapes: +8 % per launch; MI355X_MICROARCH.md, DVFS give-back (7)).
+template <typename T> struct Mfma16;
+template <> struct Mfma16<bf16_t> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<const bf16x8*>(&a), *reinterpret_cast<const bf16x8*>(&b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma16<f16_t> {
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x4& c) {
+    c = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const f16x8*>(&a), *reinterpret_cast<const f16x8*>(&b), c, 0, 0, 0);
+  }
+};
+template <> struct Mfma<f16_t> {     // same cycles as the bf16 form (MI355X_MICROARCH.md, matrix cores)
+  __device__ static inline void run(const uint4& a, const uint4& b, f32x16& c) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(&a), *reinterpret_cast<const f16x8*>(&b), c, 0, 0, 0);
+  }
+};
+
+
+// ---- row decode + tap tables shared by the DMA kernels -------------------------------------------------------------------
+// LDS tap tables (ints): [0..63] source byte offset of a tap, [64..127] weight byte offset, [128..191] (dh << 16) | (dw & 0xFFFF).
+// The per-row validity masks read the packed (dh, dw) from LDS four taps at a time: looping over the kernel-argument
+// arrays instead costs two dependent scalar loads per tap and row (measured: 5.3 us of a 41 us tile on WRN-28-10's first stage).
+constexpr int TAP_INTS = 192;
+template <int ES>
+__device__ inline void fill_tap_tables(const IgemmArgs& a, int* taps) {
+  const int tid = threadIdx.x;
+  if (tid < 64) {
+    const bool ok = tid < a.nt;
+    const int t = ok ? tid : 0;
+    const int dh = a.dh[t], dw = a.dw[t];
+    taps[tid] = ok ? (dh * a.Ws + dw) * a.Cs * ES : 0;
+    taps[64 + tid] = ok ? a.widx[t] * a.Cs * ES : 0;
+    taps[128 + tid] = ok ? ((dh << 16) | (dw & 0xFFFF)) : 0x40004000;      // padding taps: far out of range
+  }
+}
+__device__ inline void decode_row(const IgemmArgs& a, int m, int pq, int& n, int& pp, int& q) {
+  n = (int)__umulhi((unsigned)m, a.magic_pq);
+  int rem = m - n * pq;
+  if (rem >= pq) { ++n; rem -= pq; }
+  pp = (int)__umulhi((unsigned)rem, a.magic_q);
+  q = rem - pp * a.Qc;
+  if (q >= a.Qc) { ++pp; q -= a.Qc; }
+}
+
+// ---- epilogue shared by all implicit-GEMM kernels ---------------------------------------------------------------------------
+// The 32x32 MFMA leaves a lane with ONE output channel (col = lane&31) of 16 rows (row = (r&3) + 8*(r>>2) + 4*(lane>>5)):
+// storing from there means 2-byte accesses in 64-byte segments, which capped output-bound layers (1x1 convolutions at
+// 56x56) at ~0.6 TB/s.  Instead the accumulator tile goes through LDS (the staging memory, free after the K loop) in two
+// halves of 64 rows as fp32, and is read back by column-fixed threads -- thread = (16-byte output chunk column, row lane)
+// -- so every global access (store, residual, accumulate, BatchNorm operands) is a 16-byte chunk, consecutive lanes on
+// consecutive chunks of a row.  Owning a fixed channel chunk, a thread also keeps per-channel sums in registers: the
+// BatchNorm batch statistics of what it stores (forward) or the two BatchNorm-backward sums of the layer that fed the
+// convolution (dgrad), reduced over the row lanes through LDS into one partial row per M tile.
+// workgroup barrier that orders LDS traffic only: `__syncthreads()` also drains vmcnt, i.e. waits until the global
+// stores a wave has just issued are acknowledged (1-2 us each time in the epilogue)
+__device__ inline void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
+// SR: staged rows per pass (64 or 32, whatever fits the K-loop's LDS next to the reduction scratch)
+// L16: the accumulators come from v_mfma_f32_16x16x32 tiles -- acc[2 TM][TN] of f32x4 (TN then counts 16-column tiles), element r of lane l = tile row 4 (l >> 4) + r,
+// column l & 15 -- instead of 32x32 tiles (acc[TM][TN] of f32x16: row (r & 3) + 8 (r >> 2) + 4 (l >> 5), column l & 31); only the parking
+// of the registers in LDS (phase 1) and the staged-row <-> tile-row map differ
+template <typename T, int BM, int BN, int WM, int WN, int TM, int TN, int NTH = WM * WN * 64, int SR = 64, bool L16 = false, typename AccT>
+__device__ inline void igemm_epilogue(const IgemmArgs& a, AccT& acc, int m0, int n0, int wave, int lane, float* lds_f, bool active = true) {
+  if (a.probe_ep >= 2) {                       // keep every accumulator live (no dead-code elimination of the MFMAs)
+#pragma unroll
+    for (int i = 0; i < (L16 ? 2 * TM : TM); ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < (L16 ? 4 : 16); ++r) asm volatile("" ::"v"(acc[i][j][r]));
+    if (a.probe_ep == 2) return;
+  }
+  constexpr int CE = Elem<T>::CE;
+  constexpr int LDC = BN + 4;                  // fp32 row stride of the staged tile
+  constexpr int CCN = BN / CE;                 // output chunks per row
+  constexpr int LANES = NTH / CCN;             // row lanes (threads beyond LANES*CCN idle in phase 2)
+  constexpr int NBLK = BM / 32;                // 32-row MFMA blocks of the tile
+  constexpr int NPASS = BM / SR;               // passes; each takes RPB rows of EVERY block, so all waves park in every pass
+  constexpr int RPB = 32 / NPASS;              // rows of a block per pass
+  constexpr int NR = 16 / NPASS;               // accumulator registers of a lane per pass (registers NR*pass .. NR*pass+NR-1)
+  constexpr int NGRP = BM / RN_CONV_STATS_ROWS;          // partial-sum rows this tile writes (one per 128 output rows)
+  static_assert(BM % RN_CONV_STATS_ROWS == 0 && BN % CE == 0 && (NPASS == 1 || NPASS == 2 || NPASS == 4 || NPASS == 8) && RPB * NBLK == SR, "epilogue tile");
+  // staged row s = blk*RPB + lh*NR + j  <->  accumulator register r = NR*pass + j of lane half lh in block blk
+  //                                     <->  tile row blk*32 + (r&3) + 8*(r>>2) + 4*lh
+  float* ctile = lds_f;                        // [SR][LDC]
+  float* red = lds_f + SR * LDC;               // [row lanes][2][BN]
+  const int wm = wave / WN, wn = wave % WN;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int pq = a.Pc * a.Qc;
+  const int tid = threadIdx.x;
+  const int cg = tid % CCN, rl = tid / CCN;
+  const bool p2 = rl < LANES;
+  const int k0 = n0 + cg * CE;
+  const bool colok = p2 && k0 < a.Kd;
+  T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
+  const bool dense = (a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME);
+  const bool want_stats = a.stats != nullptr;
+  const bool bn_bwd = want_stats && a.bn_x != nullptr;
+  const bool res_same = a.res.mode == RN_RES_SAME;
+  // the common forward case gets its own row loop: no residual / accumulate / BatchNorm-backward operands, no bias
+  const bool simple = dense && a.res.mode == RN_RES_NONE && !a.accum && !bn_bwd && !a.bias;
+  float s0[NGRP][CE], s1[NGRP][CE], mean[CE], invstd[CE], bias[CE];
+#pragma unroll
+  for (int e = 0; e < CE; ++e) {
+#pragma unroll
+    for (int gi = 0; gi < NGRP; ++gi) s0[gi][e] = s1[gi][e] = 0.f;
+    mean[e] = 0.f; invstd[e] = 1.f; bias[e] = 0.f;
+    if (colok && bn_bwd) { mean[e] = a.bn_coef[2 * a.Kd + k0 + e]; invstd[e] = a.bn_coef[3 * a.Kd + k0 + e]; }
+    if (colok && a.bias) bias[e] = a.bias[k0 + e];
+  }
+  auto tile_row = [&](int srow, int pass) {    // staged row -> row of the tile
+    const int blk = srow / RPB, rem = srow - blk * RPB;
+    if constexpr (L16) return blk * 32 + pass * RPB + rem;      // a pass takes RPB consecutive rows of every 32-row block
+    const int hh = rem / NR, r = NR * pass + (rem - hh * NR);
+    return blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+  };
+  __syncthreads();                             // every wave is done with the K-loop staging memory
+  stamp(a.stamps, 2);
+#pragma unroll
+  for (int pass = 0; pass < NPASS; ++pass) {
+    // ---- phase 1: every wave parks NR accumulator registers of each of its MFMA blocks (fp32) ----
+    if (active && a.probe_ep != 3) {
+      if constexpr (L16) {
+        static_assert(!L16 || RPB == 16 || RPB == 8, "16x16 accumulator tiles: 16 or 8 rows of a block per pass");
+        const int l16 = lane & 15, lq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int blk = wm * TM + i;
+#pragma unroll
+          for (int it = 0; it < 2; ++it) {               // the two 16-row tiles of the 32-row block
+            if (RPB == 16 ? it != pass : it != pass / 2) continue;
+            if (RPB == 8 && (lq >> 1) != (pass & 1)) continue;          // half a tile per pass: lanes whose rows 4 lq + r fall into it
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int srow = blk * RPB + (RPB == 16 ? 4 * lq + r : 4 * (lq & 1) + r);
+#pragma unroll
+              for (int j = 0; j < TN; ++j) ctile[srow * LDC + wn * (BN / WN) + 16 * j + l16] = acc[2 * i + it][j][r];
+            }
+          }
+        }
+      } else {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const int blk = wm * TM + i;
+#pragma unroll
+        for (int jr = 0; jr < NR; ++jr) {
+          const int srow = blk * RPB + lh * NR + jr;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) ctile[srow * LDC + wn * (BN / WN) + 32 * j + lr] = acc[i][j][NR * pass + jr];
+        }
+      }
+      }
+    }
+    lds_barrier();
+    if (pass < 2) stamp(a.stamps, 3 + 2 * pass);
+    // ---- phase 2: column-fixed threads, 16-byte chunks ----
+    if (colok && a.probe_ep != 4) {
+      if (simple) {
+        // all of a thread's staged rows are read from LDS first (independent ds_reads in flight), then converted and stored: row by row,
+        // each row paid its own LDS round trip
+        constexpr int RS = (SR + LANES - 1) / LANES;
+        float4 tv[RS][CE / 4];
+#pragma unroll
+        for (int u = 0; u < RS; ++u) {
+          const int srow = rl + u * LANES;
+          if (srow < SR) {
+            const float* cp = ctile + srow * LDC + cg * CE;
+#pragma unroll
+            for (int e = 0; e < CE; e += 4) tv[u][e / 4] = *reinterpret_cast<const float4*>(cp + e);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < RS; ++u) {
+          const int srow = rl + u * LANES;
+          if (srow >= SR) continue;
+          const int trow = tile_row(srow, pass);
+          const int m = m0 + trow;
+          if (m >= a.M) continue;
+          Chunk<T> st;
+#pragma unroll
+          for (int e = 0; e < CE; e += 4) {
+            const float4 t = tv[u][e / 4];
+            st.e[e] = Elem<T>::from_f(t.x); st.e[e + 1] = Elem<T>::from_f(t.y); st.e[e + 2] = Elem<T>::from_f(t.z); st.e[e + 3] = Elem<T>::from_f(t.w);
+          }
+          if (a.probe_ep != 1 || st.u.x == 0x12345678u) store_chunk<T>(dst + (size_t)m * a.Kd + k0, st);
+          if (want_stats) {
+            const int gi = NGRP > 1 ? trow / RN_CONV_STATS_ROWS : 0;
+#pragma unroll
+            for (int e = 0; e < CE; ++e) {
+              const float vs = Elem<T>::to_f(st.e[e]);
+#pragma unroll
+              for (int gg = 0; gg < NGRP; ++gg) if (gg == gi) { s0[gg][e] += vs; s1[gg][e] += vs * vs; }
+            }
+          }
+        }
+      } else {
+        // general rows: the global operands (residual, accumulate, BatchNorm x / mask) of row i+1 are requested before row i
+        // is processed, so a thread pays their latency once per pass instead of once per row (the fused 1x1 data gradients of
+        // WRN-50-2 spend most of their time here)
+        struct Row { bool ok; size_t off; int trow, n, hd, wd; Chunk<T> cr, co, cx, cm; };
+        auto fetch = [&](int srow, Row& r) {
+          r.ok = false;
+          if (srow >= SR) return;
+          r.trow = tile_row(srow, pass);
+          const int m = m0 + r.trow;
+          if (m >= a.M) return;
+          r.ok = true;
+          r.n = r.hd = r.wd = 0;
+          size_t pix;
+          if (dense) {
+            pix = (size_t)m;
+          } else {
+            int pp, q;
+            decode_row(a, m, pq, r.n, pp, q);
+            r.hd = pp * a.ds + a.oh;
+            r.wd = q * a.ds + a.ow;
+            pix = ((size_t)r.n * a.Hd + r.hd) * a.Wd + r.wd;
+          }
+          r.off = pix * a.Kd + k0;
+          if (res_same) r.cr = load_chunk<T>(reinterpret_cast<const T*>(a.res.ptr) + r.off);
+          if (a.accum) r.co = load_chunk<T>(dst + r.off);
+          if (bn_bwd) {
+            r.cx = load_chunk<T>(reinterpret_cast<const T*>(a.bn_x) + r.off);
+            if (a.bn_mask) r.cm = load_chunk<T>(reinterpret_cast<const T*>(a.bn_mask) + r.off);
+          }
+        };
+        // G rows in flight per thread: these epilogues are latency-bound on their operand loads (a 1x1 data gradient of WRN-50-2 is two
+        // K steps and then 128 x 128 outputs with 2-3 operand chunks each); registers allow 4 rows at up to 128 columns, 2 at 160
+        constexpr int RMAX = (SR + LANES - 1) / LANES;
+        constexpr int G = (RMAX >= 4 && BN <= 128) ? 4 : (RMAX >= 2 ? 2 : 1);
+        for (int base = rl; base < SR; base += G * LANES) {
+          Row rows[G];
+#pragma unroll
+          for (int u = 0; u < G; ++u) fetch(base + u * LANES, rows[u]);
+#pragma unroll
+          for (int u = 0; u < G; ++u) {
+          const int srow = base + u * LANES;
+          const Row& cur = rows[u];
+          if (!cur.ok) continue;
+          float v[CE];
+          const float* cp = ctile + srow * LDC + cg * CE;
+#pragma unroll
+          for (int e = 0; e < CE; e += 4) {
+            const float4 t = *reinterpret_cast<const float4*>(cp + e);
+            v[e] = t.x + bias[e]; v[e + 1] = t.y + bias[e + 1]; v[e + 2] = t.z + bias[e + 2]; v[e + 3] = t.w + bias[e + 3];
+          }
+          if (res_same) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cur.cr.e[e]);
+          } else if (a.res.mode != RN_RES_NONE) {
+            res_add_chunk<T>(a.res, cur.n, cur.hd, cur.wd, k0, v);
+          }
+          if (a.accum) {
+#pragma unroll
+            for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(cur.co.e[e]);
+          }
+          Chunk<T> st;
+#pragma unroll
+          for (int e = 0; e < CE; ++e) st.e[e] = Elem<T>::from_f(v[e]);
+          if (a.probe_ep != 1 || st.u.x == 0x12345678u) store_chunk<T>(dst + cur.off, st);
+          if (want_stats) {
+            const int gi = NGRP > 1 ? cur.trow / RN_CONV_STATS_ROWS : 0;
+            float d0[CE], d1[CE];
+            if (!bn_bwd) {
+#pragma unroll
+              for (int e = 0; e < CE; ++e) { const float vs = Elem<T>::to_f(st.e[e]); d0[e] = vs; d1[e] = vs * vs; }
+            } else {
+#pragma unroll
+              for (int e = 0; e < CE; ++e) {
+                float g = Elem<T>::to_f(st.e[e]) * a.gscale;
+                if (a.bn_mask && !(Elem<T>::to_f(cur.cm.e[e]) > 0.f)) g = 0.f;
+                const float xh = (Elem<T>::to_f(cur.cx.e[e]) - mean[e]) * invstd[e];
+                d0[e] = g; d1[e] = g * xh;
+              }
+            }
+#pragma unroll
+            for (int e = 0; e < CE; ++e)
+#pragma unroll
+              for (int gg = 0; gg < NGRP; ++gg) if (gg == gi) { s0[gg][e] += d0[e]; s1[gg][e] += d1[e]; }
+          }
+          }
+        }
+      }
+    }
+    if (want_stats && pass == NPASS - 1) {     // one partial row per RN_CONV_STATS_ROWS output rows
+#pragma unroll
+      for (int gg = 0; gg < NGRP; ++gg) {
+        if (p2) {
+#pragma unroll
+          for (int e = 0; e < CE; ++e) { red[(rl * 2 + 0) * BN + cg * CE + e] = s0[gg][e]; red[(rl * 2 + 1) * BN + cg * CE + e] = s1[gg][e]; }
+        }
+        lds_barrier();
+        if (m0 + gg * RN_CONV_STATS_ROWS < a.M) {
+          for (int col = tid; col < BN; col += NTH) {
+            const int k = n0 + col;
+            if (k >= a.Kd) continue;
+            float t0 = 0.f, t1 = 0.f;
+            for (int w = 0; w < LANES; ++w) { t0 += red[(w * 2 + 0) * BN + col]; t1 += red[(w * 2 + 1) * BN + col]; }
+            float* out = a.stats + ((size_t)(a.tile_base + m0 / RN_CONV_STATS_ROWS + gg) * 2) * a.Kd;
+            out[k] = t0;
+            out[a.Kd + k] = t1;
+          }
+        }
+        if (gg + 1 < NGRP) lds_barrier();
+      }
+    }
+    lds_barrier();                             // ctile (and `red`) are reused by the next pass
+    if (pass < 2) stamp(a.stamps, 4 + 2 * pass);
+  }
+}
+
+constexpr unsigned OOB = 0xFFFFFFF0u;
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+template <int CPRT> __device__ inline int swz_t(int row, int chunk) {
+  return CPRT == 8 ? row * 8 + (chunk ^ ((row >> 1) & 7)) : row * 4 + (chunk ^ ((row >> 2) & 3));
+}
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
+// raw buffer descriptor (stride 0, bounds-checked on num_records bytes), built from wave-uniform values only
+__device__ inline v4i32 make_desc(const void* base, size_t bytes) {
+  const unsigned long long b = (unsigned long long)base;
+  v4i32 d;
+  d[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)(b & 0xFFFFFFFFull));
+  d[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)((b >> 32) & 0xFFFFull));
+  d[2] = __builtin_amdgcn_readfirstlane((int)(bytes > 0xFFFFFFE0ull ? 0xFFFFFFE0u : (unsigned)bytes));
+  d[3] = 0x00020000;
+  return d;
+}
+
+// one LDS-DMA wave instruction, invisible to hipcc's waitcnt pass (it would otherwise drain vmcnt(0) before every
+// ds_read of the same array): LDS[m0 + lane*16 .. +16) = desc[voff .. voff+16), zeros when voff is out of range.
+// Completion is tracked by the caller's counted s_waitcnt vmcnt.  M0 is saved once before a group of DMAs and restored
+// after it (m0_save / m0_restore): hipcc emits no M0-dependent instruction inside these kernels (checked in the
+// disassembly), the bracket keeps that assumption local to the address arithmetic between two DMAs of one group.
+__device__ inline unsigned m0_save() {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0" : "=s"(keep)::"memory");
+  return keep;
+}
+__device__ inline void m0_restore(unsigned keep) { asm volatile("s_mov_b32 m0, %0" ::"s"(keep) : "memory"); }
+__device__ inline void dma16(v4i32 desc, unsigned voff, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"(voff), "s"(desc), "s"(lds_addr) : "memory");
+}
+
+// tap (i, j) reads source pixel (hb + dh_i, wb + dw_j): in range iff its row AND its column are, so nth + ntw checks per
+// output row, on lists fetched from LDS ONCE per thread (14 independent reads, one wait): per-row LDS reads serialise on
+// their s_waitcnt and made this setup 2.4 us of a 41 us tile
+constexpr int MAX_GRID = 7;                    // MAX_TAPS = 7 x 7
+struct TapGrid { int dh[MAX_GRID], dw[MAX_GRID]; };
+__device__ inline void load_tap_grid(const IgemmArgs& a, const int* taps, TapGrid& g) {
+#pragma unroll
+  for (int j = 0; j < MAX_GRID; ++j) {
+    const int v = taps[128 + j];
+    g.dw[j] = j < a.ntw ? (int)(short)(v & 0xFFFF) : 0x4000;
+  }
+#pragma unroll
+  for (int i = 0; i < MAX_GRID; ++i) {
+    const int v = taps[128 + min(i * a.ntw, 63)];
+    g.dh[i] = i < a.nth ? (v >> 16) : 0x4000;
+  }
+}
+__device__ inline unsigned long long tap_mask(const IgemmArgs& a, const TapGrid& g, int hb, int wb) {
+  // the loop bounds are wave-uniform (scalar branches): a 1x1 kernel runs 1 + 1 checks, a 3x3 kernel 3 + 3
+  unsigned colbits = 0;
+#pragma unroll
+  for (int j = 0; j < MAX_GRID; ++j) {
+    if (j >= a.ntw) break;
+    if ((unsigned)(wb + g.dw[j]) < (unsigned)a.Ws) colbits |= 1u << j;
+  }
+  unsigned long long mk = 0;
+  int sh = 0;
+#pragma unroll
+  for (int i = 0; i < MAX_GRID; ++i) {
+    if (i >= a.nth) break;
+    if ((unsigned)(hb + g.dh[i]) < (unsigned)a.Hs) mk |= (unsigned long long)colbits << sh;
+    sh += a.ntw;
+  }
+  return mk;
+}
+
+// position of one logical 16-byte chunk column of a lane in the GEMM-K order (tap-major, then channel chunks), advanced
+// by one K tile per call.  The tap-table lookups for the NEXT tile are issued at the end of advance(): their LDS latency
+// then sits behind a whole K tile of MFMAs instead of in front of the DMA issue.
+template <int CPRT> struct TapWalk {
+  int tapk, cck, tp;
+  unsigned so, wo;
+  bool kv;
+  __device__ inline void fetch(const IgemmArgs& a, const int* taps) {
+    kv = tapk < a.nt;
+    tp = kv ? tapk : 0;
+    so = (unsigned)(taps[tp] + cck * 16);
+    wo = (unsigned)(taps[64 + tp] + cck * 16);
+  }
+  __device__ inline void init(const IgemmArgs& a, const int* taps, int c0) {
+    cck = c0; tapk = 0;
+    while (cck >= a.cpt) { cck -= a.cpt; ++tapk; }
+    fetch(a, taps);
+  }
+  __device__ inline void advance(const IgemmArgs& a, const int* taps) {
+    cck += CPRT;
+    if (a.cpt >= CPRT) {                       // wave-uniform: at most one tap boundary per K tile
+      const bool w = cck >= a.cpt;
+      cck -= w ? a.cpt : 0;
+      tapk += w ? 1 : 0;
+    } else {
+      while (cck >= a.cpt) { cck -= a.cpt; ++tapk; }
+    }
+    fetch(a, taps);
+  }
+};
+
+// walk serving DMA slot j: slot parity selects the chunk column.  Field-wise selects on CONSTANT indices: a dynamically
+// indexed struct array goes to scratch memory (hipcc), which put a scratch load + vmcnt(0) in front of every DMA.
+template <int CPRT, int NST>
+__device__ inline void pick_walk(const TapWalk<CPRT> (&walk)[NST], int j, bool& kv, int& tp, unsigned& so, unsigned& wo) {
+  if constexpr (NST == 2) {
+    const bool odd = (j & 1) != 0;
+    kv = odd ? walk[1].kv : walk[0].kv;
+    tp = odd ? walk[1].tp : walk[0].tp;
+    so = odd ? walk[1].so : walk[0].so;
+    wo = odd ? walk[1].wo : walk[0].wo;
+  } else {
+    kv = walk[0].kv; tp = walk[0].tp; so = walk[0].so; wo = walk[0].wo;
+  }
+}
+
+template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+}  // namespace
+
+// conv_igemm8.hip: 256-row tiles on the eight-phase schedule; returns -1 when the geometry is not one it covers (the caller falls back)
+int rn_launch_igemm8(const IgemmArgs& a, int dtype, hipStream_t s);

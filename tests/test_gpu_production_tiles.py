@@ -246,3 +246,55 @@ def test_wgrad_exact_integers():
     torch.cuda.synchronize()
     ref = torch.nn.grad.conv2d_weight(_nchw(torch.from_numpy(xv)), (K, C, 3, 3), _nchw(torch.from_numpy(dv)), 1, 1).permute(0, 2, 3, 1)
     assert torch.equal(eng.tensors[sl['dw']].cpu(), ref.contiguous())
+
+
+IGEMM8 = 1 << 22                     # rn_set_variant: the eight-phase 256-row kernel wherever the geometry allows
+IGEMM8_SMALL = [
+    (2, 16, 16, 256, 256, 3, 1, 1),      # two row tiles, forward and data gradient, 36 K tiles
+    (2, 16, 16, 64, 256, 3, 1, 1),       # one 64-channel chunk per tap (forward only: the data gradient has 64 output channels)
+    (3, 14, 14, 256, 512, 1, 1, 0),      # 1x1, two column tiles, row tail (588 = 2 x 256 + 76), 4 K tiles
+    (2, 8, 8, 64, 256, 1, 1, 0),         # ONE K tile (prologue only)
+    (2, 8, 8, 128, 256, 1, 1, 0),        # two K tiles (no steady-state iteration)
+    (2, 8, 8, 192, 256, 1, 1, 0),        # three K tiles (one steady-state iteration)
+    (2, 28, 28, 256, 256, 3, 2, 1),      # stride 2: forward on the 14 x 14 grid, data gradient as four parity classes
+    (2, 14, 14, 512, 256, 1, 2, 0),      # stride-2 projection shortcut
+    (5, 7, 7, 64, 256, 3, 1, 1),         # images of 49 pixels straddle the 256-row tile; padding taps on every side
+    (1, 7, 7, 128, 512, 3, 1, 1),        # a single, mostly empty row tile
+]
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('g', IGEMM8_SMALL)
+def test_igemm8_on_small_geometries(g, dtype):
+    """the eight-phase kernel (conv_igemm8.hip) forced onto small shapes that exercise its prologue / tail modes, row tails, strides and
+    parity classes; fused epilogues as in every case of this file."""
+    ran = run_conv_case(g, dtype, variant=IGEMM8)
+    assert ran[0] == 'igemm8<256x256>', ran
+    if g[3] % 256 == 0 and not (g[5] == 1 and g[6] == 2):          # (a stride-2 1x1 layer has three parity classes without any tap: plain zero-fill launches)
+        assert all(n == 'igemm8<256x256>' for n in ran if n.startswith('igemm')), ran
+
+
+@pytest.mark.parametrize('g', [(2, 16, 16, 128, 256, 3, 1, 1), (3, 14, 14, 64, 256, 1, 1, 0)])
+def test_igemm8_exact_integers(g):
+    """integer operands: the eight-phase kernel must equal the reference bit for bit (fragment <-> pixel / channel maps, tap walk, stage toggling)."""
+    N, Hh, W, C, K, k, s_, p = g
+    eng, sl = _one_op_engine(ir.OP_CONV_FWD, g, dict(x=((N, Hh, W, C), 'T'), w_fwd=((K, k * k, C), 'T'), y=((N, Hh, W, K), 'T')))
+    rng = np.random.RandomState(2)
+    xv = rng.randint(-2, 3, size=(N, Hh, W, C)).astype(np.float32)
+    wv = rng.randint(-1, 2, size=(K, k, k, C)).astype(np.float32)
+    eng.tensors[sl['x']].copy_(torch.from_numpy(xv).to(torch.float16))
+    eng.tensors[sl['w_fwd']].copy_(torch.from_numpy(wv).reshape(K, k * k, C).to(torch.float16))
+    eng.bind({})
+    L = _lib.lib()
+    L.rn_set_variant(IGEMM8)
+    try:
+        L.rn_kernel_log(1)
+        eng.run(0, 1, 0)
+        torch.cuda.synchronize()
+        assert 'igemm8<256x256>' in L.rn_kernel_log_read().decode()
+    finally:
+        L.rn_kernel_log(0)
+        L.rn_set_variant(0)
+    ref = torch.nn.functional.conv2d(_nchw(torch.from_numpy(xv)), torch.from_numpy(wv).permute(0, 3, 1, 2), padding=p).permute(0, 2, 3, 1)
+    assert float(ref.abs().max()) < 2048
+    assert torch.equal(eng.tensors[sl['y']].float().cpu(), ref.contiguous())
