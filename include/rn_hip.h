@@ -105,7 +105,9 @@ void rn_set_variant(int v);
 /* which convolution kernel ran: rn_kernel_log(1) starts (and clears) a per-thread log of the instantiations the conv launchers
  * pick ("igemm_dma<128x160>", "wgrad<160x160>", ...), rn_kernel_log_read() returns them comma-separated, rn_kernel_log(0) stops.
  * rn_conv_kernel_names: the names a geometry WOULD select (pass 0 forward, 1 dgrad, 2 wgrad), without launching anything
- * (host-only: works without a GPU) -- the tests use it to prove that every tile a BASELINE config selects is parity-tested */
+ * (host-only: works without a GPU) -- the tests use it to prove that every tile a BASELINE config selects is parity-tested.
+ * fused_epilogue names the launch's operand set (kernels may be specialised per set): 1 = fused BatchNorm sums (forward: statistics of the
+ * output; data gradient: the backward sums over x and the mask), 2 = identity residual, 4 = accumulate into dx */
 void rn_kernel_log(int enable);
 const char* rn_kernel_log_read(void);
 struct rn_conv_geom;

@@ -671,9 +671,13 @@ template <typename T, int BN> int launch_patch128(const IgemmArgs& a, hipStream_
   return 0;
 }
 
-// where the eight-phase kernel is the default (measured per shape family: DESIGN.md section 6, round 3)
+// where the eight-phase kernel is the default (measured on the WRN-50-2 shapes at batch 256, forward and data gradient, per-op times inside the model:
+// DESIGN.md section 6, round 3): every geometry it covers with a specialised epilogue, once the grid holds enough 256 x 256 tiles to occupy the chip
+// (one persistent workgroup per CU).  Parity classes of stride-2 data gradients (strided destination) stay on the 128-row kernels.
 static bool igemm8_rule(const IgemmArgs& a) {
-  return false;
+  if (a.Cs % 64 || a.Kd % 256) return false;
+  const long tiles = (long)cdiv(a.M, 256) * (a.Kd / 256);
+  return tiles >= 160 && rn_igemm8_fast(a);
 }
 
 template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {

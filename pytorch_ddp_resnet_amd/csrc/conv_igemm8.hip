@@ -1,4 +1,4 @@
-// Implicit-GEMM convolution on the EIGHT-PHASE schedule (gfx950), 16-bit element types: 256 x BN block tiles, 8 waves, one workgroup per CU.
+// Implicit-GEMM convolution on the EIGHT-PHASE schedule (gfx950), 16-bit element types: 256 x BN block tiles, 8 waves, one PERSISTENT workgroup per CU.
 //
 // Same contraction and tap-table view as conv_igemm.hip (forward conv and data gradient of residual_block.py:34-57, :129-159),
 //   dst[n, p*ds+oh, q*ds+ow, k] (+)= sum_t sum_c src[n, p*ss+dh[t], q*ss+dw[t], c] * wt[k][widx[t]][c]   (+ res),
@@ -6,9 +6,9 @@
 // implicit-GEMM operand walk:
 //   * a K tile = one tap x 64 channels (128-byte rows); per K tile the A tile (256 pixels) and the B tile (BN output channels) are each
 //     split in two HALF-TILES = what one quadrant row / column of every wave's output block reads;
-//   * a wave owns 128 x 64 outputs (BN = 256; 64 x 64 at BN = 128) as four quadrants; one PHASE = the fragment reads of one half-tile,
-//     the LDS-DMA of one half-tile two K tiles ahead, and the MFMAs of one quadrant x 64 channels (v_mfma_f32_16x16x32), i.e. four
-//     phases per K tile; both LDS stages of every half-tile live in ONE array (128 KiB);
+//   * a wave owns 128 x 64 outputs as four quadrants; one PHASE = the fragment reads of one half-tile, the LDS-DMA of one half-tile two K
+//     tiles ahead, and the MFMAs of one quadrant x 64 channels (v_mfma_f32_16x16x32), i.e. four phases per K tile; both LDS stages of every
+//     half-tile live in ONE array (128 KiB);
 //   * the two wave groups (waves 0-3 / 4-7, the two waves of each SIMD) run the same program ONE BARRIER apart, so one group's MFMA
 //     segment covers the other's LDS reads and DMA issue;
 //   * DMAs stay in flight across barriers: a counted s_waitcnt vmcnt once per K tile (three half-tiles remain outstanding), raw s_barrier.
@@ -19,7 +19,16 @@
 //        C segment), or ONE phase after when a counted lgkmcnt in front of the reading phase's closing barrier retired them (the B reads
 //        of phase 1 are issued first and retired by lgkmcnt(<A reads>)).
 // The taps are walked with scalar adds (IgemmArgs.w8_*: a separable arithmetic progression, checked on the host), padding taps and row
-// tails are out-of-range DMA offsets that the hardware zero-fills.  Epilogue: igemm_epilogue of igemm_shared.h (16x16 accumulator tiles).
+// tails are out-of-range DMA offsets that the hardware zero-fills.
+//
+// MFMA orientation and epilogue.  The products are taken TRANSPOSED (weights as the A operand, pixels as B): a lane then holds, per 16 x 16 tile,
+// FOUR CONSECUTIVE CHANNELS of one pixel.  A 4 x 4 transpose across the wave's four 16-lane rows (v_permlane32_swap + v_permlane16_swap, fp32)
+// gives every lane 16 consecutive channels of its pixel = two 16-byte chunks, so the accumulators go to global memory straight from registers:
+// no LDS staging, no workgroup barrier, every fused operand (bias, residual, accumulate, BatchNorm-backward x / mask) a 16-byte access in the
+// same layout, the BatchNorm sums reduced over a lane row by DPP adds into ONE partial row per wave (a wave = 128 output rows = one row of
+// the [rows][2][K] partial-sum buffer).
+// Because the epilogue needs no LDS the workgroup is persistent: it walks its tiles, and the first K tiles of tile i+1 are already in flight
+// (LDS-DMA) while the waves store tile i.
 #include "igemm_shared.h"
 
 namespace {
@@ -35,65 +44,326 @@ struct Walk8 {          // scalar position of one K tile: tap bit, source / weig
   int i, j, cc, t;
   unsigned src, wt;
 };
-__device__ inline void walk8_advance(const IgemmArgs& a, Walk8& w) {
+// the walk's constants, held in scalar registers for the kernel's lifetime (the K loop must not re-read kernel arguments: a scalar load inside
+// it would sit in the same counter as the fragment reads)
+struct Walk8K { int cpc, ntw; unsigned dsj, dsi, dwj, dwi; };
+__device__ inline void walk8_advance(const Walk8K& k, Walk8& w) {
   w.cc += 1; w.src += 128u; w.wt += 128u;
-  if (w.cc == a.w8_cpc) {
+  if (w.cc == k.cpc) {
     w.cc = 0; w.j += 1; w.t += 1;
-    w.src += (unsigned)(a.w8_sj - a.w8_cpc * 128); w.wt += (unsigned)(a.w8_wj - a.w8_cpc * 128);
-    if (w.j == a.ntw) {
+    w.src += k.dsj; w.wt += k.dwj;
+    if (w.j == k.ntw) {
       w.j = 0; w.i += 1;
-      w.src += (unsigned)(a.w8_si - a.ntw * a.w8_sj); w.wt += (unsigned)(a.w8_wi - a.ntw * a.w8_wj);
+      w.src += k.dsi; w.wt += k.dwi;
+    }
+  }
+}
+__device__ inline void walk8_seek(const IgemmArgs& a, Walk8& w, int g) {      // K tile g = (tap g / cpc, chunk g % cpc)
+  const int tap = g / a.w8_cpc;
+  w.cc = g - tap * a.w8_cpc; w.t = tap;
+  w.i = tap / a.ntw; w.j = tap - w.i * a.ntw;
+  w.src = (unsigned)(a.w8_src0 + w.i * a.w8_si + w.j * a.w8_sj + w.cc * 128);
+  w.wt = (unsigned)(a.w8_wt0 + w.i * a.w8_wi + w.j * a.w8_wj + w.cc * 128);
+}
+
+// ---- lane-row transposes (all 64 lanes active) ----
+__device__ inline void swap32(float& d, float& s) {       // rows 2,3 of d <-> rows 0,1 of s
+  const auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, d), __builtin_bit_cast(unsigned, s), false, false);
+  d = __builtin_bit_cast(float, (unsigned)r[0]); s = __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ inline void swap16(float& d, float& s) {       // rows 1,3 of d <-> rows 0,2 of s
+  const auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, d), __builtin_bit_cast(unsigned, s), false, false);
+  d = __builtin_bit_cast(float, (unsigned)r[0]); s = __builtin_bit_cast(float, (unsigned)r[1]);
+}
+__device__ inline void swap32u(unsigned& d, unsigned& s) {
+  const auto r = __builtin_amdgcn_permlane32_swap(d, s, false, false);
+  d = r[0]; s = r[1];
+}
+__device__ inline void swap16u(unsigned& d, unsigned& s) {
+  const auto r = __builtin_amdgcn_permlane16_swap(d, s, false, false);
+  d = r[0]; s = r[1];
+}
+__device__ inline void xpose4u(unsigned& x0, unsigned& x1, unsigned& x2, unsigned& x3) {
+  swap32u(x0, x2); swap32u(x1, x3);
+  swap16u(x0, x1); swap16u(x2, x3);
+}
+// in: x_c on lane row q = M[q][c]; out: x_s on lane row q = M[s][q]
+__device__ inline void xpose4(float& x0, float& x1, float& x2, float& x3) {
+  swap32(x0, x2); swap32(x1, x3);
+  swap16(x0, x1); swap16(x2, x3);
+}
+// sum over the 16 lanes of a row, result in every lane: xor 1, xor 2 (quad permutes), half-row mirror, row mirror
+__device__ inline float row_sum16(float x) {
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0xB1, 0xF, 0xF, true));    // quad_perm [1,0,3,2]
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x4E, 0xF, 0xF, true));    // quad_perm [2,3,0,1]
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x141, 0xF, 0xF, true));   // row_half_mirror
+  x += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), 0x140, 0xF, 0xF, true));   // row_mirror
+  return x;
+}
+
+// ---- epilogue: a wave stores its 16 RT x 64 block from registers.  acc[pt][ct][r] = pixel mw + 16 pt + (lane & 15), channel kw + 16 ct + 4 (lane >> 4) + r ----
+// Specialised per operand set (compile-time MODE, picked once per launch): with the flags at run time inside one unrolled body the register
+// allocator has to cover the union of all operand sets next to the 128 accumulator registers and spills.
+//   EP8_PLAIN        dense destination, no fused operand (forward convolutions; optional BatchNorm statistics)
+//   EP8_RES          + identity residual (the block's last convolution)
+//   EP8_BNB [+ RES | + ACC]   dense destination + BatchNorm-backward sums over (x, mask); with the shortcut gradient as identity residual, or
+//                    accumulating into the destination (the three forms the block backward of residual_block.py:67-99, :173-215 lowers to)
+//   EP8_GEN          everything else, flags at run time: strided destination (parity classes of a stride-2 data gradient), pad / subsample
+//                    residuals, bias, sums without a mask (slow path: it spills)
+enum { EP8_PLAIN = 0, EP8_RES = 1, EP8_ACC = 2, EP8_BNB = 4, EP8_GEN = 8 };
+
+template <typename T, int RT, int MODE>
+__device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw, int kw, int lane, float* lds_mean) {
+  constexpr int CE = 8;
+  constexpr bool GEN = MODE == EP8_GEN;
+  constexpr bool C_RES = (MODE & EP8_RES) != 0, C_ACC = (MODE & EP8_ACC) != 0, C_BNB = (MODE & EP8_BNB) != 0;
+  constexpr int D = MODE == EP8_RES ? 2 : 1;     // pixel tiles of operand loads in flight ahead of the one being processed (registers decide)
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int kc = kw + 16 * lq;                   // after the transpose this lane owns channels kc .. kc + 15 of its pixel
+  T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
+  const bool dense = !GEN || ((a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME));
+  const bool want_stats = a.stats != nullptr;
+  const bool bn_bwd = C_BNB || (GEN && want_stats && a.bn_x != nullptr);
+  const bool has_mask = C_BNB || (GEN && a.bn_mask != nullptr);
+  const bool res_same = C_RES || (GEN && a.res.mode == RN_RES_SAME);
+  const bool accum = C_ACC || (GEN && a.accum);
+  const int pq = a.Pc * a.Qc;
+  float s0[16], s1[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) s0[e] = s1[e] = 0.f;
+
+  auto transposed = [&](int pt, float (&v)[16]) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float x0 = acc[pt][0][r], x1 = acc[pt][1][r], x2 = acc[pt][2][r], x3 = acc[pt][3][r];
+      xpose4(x0, x1, x2, x3);
+      v[r] = x0; v[4 + r] = x1; v[8 + r] = x2; v[12 + r] = x3;
+    }
+  };
+  auto round_store = [&](size_t off, const float (&v)[16], Chunk<T> (&st)[2]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e) st[c].e[e] = Elem<T>::from_f(v[c * CE + e]);
+      store_chunk<T>(dst + off + c * CE, st[c]);
+    }
+  };
+
+  if constexpr (MODE == EP8_PLAIN) {
+    // nothing is added to the accumulators: round FIRST, then transpose the packed pairs -- half the lane exchanges
+#pragma unroll
+    for (int pt = 0; pt < RT; ++pt) {
+      Chunk<T> st[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        unsigned x[4];
+#pragma unroll
+        for (int ct = 0; ct < 4; ++ct) {
+          union { T e[2]; unsigned u; } pk;
+          pk.e[0] = Elem<T>::from_f(acc[pt][ct][2 * h]); pk.e[1] = Elem<T>::from_f(acc[pt][ct][2 * h + 1]);
+          x[ct] = pk.u;
+        }
+        xpose4u(x[0], x[1], x[2], x[3]);           // x[s] = channels 16 lq + 4 s + 2 h + {0, 1}
+        st[0].u.x = h == 0 ? x[0] : st[0].u.x; st[0].u.y = h == 1 ? x[0] : st[0].u.y;
+        st[0].u.z = h == 0 ? x[1] : st[0].u.z; st[0].u.w = h == 1 ? x[1] : st[0].u.w;
+        st[1].u.x = h == 0 ? x[2] : st[1].u.x; st[1].u.y = h == 1 ? x[2] : st[1].u.y;
+        st[1].u.z = h == 0 ? x[3] : st[1].u.z; st[1].u.w = h == 1 ? x[3] : st[1].u.w;
+      }
+      const int m = mw + 16 * pt + l16;
+      if (m < a.M) {
+        T* o = dst + (size_t)m * a.Kd + kc;
+        store_chunk<T>(o, st[0]);
+        store_chunk<T>(o + CE, st[1]);
+        if (want_stats) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) { const float vs = Elem<T>::to_f(st[e / CE].e[e % CE]); s0[e] += vs; s1[e] += vs * vs; }
+        }
+      }
+    }
+  } else {
+    // BatchNorm-backward second sum: sum g * xhat = invstd * sum g * (x - mean): only the mean is held per channel, invstd multiplies the row sum
+    // The means of this lane row's 16 channels are parked in a wave-private corner of LDS (64 floats per wave) and re-read per pixel tile: sixteen
+    // registers the BatchNorm-backward specialisations do not have (LDS reads do not touch vmcnt; a scratch reload would wait for the stores in flight).
+    float* lm = lds_mean + 16 * lq;
+    if (bn_bwd) {
+      if (l16 < 4) *reinterpret_cast<float4*>(lm + 4 * l16) = *reinterpret_cast<const float4*>(a.bn_coef + 2 * a.Kd + kc + 4 * l16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // same wave writes and reads: program order + the wait
+    }
+    struct Ops { bool ok; size_t off; int n, hd, wd; Chunk<T> cr[2], co[2], cx[2], cm[2]; };
+    auto fetch = [&](int pt, Ops& o) {
+      const int m = mw + 16 * pt + l16;
+      o.ok = m < a.M;
+      o.n = o.hd = o.wd = 0; o.off = 0;
+      if (!o.ok) return;
+      size_t pix;
+      if (dense) {
+        pix = (size_t)m;
+      } else {
+        int pp, q;
+        decode_row(a, m, pq, o.n, pp, q);
+        o.hd = pp * a.ds + a.oh;
+        o.wd = q * a.ds + a.ow;
+        pix = ((size_t)o.n * a.Hd + o.hd) * a.Wd + o.wd;
+      }
+      o.off = pix * a.Kd + kc;
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        if (res_same) o.cr[c] = load_chunk<T>(reinterpret_cast<const T*>(a.res.ptr) + o.off + c * CE);
+        if (accum) o.co[c] = load_chunk<T>(dst + o.off + c * CE);
+        if (bn_bwd) {
+          o.cx[c] = load_chunk<T>(reinterpret_cast<const T*>(a.bn_x) + o.off + c * CE);
+          if (has_mask) o.cm[c] = load_chunk<T>(reinterpret_cast<const T*>(a.bn_mask) + o.off + c * CE);
+        }
+      }
+    };
+    Ops ops[RT];
+#pragma unroll
+    for (int pt = 0; pt < D && pt < RT; ++pt) fetch(pt, ops[pt]);
+#pragma unroll
+    for (int pt = 0; pt < RT; ++pt) {
+      if (pt + D < RT) fetch(pt + D, ops[pt + D]);
+      float v[16];
+      transposed(pt, v);
+      const Ops& o = ops[pt];
+      if (o.ok) {
+        if (GEN && a.bias) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += a.bias[kc + e];
+        }
+        if (res_same) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += Elem<T>::to_f(o.cr[e / CE].e[e % CE]);
+        } else if (GEN && a.res.mode != RN_RES_NONE) {
+          res_add_chunk<T>(a.res, o.n, o.hd, o.wd, kc, v);
+          res_add_chunk<T>(a.res, o.n, o.hd, o.wd, kc + CE, v + CE);
+        }
+        if (accum) {
+#pragma unroll
+          for (int e = 0; e < 16; ++e) v[e] += Elem<T>::to_f(o.co[e / CE].e[e % CE]);
+        }
+        Chunk<T> st[2];
+        round_store(o.off, v, st);
+        if (want_stats) {
+          if (!bn_bwd) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) { const float vs = Elem<T>::to_f(st[e / CE].e[e % CE]); s0[e] += vs; s1[e] += vs * vs; }
+          } else {
+#pragma unroll
+            for (int e4 = 0; e4 < 16; e4 += 4) {
+              const float4 mu = *reinterpret_cast<const float4*>(lm + e4);
+              const float mean[4] = {mu.x, mu.y, mu.z, mu.w};
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int e = e4 + u;
+                float g = Elem<T>::to_f(st[e / CE].e[e % CE]) * a.gscale;
+                if (has_mask && !(Elem<T>::to_f(o.cm[e / CE].e[e % CE]) > 0.f)) g = 0.f;
+                s0[e] += g; s1[e] += g * (Elem<T>::to_f(o.cx[e / CE].e[e % CE]) - mean[u]);
+              }
+            }
+          }
+        }
+      }
+    }
+  }
+  if (want_stats) {                              // one partial row per wave (16 RT = RN_CONV_STATS_ROWS output rows)
+    static_assert(16 * RT == RN_CONV_STATS_ROWS, "a wave's block is one partial-sum row");
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { s0[e] = row_sum16(s0[e]); s1[e] = row_sum16(s1[e]); }
+    if (bn_bwd) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) s1[e] *= a.bn_coef[3 * a.Kd + kc + e];
+    }
+    if (l16 == 0 && mw < a.M) {
+      float* out = a.stats + ((size_t)(a.tile_base + mw / RN_CONV_STATS_ROWS) * 2) * a.Kd + kc;
+#pragma unroll
+      for (int e = 0; e < 16; e += 4) {
+        *reinterpret_cast<float4*>(out + e) = make_float4(s0[e], s0[e + 1], s0[e + 2], s0[e + 3]);
+        *reinterpret_cast<float4*>(out + a.Kd + e) = make_float4(s1[e], s1[e + 1], s1[e + 2], s1[e + 3]);
+      }
     }
   }
 }
 
-template <typename T, int BN>
+// the launch's epilogue specialisation (host and device agree: the launcher's rule reads it too)
+__host__ __device__ inline int ep8_mode(const IgemmArgs& a) {
+  const bool dense = (a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME) && !a.bias;
+  if (!dense) return EP8_GEN;
+  const bool res = a.res.mode == RN_RES_SAME, acc = a.accum != 0;
+  if (a.stats != nullptr && a.bn_x != nullptr) {
+    if (!a.bn_mask || (res && acc)) return EP8_GEN;
+    return EP8_BNB | (res ? EP8_RES : 0) | (acc ? EP8_ACC : 0);
+  }
+  if (acc) return EP8_GEN;
+  return res ? EP8_RES : EP8_PLAIN;
+}
+
+template <typename T, int BN, int EPM>
 __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
   constexpr int BM = 256, ES = 2;
-  constexpr int WM = BN == 256 ? 2 : 4, WN = 8 / WM;        // 2 x 4 waves of 128 x 64, or 4 x 2 waves of 64 x 64
+  constexpr int WM = 2, WN = 4;                             // 2 x 4 waves of 128 x 64
   constexpr int WTM = BM / WM, WTN = BN / WN;
-  constexpr int RT = WTM / 16, CT = WTN / 16;               // 16 x 16 accumulator tiles of a wave
+  constexpr int RT = WTM / 16, CT = WTN / 16;               // 16 x 16 accumulator tiles of a wave: pixel tiles x channel tiles
   constexpr int QR = RT / 2, QC = CT / 2;                   // ... of a quadrant
   constexpr int HR = WTM / 2, HC = WTN / 2;                 // rows / columns of a wave's quadrant
   constexpr int AI = 2, BI = BN / 128;                      // DMA instructions per wave and half-tile (A: 128 rows, B: BN/2 rows)
   constexpr int STG = 4096;                                 // uint4 per stage: 64 KiB (A0 | A1 | B0 | B1), power of two: the stage toggles by XOR
   constexpr int A_H = 1024, B_0 = 2048, B_H = BN * 4;       // uint4 offsets: second A half, B, second B half
-  static_assert(sizeof(T) == ES && (BN == 256 || BN == 128) && B_0 + 2 * B_H <= STG, "tile");
-  __shared__ uint4 smem[2 * STG + TAP_INTS / 4];
+  static_assert(sizeof(T) == ES && BN == 256 && CT == 4 && B_0 + 2 * B_H <= STG, "tile");
+  __shared__ uint4 smem[2 * STG + TAP_INTS / 4 + 8 * 16];
   int* taps = reinterpret_cast<int*>(&smem[2 * STG]);
 
-  preload_args(a);
-  asm volatile("" ::"s"(a.w8_src0), "s"(a.w8_si), "s"(a.w8_sj), "s"(a.w8_wt0), "s"(a.w8_wi), "s"(a.w8_wj), "s"(a.w8_cpc));
+  // (no blanket preload of the kernel arguments: this kernel is persistent and its epilogues read many of them -- held in SGPRs across the whole
+  // kernel they spill into VGPR lanes, which the K loop cannot afford; only what the K loop reads is pinned)
+  Walk8K wkk;
+  wkk.cpc = a.w8_cpc; wkk.ntw = a.ntw;
+  wkk.dsj = (unsigned)(a.w8_sj - a.w8_cpc * 128); wkk.dwj = (unsigned)(a.w8_wj - a.w8_cpc * 128);
+  wkk.dsi = (unsigned)(a.w8_si - a.ntw * a.w8_sj); wkk.dwi = (unsigned)(a.w8_wi - a.ntw * a.w8_wj);
+  asm volatile("" : "+s"(wkk.cpc), "+s"(wkk.ntw), "+s"(wkk.dsj), "+s"(wkk.dwj), "+s"(wkk.dsi), "+s"(wkk.dwi));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int nmt = (a.M + BM - 1) / BM;
-  int bid = blockIdx.x;
-  if (a.xcd_remap) {
-    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  const int nnt_ = gridDim.x / nmt;
-  const int ntile = a.xcd_remap ? bid % nnt_ : bid / nmt, mt = a.xcd_remap ? bid / nnt_ : bid % nmt;
-  const int m0 = mt * BM, n0 = ntile * BN;
+  const int nmt = (a.M + BM - 1) / BM, nnt = a.Kd / BN, ntiles = nmt * nnt;
   const int pq = a.Pc * a.Qc;
-  const int n_first = m0 / pq;
   const size_t img_bytes = (size_t)a.Hs * a.Ws * a.Cs * ES;
-  const v4i32 ra_desc = make_desc(reinterpret_cast<const char*>(a.src) + (size_t)n_first * img_bytes, (size_t)(a.N - n_first) * img_bytes);
   const v4i32 rb_desc = make_desc(a.wt, (size_t)a.Kd * a.wrs * a.Cs * ES);
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);
+  const int nk = a.nk;
+  float* lds_mean = reinterpret_cast<float*>(&smem[2 * STG + TAP_INTS / 4 + wave * 16]);     // 64 floats per wave (epilogue8)
+  // the launch's epilogue specialisation (wave-uniform, from the kernel arguments)
 
   fill_tap_tables<ES>(a, taps);
   __syncthreads();
+  TapGrid grid;
+  load_tap_grid(a, taps, grid);
+#pragma unroll
+  for (int i = 0; i < MAX_GRID; ++i) {                      // wave-uniform: keep the tap grid in scalar registers for the kernel's lifetime
+    grid.dh[i] = __builtin_amdgcn_readfirstlane(grid.dh[i]);
+    grid.dw[i] = __builtin_amdgcn_readfirstlane(grid.dw[i]);
+  }
 
-  // ---- DMA roles.  One instruction = 8 LDS rows x 128 B; instruction q of a half-tile covers its LDS rows 8q .. 8q+7; lane = (row lrow, physical
-  // chunk p), which holds logical chunk p ^ ((row >> 1) & 7) (the XOR goes on the SOURCE address, the destination is lane-linear).
-  // A half h, LDS row r  <->  tile row (r / HR) * WTM + h * HR + r % HR;  B half h, LDS row r  <->  tile column (r / HC) * WTN + h * HC + r % HC.
+  // ---- fragment addresses (uint4 units inside a stage): 16 consecutive LDS rows at chunk (4 ks + lq) ^ ((row >> 1) & 7); the row bases are multiples of 16
+  const int wm = wave / WN, wn = wave % WN;
+  const int l16 = lane & 15, lq = lane >> 4;
+  const int sw = (l16 >> 1) & 7;
+  const int fa0 = (wm * HR + l16) * 8 + (lq ^ sw), fa1 = (wm * HR + l16) * 8 + ((4 + lq) ^ sw);
+  const int fb0 = B_0 + (wn * HC + l16) * 8 + (lq ^ sw), fb1 = B_0 + (wn * HC + l16) * 8 + ((4 + lq) ^ sw);
   const int lrow = lane >> 3, p = lane & 7;
+
+  // ---- per-tile DMA roles.  One instruction = 8 LDS rows x 128 B; instruction q of a half-tile covers its LDS rows 8q .. 8q+7; lane = (row lrow,
+  // physical chunk p), which holds logical chunk p ^ ((row >> 1) & 7) (the XOR goes on the SOURCE address, the destination is lane-linear).
+  // A half h, LDS row r  <->  tile row (r / HR) * WTM + h * HR + r % HR;  B half h, LDS row r  <->  tile column (r / HC) * WTN + h * HC + r % HC.
   unsigned abase[2 * AI];
   unsigned amask[AI];                 // two 16-bit tap masks per register: half 0 low, half 1 high
-  {
-    TapGrid grid;
-    load_tap_grid(a, taps, grid);
+  unsigned bbase[BI];
+  int ra_w0 = 0, ra_w1 = 0, ra_w2 = 0;   // the source descriptor of the current tile (based at its first image), as three wave-uniform words
+  const unsigned bhalf = (unsigned)((size_t)HC * a.wrs * a.Cs * ES);                      // B half 1 = the columns HC further
+  const unsigned rowb = (unsigned)(a.Cs * ES);                       // bytes of one source pixel
+  auto tile_roles = [&](int m0, int n0) {
+    int n_first = (int)__umulhi((unsigned)m0, a.magic_pq);           // m0 / pq (magic multiply + one correction, as decode_row)
+    if (m0 - n_first * pq >= pq) ++n_first;
+    {
+      const v4i32 d = make_desc(reinterpret_cast<const char*>(a.src) + (size_t)n_first * img_bytes, (size_t)(a.N - n_first) * img_bytes);
+      ra_w0 = d[0]; ra_w1 = d[1]; ra_w2 = d[2];
+    }
 #pragma unroll
     for (int jj = 0; jj < AI; ++jj) amask[jj] = 0;
 #pragma unroll
@@ -104,28 +374,33 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
         const int c = p ^ ((r >> 1) & 7);
         const int m = m0 + (r / HR) * WTM + h * HR + (r % HR);
         unsigned base = 0, mk = 0;
-        if (m < a.M) {
-          int n, pp, q;
-          decode_row(a, m, pq, n, pp, q);
-          const int hb = pp * a.ss, wb = q * a.ss;
-          base = (unsigned)((((size_t)(n - n_first) * a.Hs + hb) * a.Ws + wb) * a.Cs * ES) + (unsigned)(c * 16);
-          mk = (unsigned)tap_mask(a, grid, hb, wb) & 0xFFFFu;
+        if (m < a.M) {                                               // offsets fit 32 bits (launcher)
+          if (a.dense_src) {                                         // 1x1, stride 1: row m reads pixel m, no padding
+            base = (unsigned)(m - n_first * pq) * rowb + (unsigned)(c * 16);
+            mk = 1u;
+          } else {
+            int n, pp, q;
+            decode_row(a, m, pq, n, pp, q);
+            const int hb = pp * a.ss, wb = q * a.ss;
+            base = (unsigned)(((n - n_first) * a.Hs + hb) * a.Ws + wb) * rowb + (unsigned)(c * 16);
+            mk = (unsigned)tap_mask(a, grid, hb, wb) & 0xFFFFu;
+          }
         }
         abase[h * AI + jj] = base;
         amask[jj] |= mk << (16 * h);
       }
-  }
-  unsigned bbase[BI];
 #pragma unroll
-  for (int jj = 0; jj < BI; ++jj) {
-    const int r = 8 * (wave * BI + jj) + lrow;
-    const int c = p ^ ((r >> 1) & 7);
-    const int k = n0 + (r / HC) * WTN + (r % HC);
-    bbase[jj] = (unsigned)((size_t)k * a.wrs * a.Cs * ES) + (unsigned)(c * 16);          // Kd % BN == 0 (launcher): every column exists
-  }
-  const unsigned bhalf = (unsigned)((size_t)HC * a.wrs * a.Cs * ES);                      // B half 1 = the columns HC further
-
+    for (int jj = 0; jj < BI; ++jj) {
+      const int r = 8 * (wave * BI + jj) + lrow;
+      const int c = p ^ ((r >> 1) & 7);
+      const int k = n0 + (r / HC) * WTN + (r % HC);
+      bbase[jj] = (unsigned)k * (unsigned)a.wrs * rowb + (unsigned)(c * 16);          // Kd % BN == 0 (launcher): every column exists
+    }
+  };
   auto issue_a = [&](int h, unsigned stage_lds, const Walk8& w) {
+    v4i32 ra_desc;                                          // rebuilt from readfirstlane'd words: provably wave-uniform for the "s" operand
+    ra_desc[0] = __builtin_amdgcn_readfirstlane(ra_w0); ra_desc[1] = __builtin_amdgcn_readfirstlane(ra_w1);
+    ra_desc[2] = __builtin_amdgcn_readfirstlane(ra_w2); ra_desc[3] = 0x00020000;
     const unsigned keep = m0_save();
 #pragma unroll
     for (int jj = 0; jj < AI; ++jj) {
@@ -142,38 +417,9 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
     m0_restore(keep);
   };
 
-  // ---- fragment addresses (uint4 units inside a stage): 16 consecutive LDS rows at chunk (4 ks + lq) ^ ((row >> 1) & 7); the row bases are multiples of 16
-  const int wm = wave / WN, wn = wave % WN;
-  const int l16 = lane & 15, lq = lane >> 4;
-  const int sw = (l16 >> 1) & 7;
-  const int fa0 = (wm * HR + l16) * 8 + (lq ^ sw), fa1 = (wm * HR + l16) * 8 + ((4 + lq) ^ sw);
-  const int fb0 = B_0 + (wn * HC + l16) * 8 + (lq ^ sw), fb1 = B_0 + (wn * HC + l16) * 8 + ((4 + lq) ^ sw);
-
   f32x4 acc[RT][CT];
-#pragma unroll
-  for (int i = 0; i < RT; ++i)
-#pragma unroll
-    for (int j = 0; j < CT; ++j)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-
-  // ---- prologue: K tile 0 whole, then B0 / A0 / B1 of K tile 1 (the state every K tile's phase 1 starts from) ----
-  Walk8 wk;
-  wk.i = 0; wk.j = 0; wk.cc = 0; wk.t = 0; wk.src = (unsigned)a.w8_src0; wk.wt = (unsigned)a.w8_wt0;
-  const int nk = a.nk;
-  issue_b(0, lds0, wk); issue_a(0, lds0, wk); issue_b(1, lds0, wk); issue_a(1, lds0, wk);
-  walk8_advance(a, wk);
-  if (nk > 1) {
-    issue_b(0, lds0 + STG * 16, wk); issue_a(0, lds0 + STG * 16, wk); issue_b(1, lds0 + STG * 16, wk);
-    wait_vmcnt<AI + 2 * BI>();
-  } else {
-    wait_vmcnt<0>();
-  }
-  raw_barrier();
-  if (wave >= 4) raw_barrier();                           // the second wave group runs one barrier behind
-
   uint4 af[QR][2], b0[QC][2], b1[QC][2];
-  // MODE 2: K tiles kt+1 and kt+2 exist (steady state); 1: kt+1 is the last; 0: kt is the last
+  // one K tile = four phases.  MODE 2: K tiles kt+1 and kt+2 exist (steady state); 1: kt+1 is the last; 0: kt is the last
   auto ktile = [&](auto mode_tag, int sx, const Walk8& prev, const Walk8& cur) {
     constexpr int MODE = decltype(mode_tag)::value;
     const uint4* S = &smem[sx];                           // this K tile's stage
@@ -196,7 +442,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int i = 0; i < QR; ++i)
 #pragma unroll
-        for (int j = 0; j < QC; ++j) Mfma16<T>::run(af[i][ks], b0[j][ks], acc[i][j]);
+        for (int j = 0; j < QC; ++j) Mfma16<T>::run(b0[j][ks], af[i][ks], acc[i][j]);
     __builtin_amdgcn_s_setprio(0);
     raw_barrier();
     // ---- phase 2: B1 -> quadrant (0, 1); stage B0 of K tile kt+2 ----
@@ -213,7 +459,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int i = 0; i < QR; ++i)
 #pragma unroll
-        for (int j = 0; j < QC; ++j) Mfma16<T>::run(af[i][ks], b1[j][ks], acc[i][QC + j]);
+        for (int j = 0; j < QC; ++j) Mfma16<T>::run(b1[j][ks], af[i][ks], acc[i][QC + j]);
     __builtin_amdgcn_s_setprio(0);
     raw_barrier();
     // ---- phase 3: A1 -> quadrant (1, 1); stage A0 of K tile kt+2 ----
@@ -230,7 +476,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int i = 0; i < QR; ++i)
 #pragma unroll
-        for (int j = 0; j < QC; ++j) Mfma16<T>::run(af[i][ks], b1[j][ks], acc[QR + i][QC + j]);
+        for (int j = 0; j < QC; ++j) Mfma16<T>::run(b1[j][ks], af[i][ks], acc[QR + i][QC + j]);
     __builtin_amdgcn_s_setprio(0);
     raw_barrier();
     // ---- phase 4: quadrant (1, 0) from registers; stage B1 of K tile kt+2; K tile kt+1 has landed behind this wait ----
@@ -243,27 +489,79 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int i = 0; i < QR; ++i)
 #pragma unroll
-        for (int j = 0; j < QC; ++j) Mfma16<T>::run(af[i][ks], b0[j][ks], acc[QR + i][j]);
+        for (int j = 0; j < QC; ++j) Mfma16<T>::run(b0[j][ks], af[i][ks], acc[QR + i][j]);
     __builtin_amdgcn_s_setprio(0);
     raw_barrier();
   };
 
-  int sx = 0;
-  Walk8 prev = wk;                                        // K tile 1
-  for (int kt = 0; kt + 2 < nk; ++kt) {
-    walk8_advance(a, wk);                                 // K tile kt+2
-    ktile(std::integral_constant<int, 2>{}, sx, prev, wk);
-    prev = wk;
-    sx ^= STG;
-  }
-  if (nk > 1) {
-    ktile(std::integral_constant<int, 1>{}, sx, prev, wk);
-    sx ^= STG;
-  }
-  ktile(std::integral_constant<int, 0>{}, sx, prev, wk);
-  if (wave < 4) raw_barrier();                            // the first group waits for the second: every wave has executed the same barriers
+  // ---- persistent walk.  Workgroups b and b + 8 share an XCD (round-robin dispatch); the tile order is column tiles fastest, and each XCD class takes a
+  // contiguous eighth of it, its workgroups interleaved -- so the tiles in flight on one XCD at one time are neighbours: they read the same input
+  // rows / the same weights out of that XCD's L2 ----
+  const int G = gridDim.x;                                  // a multiple of 8, or ntiles (launcher)
+  int pm0 = -1, pn0 = 0;                                    // the tile whose accumulators are still in registers
+  for (int it = 0;; ++it) {
+    const int vb = it * G + blockIdx.x;
+    const bool more = vb < ntiles;                          // wave-uniform
+    int m0 = 0, n0 = 0;
+    Walk8 wk;
+    const unsigned long long* stp = it == 1 ? a.stamps : nullptr;      // diagnostic (rn_set_stamp_buffer): the workgroup's SECOND tile
+    stamp(stp, 0);
+    if (more) {
+      int tile = vb;
+      if (a.xcd_remap) {
+        const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
+        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+      }
+      int mt = (int)__umulhi((unsigned)tile, (unsigned)a.w8_magic_nnt);      // tile / nnt
+      if (tile - mt * nnt >= nnt) ++mt;
+      m0 = mt * BM; n0 = (tile - mt * nnt) * BN;
+      tile_roles(m0, n0);
+      stamp(stp, 1);
+      // prologue: K tile 0 whole, then B0 / A0 / B1 of K tile 1 (the state every K tile's phase 1 starts from).  Every wave has left the previous
+      // tile's K loop (its closing rendezvous), so both stages are free.
+      walk8_seek(a, wk, 0);
+      issue_b(0, lds0, wk); issue_a(0, lds0, wk); issue_b(1, lds0, wk); issue_a(1, lds0, wk);
+      walk8_advance(wkk, wk);
+      if (nk > 1) { issue_b(0, lds0 + STG * 16, wk); issue_a(0, lds0 + STG * 16, wk); issue_b(1, lds0 + STG * 16, wk); }
+    }
+    stamp(stp, 2);
+    // the previous tile leaves the registers while this tile's first K tiles are in flight (ONE call site: the epilogue is large)
+    if (pm0 >= 0) {
+      const int mw = pm0 + wm * WTM, kw = pn0 + wn * WTN;
+      epilogue8<T, RT, EPM>(a, acc, mw, kw, lane, lds_mean);         // the epilogue specialisation is a kernel template parameter: one copy per kernel
+    }
+    stamp(stp, 3);
+    if (!more) break;
+#pragma unroll
+    for (int i = 0; i < RT; ++i)
+#pragma unroll
+      for (int j = 0; j < CT; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+    // vmcnt counts in issue order: behind the epilogue's stores this wait also drains them, all but the youngest (conservative: the compiler's
+    // stores are not counted by hand)
+    if (nk > 1) wait_vmcnt<AI + 2 * BI>(); else wait_vmcnt<0>();
+    raw_barrier();
+    if (wave >= 4) raw_barrier();                           // the second wave group runs one barrier behind
+    stamp(stp, 4);
 
-  igemm_epilogue<T, BM, BN, WM, WN, WTM / 32, CT, 512, 64, true>(a, acc, m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
+    int sx = 0;
+    Walk8 prev = wk;                                        // K tile 1
+    for (int kt = 0; kt + 2 < nk; ++kt) {
+      walk8_advance(wkk, wk);                                 // K tile kt+2
+      ktile(std::integral_constant<int, 2>{}, sx, prev, wk);
+      prev = wk;
+      sx ^= STG;
+    }
+    if (nk > 1) {
+      ktile(std::integral_constant<int, 1>{}, sx, prev, wk);
+      sx ^= STG;
+    }
+    ktile(std::integral_constant<int, 0>{}, sx, prev, wk);
+    if (wave < 4) raw_barrier();                            // the first group waits for the second: every wave has executed the same barriers
+    stamp(stp, 5);
+    pm0 = m0; pn0 = n0;
+  }
 }
 
 // the taps must form a separable arithmetic progression: dh[i * ntw + j] = dh0 + i * ddh, dw = dw0 + j * ddw, widx = widx0 + i * dwi + j * dwj
@@ -291,10 +589,20 @@ template <typename T> int launch8(IgemmArgs& a, hipStream_t s) {
   const int BN = 256;
   if (!fill_walk8(a)) return -1;
   a.nk = a.nt * a.w8_cpc;
-  rn_note_kernel("igemm8<256x%d>", BN);
+  { const unsigned nnt = (unsigned)(a.Kd / BN); a.w8_magic_nnt = nnt <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / nnt); }
+  static const char* const EPN[] = {"plain", "res", "?", "?", "bnb", "bnb+res", "bnb+acc", "?", "gen"};
+  rn_note_kernel("igemm8<256x%d:%s>", BN, EPN[ep8_mode(a)]);
   if (rn_dry_run()) return 0;
-  const dim3 grid(cdiv(a.M, 256) * (a.Kd / BN));
-  hipLaunchKernelGGL((igemm8_kernel<T, 256>), grid, dim3(512), 0, s, a);
+  const int ntiles = cdiv(a.M, 256) * (a.Kd / BN);
+  const int grid = ntiles < 256 ? ntiles : 256;            // one persistent workgroup per CU
+  switch (ep8_mode(a)) {
+    case EP8_PLAIN: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_PLAIN>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_RES: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_RES>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_BNB: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_BNB>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_BNB | EP8_RES: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_BNB | EP8_RES>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_BNB | EP8_ACC: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_BNB | EP8_ACC>), dim3(grid), dim3(512), 0, s, a); break;
+    default: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_GEN>), dim3(grid), dim3(512), 0, s, a); break;
+  }
   RN_CHECK_LAUNCH("igemm8");
   return 0;
 }
@@ -303,6 +611,9 @@ template <typename T> int launch8(IgemmArgs& a, hipStream_t s) {
 
 // geometry the eight-phase kernel covers: 16-bit elements, channel count a multiple of 64 (a K tile never straddles a tap), output channels a
 // multiple of the column tile, 1..16 taps in a separable progression, 32-bit tile offsets; the grid rule (enough tiles for the chip) is the caller's
+// 1: the geometry is one the eight-phase kernel covers with a specialised (spill-free) epilogue; 0: not covered, or only by its general epilogue
+int rn_igemm8_fast(const IgemmArgs& a) { return ep8_mode(a) != EP8_GEN ? 1 : 0; }
+
 int rn_launch_igemm8(const IgemmArgs& a_in, int dtype, hipStream_t s) {
   if (dtype != RN_BF16 && dtype != RN_F16) return -1;
   if (a_in.Cs % 64 || a_in.Kd % 256 || a_in.M <= 0) return -1;

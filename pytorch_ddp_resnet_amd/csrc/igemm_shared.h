@@ -43,6 +43,7 @@ struct IgemmArgs {
   // eight-phase kernels (conv_igemm8.hip): the taps as a separable arithmetic progression, walked with scalar adds.  K tile g = (tap (i, j),
   // 64-channel chunk cc): source byte offset w8_src0 + i w8_si + j w8_sj + 128 cc, weight byte offset w8_wt0 + i w8_wi + j w8_wj + 128 cc
   int w8_src0, w8_si, w8_sj, w8_wt0, w8_wi, w8_wj, w8_cpc;
+  unsigned w8_magic_nnt;   // floor(2^32 / column tiles): tile -> (row tile, column tile) by multiply-high + one correction
   int dh[MAX_TAPS], dw[MAX_TAPS], widx[MAX_TAPS];
 };
 
@@ -521,3 +522,4 @@ template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt v
 
 // conv_igemm8.hip: 256-row tiles on the eight-phase schedule; returns -1 when the geometry is not one it covers (the caller falls back)
 int rn_launch_igemm8(const IgemmArgs& a, int dtype, hipStream_t s);
+int rn_igemm8_fast(const IgemmArgs& a);

@@ -19,7 +19,7 @@ from filler import fill
 from pytorch_ddp_resnet_amd import _lib
 from pytorch_ddp_resnet_amd.engine import ir
 from pytorch_ddp_resnet_amd.engine.lowering import conv_stats_rows
-from prod_geoms import PROD_GEOMS, geom, resolve
+from prod_geoms import PROD_GEOMS, IGEMM8_GEOMS, geom, resolve
 
 pytestmark = pytest.mark.gpu
 
@@ -42,8 +42,10 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
-def run_conv_case(g, dtype, variant=0, expect_same_names=True):
-    """one convolution layer: pack -> forward(+residual, +stats) -> dgrad(+BN-backward sums) -> wgrad, HIP vs torch-CPU."""
+def run_conv_case(g, dtype, variant=0, expect_same_names=True, fwd_res=True, dgrad_merge='none'):
+    """one convolution layer: pack -> forward(+residual, +stats) -> dgrad(+BN-backward sums) -> wgrad, HIP vs torch-CPU.
+    fwd_res: the forward adds an identity residual; dgrad_merge: 'none' | 'res' (dx = conv^T(dy) + shortcut gradient) | 'acc' (dx += conv^T(dy)) --
+    the operand sets the block backward of the reference lowers to (the eight-phase kernels are specialised per set)."""
     import gpu_harness as h
     from pytorch_ddp_resnet_amd.engine.executor import Engine
     L = _lib.lib()
@@ -60,9 +62,12 @@ def run_conv_case(g, dtype, variant=0, expect_same_names=True):
     bx = b.slot('bx', (N, Hh, W, C)); bm = b.slot('bm', (N, Hh, W, C)); coef = b.slot('coef', (4, C), 'f32')
     dw = b.slot('dw', (K, k, k, C), 'f32'); ws = b.slot('workspace', (0,), 'u8')
     b.op(ir.OP_PACK_W, buf=dict(w=w, w_fwd=wf, w_dgrad=wd), dim=dict(K=K, RS=k * k, C=C))
-    b.op(ir.OP_CONV_FWD, buf=dict(x=x, w_fwd=wf, y=y, res=res, stats=st), dim=dict(gm, res_mode=ir.RES_SAME, res_C=K))
-    b.op(ir.OP_CONV_DGRAD, buf=dict(dy=dy, w_dgrad=wd, dx=dx, res=-1, bn_x=bx, bn_mask=bm, bn_coef=coef, bn_partial=dp),
-         dim=dict(gm, res_mode=0, res_C=0), fp=dict(gscale=1 / 0.7))
+    b.op(ir.OP_CONV_FWD, buf=dict(x=x, w_fwd=wf, y=y, res=res if fwd_res else -1, stats=st),
+         dim=dict(gm, res_mode=ir.RES_SAME if fwd_res else 0, res_C=K if fwd_res else 0))
+    dres = b.slot('dres', (N, Hh, W, C))
+    b.op(ir.OP_CONV_DGRAD, buf=dict(dy=dy, w_dgrad=wd, dx=dx, res=dres if dgrad_merge == 'res' else -1, bn_x=bx, bn_mask=bm, bn_coef=coef, bn_partial=dp),
+         dim=dict(gm, res_mode=ir.RES_SAME if dgrad_merge == 'res' else 0, res_C=C if dgrad_merge == 'res' else 0), fp=dict(gscale=1 / 0.7),
+         flags=ir.F_ACCUM if dgrad_merge == 'acc' else 0)
     b.op(ir.OP_CONV_WGRAD, buf=dict(x=x, dy=dy, dw=dw, ws=ws), dim=dict(gm))
     b.ws_need.append(('wgrad', gm))
     plan = b.plan(fp32)
@@ -76,10 +81,14 @@ def run_conv_case(g, dtype, variant=0, expect_same_names=True):
     resv = _round(fill((N, P, Q, K), 4), dtype)
     bxv = _round(fill((N, Hh, W, C), 5), dtype)
     bmv = _round(fill((N, Hh, W, C), 6), dtype)
+    dresv = _round(fill((N, Hh, W, C), 7), dtype)
     cf = torch.from_numpy(np.stack([fill((C,), 71, 0.2, 1.0), fill((C,), 72, 0.1), fill((C,), 73, 0.3), fill((C,), 74, 0.2, 1.0)]))
 
     eng = Engine(plan, h.DEV, TORCH_DT[dtype])
-    for name, v in dict(x=xv, w=wv, dy=dyv, res=resv, bx=bxv, bm=bmv, coef=cf).items():
+    feed = dict(x=xv, w=wv, dy=dyv, res=resv, bx=bxv, bm=bmv, coef=cf, dres=dresv)
+    if dgrad_merge == 'acc':
+        feed['dx'] = dresv                                   # the destination already holds the other branch's gradient
+    for name, v in feed.items():
         t = eng.tensors[plan.slot_of[name]]
         t.copy_(v.reshape(t.shape).to(t.dtype))
     eng.bind({})
@@ -92,8 +101,9 @@ def run_conv_case(g, dtype, variant=0, expect_same_names=True):
         L.rn_kernel_log(0)
         if expect_same_names:
             want = []
+            flags = [1 | (2 if fwd_res else 0), 1 | {'none': 0, 'res': 2, 'acc': 4}[dgrad_merge], 0]
             for ps in range(3):
-                want += _lib.conv_kernel_names(ps, RN_DT[dtype], gm, fused_epilogue=True)
+                want += _lib.conv_kernel_names(ps, RN_DT[dtype], gm, fused_epilogue=flags[ps])
             assert ran == want, (ran, want)
     finally:
         L.rn_set_variant(0)
@@ -102,8 +112,8 @@ def run_conv_case(g, dtype, variant=0, expect_same_names=True):
 
     # ---- torch-CPU reference on the same (pre-rounded) operands, fp32 ----
     xn, wn, dyn = _nchw(xv), wv.permute(0, 3, 1, 2).contiguous(), _nchw(dyv)
-    y_ref = _nhwc(F.conv2d(xn, wn, None, s, p)) + resv
-    dx_ref = _nhwc(torch.nn.grad.conv2d_input(xn.shape, wn, dyn, s, p))
+    y_ref = _nhwc(F.conv2d(xn, wn, None, s, p)) + (resv if fwd_res else 0)
+    dx_ref = _nhwc(torch.nn.grad.conv2d_input(xn.shape, wn, dyn, s, p)) + (dresv if dgrad_merge != 'none' else 0)
     dw_ref = torch.nn.grad.conv2d_weight(xn, wn.shape, dyn, s, p).permute(0, 2, 3, 1)
     tol = TOL[dtype]
 
@@ -269,9 +279,33 @@ def test_igemm8_on_small_geometries(g, dtype):
     """the eight-phase kernel (conv_igemm8.hip) forced onto small shapes that exercise its prologue / tail modes, row tails, strides and
     parity classes; fused epilogues as in every case of this file."""
     ran = run_conv_case(g, dtype, variant=IGEMM8)
-    assert ran[0] == 'igemm8<256x256>', ran
+    assert ran[0] == 'igemm8<256x256:res>', ran
     if g[3] % 256 == 0 and not (g[5] == 1 and g[6] == 2):          # (a stride-2 1x1 layer has three parity classes without any tap: plain zero-fill launches)
-        assert all(n == 'igemm8<256x256>' for n in ran if n.startswith('igemm')), ran
+        assert all(n.startswith('igemm8<256x256:') for n in ran if n.startswith('igemm')), ran
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('merge', ['none', 'res', 'acc'])
+@pytest.mark.parametrize('g', [(2, 16, 16, 256, 256, 3, 1, 1), (3, 14, 14, 256, 512, 1, 1, 0)])
+def test_igemm8_epilogue_specialisations(g, merge, dtype):
+    """every operand set the eight-phase kernel is specialised for: forward without a residual (plain) and the three data-gradient forms
+    (BatchNorm-backward sums alone, + shortcut gradient as residual, + accumulate into dx)."""
+    ran = run_conv_case(g, dtype, variant=IGEMM8, fwd_res=False, dgrad_merge=merge)
+    assert ran[0] == 'igemm8<256x256:plain>', ran
+    assert ran[1] == {'none': 'igemm8<256x256:bnb>', 'res': 'igemm8<256x256:bnb+res>', 'acc': 'igemm8<256x256:bnb+acc>'}[merge], ran
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('ops', [(True, 'none'), (False, 'res'), (False, 'acc')])
+@pytest.mark.parametrize('g', IGEMM8_GEOMS)
+def test_igemm8_production_operand_sets(g, ops, dtype):
+    """the eight-phase kernels at production grids (>= 160 persistent tiles, the shipped selection rule), with every operand set the full-batch
+    WRN-50-2 configuration launches them with: forward +- identity residual; data gradient with the BatchNorm-backward sums alone, with the
+    shortcut gradient as residual, accumulating into dx.  The kernel that ran is asserted against the launchers' own choice."""
+    ran = run_conv_case(g, dtype, fwd_res=ops[0], dgrad_merge=ops[1])
+    assert ran[0] == ('igemm8<256x256:res>' if ops[0] else 'igemm8<256x256:plain>'), ran
+    if g[6] == 1:
+        assert ran[1] == {'none': 'igemm8<256x256:bnb>', 'res': 'igemm8<256x256:bnb+res>', 'acc': 'igemm8<256x256:bnb+acc>'}[ops[1]], ran
 
 
 @pytest.mark.parametrize('g', [(2, 16, 16, 128, 256, 3, 1, 1), (3, 14, 14, 64, 256, 1, 1, 0)])
@@ -291,7 +325,7 @@ def test_igemm8_exact_integers(g):
         L.rn_kernel_log(1)
         eng.run(0, 1, 0)
         torch.cuda.synchronize()
-        assert 'igemm8<256x256>' in L.rn_kernel_log_read().decode()
+        assert 'igemm8<256x256:plain>' in L.rn_kernel_log_read().decode()
     finally:
         L.rn_kernel_log(0)
         L.rn_set_variant(0)

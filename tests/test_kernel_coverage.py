@@ -11,7 +11,7 @@ import pytest
 from pytorch_ddp_resnet_amd import _lib
 from pytorch_ddp_resnet_amd.engine import ir
 from pytorch_ddp_resnet_amd.engine.lowering import lower
-from prod_geoms import PROD_GEOMS, CONFIGS, geom, resolve
+from prod_geoms import PROD_GEOMS, IGEMM8_GEOMS, CONFIGS, geom, resolve
 
 pytestmark = pytest.mark.skipif(not os.path.exists(_lib.LIB_PATH), reason='librn_hip.so not built')
 
@@ -34,9 +34,27 @@ def _tested_names(dtype):
         g = resolve(g, dtype == ir.RN_F32)
         if g[3] % ce or g[4] % ce:
             continue
-        for p in range(3):
-            names.update(_lib.conv_kernel_names(p, dtype, geom(*g), fused_epilogue=True))
+        # operand sets of tests/test_gpu_production_tiles.py::run_conv_case: forward = statistics + identity residual, data gradient = BatchNorm-backward sums
+        for p, fl in ((0, 3), (1, 1), (2, 0)):
+            names.update(_lib.conv_kernel_names(p, dtype, geom(*g), fused_epilogue=fl))
+    for g in IGEMM8_GEOMS:                     # test_igemm8_production_operand_sets: every operand set
+        if dtype == ir.RN_F32:
+            break
+        for p, fls in ((0, (1, 3)), (1, (1, 3, 5)), (2, (0,))):
+            for fl in fls:
+                names.update(_lib.conv_kernel_names(p, dtype, geom(*g), fused_epilogue=fl))
     return names
+
+
+def _op_flags(op):
+    """the operand set of a convolution op as rn_conv_kernel_names takes it: 1 fused sums, 2 identity residual, 4 accumulate"""
+    b = op.buf
+    fl = 1 if (b.get('stats', -1) >= 0 or b.get('bn_x', -1) >= 0) else 0
+    if b.get('res', -1) >= 0 and op.dim.get('res_mode', 0) == ir.RES_SAME:
+        fl |= 2
+    if op.kind == ir.OP_CONV_DGRAD and (op.flags & ir.F_ACCUM):
+        fl |= 4
+    return fl
 
 
 @pytest.mark.parametrize('dtype', [ir.RN_F32, ir.RN_BF16])
@@ -53,7 +71,7 @@ def test_every_production_tile_is_parity_tested(name, dtype):
             continue
         n_conv += 1
         g = {k: op.dim[k] for k in 'N H W C P Q K R S stride pad'.split()}
-        for nm in _lib.conv_kernel_names(PASS_OF[op.kind], dtype, g, fused_epilogue=True):
+        for nm in _lib.conv_kernel_names(PASS_OF[op.kind], dtype, g, fused_epilogue=_op_flags(op)):
             if nm not in tested:
                 missing.setdefault(nm, []).append((ir.OP_NAMES[op.kind], tuple(g.values())))
     assert n_conv > 10
