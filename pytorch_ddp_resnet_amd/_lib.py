@@ -7,6 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librn_hip.so')
 
 OP_NBUF, OP_NDIM = 8, 20
+ABI_VERSION = 3          # include/rn_hip.h RN_ABI_VERSION this binding was written for
 
 
 class RnOp(C.Structure):
@@ -36,6 +37,9 @@ def lib():
     vp, i32, i64, u32, u64, f32, f64, sz = C.c_void_p, C.c_int, C.c_int64, C.c_uint32, C.c_uint64, C.c_float, C.c_double, C.c_size_t
     L.rn_last_error.restype = C.c_char_p
     L.rn_version.restype = i32
+    if L.rn_version() != ABI_VERSION:
+        raise RnError(f"{LIB_PATH} reports ABI version {L.rn_version()}, this binding is written for {ABI_VERSION}: rebuild the library "
+                      f"(make -C pytorch_ddp_resnet_amd/csrc); a stale library would take shifted arguments")
     L.rn_plan_create.argtypes = [C.POINTER(RnOp), i32, i32, i32, C.POINTER(vp)]
     L.rn_plan_bind.argtypes = [vp, C.POINTER(vp), i32]
     L.rn_plan_set_bytes.argtypes = [vp, i32, sz]
@@ -59,6 +63,10 @@ def lib():
     L.rn_sgd_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, f32, vp]
     L.rn_sgd_step_amp.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, vp, vp, vp]
     L.rn_set_variant.argtypes = [i32]
+    L.rn_conv_workspace_bytes.restype = sz
+    L.rn_set_conv_workspace.argtypes = [vp, sz]
+    L.rn_wgrad8_workspace_bytes.restype = sz
+    L.rn_set_wgrad8_workspace.argtypes = [vp, sz]
     L.rn_augment_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     L.rn_amp_check_unscale.argtypes = [vp, C.c_int64, vp, vp, vp]
     L.rn_kernel_log.argtypes = [i32]

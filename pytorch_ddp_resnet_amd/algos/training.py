@@ -3,8 +3,9 @@ The training step around the hot path.  ``train_step`` is this build's counterpa
 (/root/reference/resnet/algos/training.py:92-113): forward -> loss/metrics -> backward (+ gradient mean across ranks)
 -> optimizer step once ``num_microbatches`` microbatches have been accumulated (gradients are SUMMED over
 microbatches, the loss is not rescaled -- training.py:92-113).  ``training_loop`` keeps the reference's
-control flow (epochs over the loader, scheduler step unit, per-epoch evaluation) without its TensorBoard / checkpoint
-plumbing, which is out of the accelerated path's scope.
+control flow (epochs over the loader, scheduler step unit, per-epoch evaluation, rank 0 saving
+``{checkpoint_strategy, classifier, optimizer, scheduler, scaler}`` whenever the checkpoint strategy says so, at the
+reference's two points, training.py:129-139 and :161-171) without its TensorBoard writer.
 """
 from collections import Counter
 from typing import Optional
@@ -66,8 +67,19 @@ def train_step(classifier, x, y, optimizer=None, reducer=None, world_size=1, mic
 
 
 def training_loop(rank, world_size, device, dl_train, dl_test, classifier, optimizer, scheduler=None, scheduler_step_unit='none',
-                  num_microbatches=1, global_step=0, max_steps=1, reducer=None, sampler_train=None, log=print, scaler=None, **kwargs):
+                  num_microbatches=1, global_step=0, max_steps=1, reducer=None, sampler_train=None, log=print, scaler=None,
+                  checkpoint_strategy=None, checkpoint_dir=None, **kwargs):
     from .evaluation import evaluation_loop
+    from ..utils.checkpoint_util import ddp_keys, save_checkpoints
+
+    def maybe_save(unit, loss, steps):
+        """rank 0 only, as the reference (its strategy counters advance on rank 0 alone); the loss is the step's / the epoch's mean"""
+        if rank != 0 or checkpoint_strategy is None or checkpoint_dir is None:
+            return
+        if checkpoint_strategy.observe(unit=unit, loss=loss):
+            save_checkpoints(checkpoint_dir, {'checkpoint_strategy': checkpoint_strategy, 'classifier': ddp_keys(classifier), 'optimizer': optimizer,
+                                              'scheduler': scheduler, 'scaler': scaler}, steps=steps)
+
     epoch = 0
     while global_step < max_steps:
         if sampler_train is not None:
@@ -90,6 +102,7 @@ def training_loop(rank, world_size, device, dl_train, dl_test, classifier, optim
                     last_loss[0] = means.get('loss')
                     if rank == 0:
                         log(f"global step: {gs}... loss: {means.get('loss')}")
+                    maybe_save('batch', means.get('loss'), gs + 1)           # training.py:129-139 (resolved one microbatch late, in step order)
                     running = Counter()
 
         for microbatch_id, (x, y) in enumerate(dl_train, 1):
@@ -113,5 +126,6 @@ def training_loop(rank, world_size, device, dl_train, dl_test, classifier, optim
                 step_scheduler(scheduler, val.get('loss'))
             if rank == 0:
                 log(f"epoch: {epoch}... validation loss: {val.get('loss')}")
+            maybe_save('epoch', val.get('loss'), global_step + 1)           # training.py:161-171
         epoch += 1
     return global_step

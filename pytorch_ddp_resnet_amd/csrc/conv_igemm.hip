@@ -683,9 +683,9 @@ static bool igemm8_rule(const IgemmArgs& a) {
 template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   if (a.M <= 0) return 0;
   const int K = a.Kd;
-  // 256-row tiles on the eight-phase schedule (conv_igemm8.hip).  rn_set_variant: 1 << 22 = wherever the geometry allows, 1 << 23 = never.
+  // 256-row tiles on the eight-phase schedule (conv_igemm8.hip).  rn_set_variant: 1 << 22 = wherever the geometry allows, 1 << 27 = never.
   if constexpr (sizeof(T) == 2) {
-    const bool force8 = (g_rn_variant & (1 << 22)) != 0, forbid8 = (g_rn_variant & (1 << 23)) != 0;
+    const bool force8 = (g_rn_variant & (1 << 22)) != 0, forbid8 = (g_rn_variant & (1 << 27)) != 0;
     if (!forbid8 && (force8 || igemm8_rule(a))) {
       const int e = rn_launch_igemm8(a, std::is_same<T, bf16_t>::value ? RN_BF16 : RN_F16, s);
       if (e >= 0) return e;

@@ -31,7 +31,14 @@
 // (LDS-DMA) while the waves store tile i.
 #include "igemm_shared.h"
 
+static void* g_sk_ws = nullptr;
+static size_t g_sk_ws_bytes = 0;
+
 namespace {
+
+constexpr size_t SK_CNT_BYTES = 4096;                     // stream-K workspace: 1,024 tile tickets, then 2 slots of fp32 accumulators per workgroup
+constexpr int SK_GRID = 256;                              // persistent workgroups (one per CU)
+constexpr size_t SK_SLOT_BYTES = (size_t)512 * 128 * 4;   // 256 x 256 tile: 128 accumulator registers of 512 threads
 
 template <int N> __device__ inline void wait_lgkm() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ inline void raw_barrier() {
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
   constexpr int STG = 4096;                                 // uint4 per stage: 64 KiB (A0 | A1 | B0 | B1), power of two: the stage toggles by XOR
   constexpr int A_H = 1024, B_0 = 2048, B_H = BN * 4;       // uint4 offsets: second A half, B, second B half
   static_assert(sizeof(T) == ES && BN == 256 && CT == 4 && B_0 + 2 * B_H <= STG, "tile");
-  __shared__ uint4 smem[2 * STG + TAP_INTS / 4 + 8 * 16];
+  __shared__ uint4 smem[2 * STG + TAP_INTS / 4 + 8 * 16 + 1];     // stages | tap tables | 64 floats per wave (epilogue8) | one ticket word
   int* taps = reinterpret_cast<int*>(&smem[2 * STG]);
 
   // (no blanket preload of the kernel arguments: this kernel is persistent and its epilogues read many of them -- held in SGPRs across the whole
@@ -494,41 +501,120 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
     raw_barrier();
   };
 
-  // ---- persistent walk.  Workgroups b and b + 8 share an XCD (round-robin dispatch); the tile order is column tiles fastest, and each XCD class takes a
-  // contiguous eighth of it, its workgroups interleaved -- so the tiles in flight on one XCD at one time are neighbours: they read the same input
-  // rows / the same weights out of that XCD's L2 ----
+  // ---- persistent walk.  Work = whole tiles (data-parallel part) and then a range of K-TILE UNITS (stream-K part, Osama et al. 2023):
+  //  * tiles [0, dp_tiles): workgroup b takes tiles b, b + G, ... (dp_tiles is a multiple of G).  Workgroups b and b + 8 share an XCD (round-robin
+  //    dispatch); the tile order is column tiles fastest and each XCD class takes a contiguous eighth of it, its workgroups interleaved -- the tiles
+  //    in flight on one XCD at one time are neighbours and read the same input rows / weights out of that XCD's L2;
+  //  * tiles [dp_tiles, ntiles): their sk_tiles * nk K tiles are cut into G equal contiguous ranges, one per workgroup, so the last partial round of a
+  //    grid that is no multiple of the CU count costs ~(1 + fraction) / 2 rounds instead of one (196 tiles on 256 CUs: 77 % -> ~100 % occupancy).
+  //    A tile cut between workgroups is summed through memory: every part writes its fp32 accumulators to its slot, releases, and draws a
+  //    ticket (agent-scope atomic); whoever draws the LAST ticket acquires, adds the parts in slice order (fixed order: bitwise reproducible, own
+  //    part re-read like the others) and runs the epilogue.  Nobody waits for anybody: no spin, no residency assumption.
   const int G = gridDim.x;                                  // a multiple of 8, or ntiles (launcher)
-  int pm0 = -1, pn0 = 0;                                    // the tile whose accumulators are still in registers
-  for (int it = 0;; ++it) {
+  const int dp_tiles = a.w8_dp_tiles;
+  const unsigned U = (unsigned)(ntiles - dp_tiles) * (unsigned)nk;             // stream-K units; U * G < 2^31 (launcher)
+  const int wv = (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);    // XCD-contiguous index: neighbours in the unit order share an L2
+  const unsigned su0 = U ? (unsigned)wv * U / (unsigned)G : 0u, su1 = U ? (unsigned)(wv + 1) * U / (unsigned)G : 0u;
+  unsigned su = su0;
+  int it = 0;
+  int pm0 = -1, pn0 = 0, pt_sk = -1, pseg = 0;              // the segment whose accumulators are still in registers (pt_sk >= 0: a partial stream-K tile)
+  for (;;) {
     const int vb = it * G + blockIdx.x;
-    const bool more = vb < ntiles;                          // wave-uniform
-    int m0 = 0, n0 = 0;
-    Walk8 wk;
-    const unsigned long long* stp = it == 1 ? a.stamps : nullptr;      // diagnostic (rn_set_stamp_buffer): the workgroup's SECOND tile
-    stamp(stp, 0);
-    if (more) {
-      int tile = vb;
+    int tile = 0, kb = 0, ke = nk, t_sk = -1, seg = 0;
+    bool more = true;                                       // wave-uniform
+    if (vb < dp_tiles) {
+      tile = vb;
       if (a.xcd_remap) {
-        const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
+        const int xcd = vb & 7, q = dp_tiles >> 3, r = dp_tiles & 7;
         tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
       }
+      ++it;
+    } else if (su < su1) {
+      t_sk = (int)(su / (unsigned)nk);
+      kb = (int)(su - (unsigned)t_sk * (unsigned)nk);
+      ke = min(nk, kb + (int)(su1 - su));
+      seg = su == su0 ? 0 : 1;
+      tile = dp_tiles + t_sk;
+      su += (unsigned)(ke - kb);
+      if (kb == 0 && ke == nk) t_sk = -1;                   // the whole tile is this workgroup's: nothing to sum
+    } else {
+      more = false;
+    }
+    const int nseg = ke - kb;                               // K tiles of this segment
+    int m0 = 0, n0 = 0;
+    Walk8 wk;
+    const unsigned long long* stp = it == 2 && vb < dp_tiles ? a.stamps : nullptr;      // diagnostic (rn_set_stamp_buffer): the workgroup's SECOND tile
+    stamp(stp, 0);
+    if (more) {
       int mt = (int)__umulhi((unsigned)tile, (unsigned)a.w8_magic_nnt);      // tile / nnt
       if (tile - mt * nnt >= nnt) ++mt;
       m0 = mt * BM; n0 = (tile - mt * nnt) * BN;
       tile_roles(m0, n0);
       stamp(stp, 1);
-      // prologue: K tile 0 whole, then B0 / A0 / B1 of K tile 1 (the state every K tile's phase 1 starts from).  Every wave has left the previous
-      // tile's K loop (its closing rendezvous), so both stages are free.
-      walk8_seek(a, wk, 0);
+      // prologue: the segment's first K tile whole, then B0 / A0 / B1 of its second (the state every K tile's phase 1 starts from).  Every wave has
+      // left the previous segment's K loop (its closing rendezvous), so both stages are free.
+      walk8_seek(a, wk, kb);
       issue_b(0, lds0, wk); issue_a(0, lds0, wk); issue_b(1, lds0, wk); issue_a(1, lds0, wk);
       walk8_advance(wkk, wk);
-      if (nk > 1) { issue_b(0, lds0 + STG * 16, wk); issue_a(0, lds0 + STG * 16, wk); issue_b(1, lds0 + STG * 16, wk); }
+      if (nseg > 1) { issue_b(0, lds0 + STG * 16, wk); issue_a(0, lds0 + STG * 16, wk); issue_b(1, lds0 + STG * 16, wk); }
     }
     stamp(stp, 2);
-    // the previous tile leaves the registers while this tile's first K tiles are in flight (ONE call site: the epilogue is large)
+    // the previous segment leaves the registers while this one's first K tiles are in flight (ONE call site: the epilogue is large)
     if (pm0 >= 0) {
-      const int mw = pm0 + wm * WTM, kw = pn0 + wn * WTN;
-      epilogue8<T, RT, EPM>(a, acc, mw, kw, lane, lds_mean);         // the epilogue specialisation is a kernel template parameter: one copy per kernel
+      bool finish = true;
+      if (pt_sk >= 0) {
+        // ---- a part of a cut tile: publish it, draw a ticket; the last arriver sums the parts ----
+        const unsigned uf = (unsigned)pt_sk * (unsigned)nk;
+        const int w_first = (int)(((uf + 1u) * (unsigned)G - 1u) / U), w_last = (int)(((uf + (unsigned)nk) * (unsigned)G - 1u) / U);   // owners of the tile's first / last unit
+        const int parts = w_last - w_first + 1;
+        f32x4* slots = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.w8_ws) + SK_CNT_BYTES);
+        constexpr size_t SLOT = (size_t)RT * CT * 512;       // f32x4 per slot: register-major, thread-minor (every access 16 bytes per lane, coalesced)
+        f32x4* mine = slots + (size_t)(wv * 2 + pseg) * SLOT + tid;
+#pragma unroll
+        for (int i = 0; i < RT; ++i)
+#pragma unroll
+          for (int j = 0; j < CT; ++j) mine[(size_t)(i * CT + j) * 512] = acc[i][j];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains, then the workgroup meets, then ONE lane releases and signals
+        __syncthreads();
+        int* cnt = reinterpret_cast<int*>(a.w8_ws) + pt_sk;
+        volatile int* flagw = reinterpret_cast<volatile int*>(&smem[2 * STG + TAP_INTS / 4 + 8 * 16]);
+        if (tid == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (keep: the compiler may drop the fence's own wait)
+          *flagw = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        finish = *flagw == parts - 1;                        // wave-uniform: every thread reads the same LDS word
+        if (finish) {
+          if (tid == 0) {
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // every part has arrived: the counter is clean for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __syncthreads();
+#pragma unroll
+          for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
+          for (int sl = 0; sl < parts; ++sl) {               // slice order: the sum does not depend on who arrived last
+            const int wq = w_first + sl;
+            const int sq = (int)(((unsigned)wq * U / (unsigned)G) / (unsigned)nk) == pt_sk ? 0 : 1;       // that workgroup's first segment, or its last
+            const f32x4* src = slots + (size_t)(wq * 2 + sq) * SLOT + tid;
+#pragma unroll
+            for (int i = 0; i < RT; ++i)
+#pragma unroll
+              for (int j = 0; j < CT; ++j) acc[i][j] += src[(size_t)(i * CT + j) * 512];
+          }
+        } else {
+          __syncthreads();                                   // same barrier count on both paths
+        }
+      }
+      if (finish) {
+        const int mw = pm0 + wm * WTM, kw = pn0 + wn * WTN;
+        epilogue8<T, RT, EPM>(a, acc, mw, kw, lane, lds_mean);       // the epilogue specialisation is a kernel template parameter: one copy per kernel
+      }
     }
     stamp(stp, 3);
     if (!more) break;
@@ -540,27 +626,27 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
         for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
     // vmcnt counts in issue order: behind the epilogue's stores this wait also drains them, all but the youngest (conservative: the compiler's
     // stores are not counted by hand)
-    if (nk > 1) wait_vmcnt<AI + 2 * BI>(); else wait_vmcnt<0>();
+    if (nseg > 1) wait_vmcnt<AI + 2 * BI>(); else wait_vmcnt<0>();
     raw_barrier();
     if (wave >= 4) raw_barrier();                           // the second wave group runs one barrier behind
     stamp(stp, 4);
 
     int sx = 0;
-    Walk8 prev = wk;                                        // K tile 1
-    for (int kt = 0; kt + 2 < nk; ++kt) {
-      walk8_advance(wkk, wk);                                 // K tile kt+2
+    Walk8 prev = wk;                                        // the segment's second K tile
+    for (int kt = 0; kt + 2 < nseg; ++kt) {
+      walk8_advance(wkk, wk);                               // K tile kt+2
       ktile(std::integral_constant<int, 2>{}, sx, prev, wk);
       prev = wk;
       sx ^= STG;
     }
-    if (nk > 1) {
+    if (nseg > 1) {
       ktile(std::integral_constant<int, 1>{}, sx, prev, wk);
       sx ^= STG;
     }
     ktile(std::integral_constant<int, 0>{}, sx, prev, wk);
     if (wave < 4) raw_barrier();                            // the first group waits for the second: every wave has executed the same barriers
     stamp(stp, 5);
-    pm0 = m0; pn0 = n0;
+    pm0 = m0; pn0 = n0; pt_sk = t_sk; pseg = seg;
   }
 }
 
@@ -594,7 +680,20 @@ template <typename T> int launch8(IgemmArgs& a, hipStream_t s) {
   rn_note_kernel("igemm8<256x%d:%s>", BN, EPN[ep8_mode(a)]);
   if (rn_dry_run()) return 0;
   const int ntiles = cdiv(a.M, 256) * (a.Kd / BN);
-  const int grid = ntiles < 256 ? ntiles : 256;            // one persistent workgroup per CU
+  // data-parallel rounds, then stream-K over the last (1 + fraction) rounds -- when the grid wastes more than 8 % of its last round, a workspace is
+  // set (rn_set_conv_workspace) and every workgroup still gets a few K tiles.  rn_set_variant 1 << 28: never (A/B).
+  int grid = ntiles < SK_GRID ? ntiles : SK_GRID;
+  a.w8_dp_tiles = ntiles;
+  a.w8_ws = g_sk_ws;
+  const int rem = ntiles % SK_GRID, full = ntiles / SK_GRID;
+  if (rem != 0 && g_sk_ws && g_sk_ws_bytes >= SK_CNT_BYTES + 2 * SK_GRID * SK_SLOT_BYTES && !(g_rn_variant & (1 << 28)) && (double)ntiles / ((full + 1) * SK_GRID) < 0.92) {
+    const int sk_tiles = full >= 1 ? SK_GRID + rem : rem;
+    const long units = (long)sk_tiles * a.nk;
+    if (units >= 4L * SK_GRID && units * SK_GRID < (1L << 31) && sk_tiles <= (int)(SK_CNT_BYTES / 4)) {
+      a.w8_dp_tiles = ntiles - sk_tiles;
+      grid = SK_GRID;
+    }
+  }
   switch (ep8_mode(a)) {
     case EP8_PLAIN: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_PLAIN>), dim3(grid), dim3(512), 0, s, a); break;
     case EP8_RES: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_RES>), dim3(grid), dim3(512), 0, s, a); break;
@@ -608,6 +707,15 @@ template <typename T> int launch8(IgemmArgs& a, hipStream_t s) {
 }
 
 }  // namespace
+
+extern "C" size_t rn_conv_workspace_bytes(void) { return SK_CNT_BYTES + 2 * SK_GRID * SK_SLOT_BYTES; }
+// the stream-K workspace of the eight-phase convolution kernels: device memory of rn_conv_workspace_bytes() bytes whose first 4 KiB are ZERO (the tile
+// tickets; the kernels leave them zero), owned by the caller, used by one stream at a time (the plan executor launches every convolution forward /
+// data gradient on its launch stream).  NULL (the default): no stream-K, whole tiles only.
+extern "C" int rn_set_conv_workspace(void* p, size_t bytes) {
+  g_sk_ws = p; g_sk_ws_bytes = p ? bytes : 0;
+  return 0;
+}
 
 // geometry the eight-phase kernel covers: 16-bit elements, channel count a multiple of 64 (a K tile never straddles a tap), output channels a
 // multiple of the column tile, 1..16 taps in a separable progression, 32-bit tile offsets; the grid rule (enough tiles for the chip) is the caller's

@@ -13,6 +13,9 @@
 #include <stdlib.h>
 
 extern int g_rn_variant;   // conv_igemm.hip (rn_set_variant)
+// conv_wgrad8.hip: the eight-phase kernel for channel counts that are multiples of 256 (stream-K, sums in-kernel: no slabs, no reduction launch)
+int rn_wgrad8_applies(const rn_conv_geom* g, int dtype);
+int rn_launch_wgrad8(const void* x, const void* dy, float* dw, int flags, int dtype, const rn_conv_geom* g, hipStream_t s);
 
 namespace {
 
@@ -487,6 +490,7 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   RN_CHECK_ARG(g->C % ce == 0 && g->K % ce == 0, "rn_conv_wgrad: C=%d, K=%d must be multiples of %d", g->C, g->K, ce);
   RN_CHECK_ARG(g->R == g->S && g->R * g->S <= MAX_TAPS, "rn_conv_wgrad: kernel %dx%d unsupported", g->R, g->S);
   RN_CHECK_ARG((long)g->N * g->P * g->Q < (1L << 31), "rn_conv_wgrad: too many pixels");
+  if (rn_wgrad8_applies(g, dtype)) return rn_launch_wgrad8(x, dy, dw_krsc, flags, dtype, g, as_stream(s));
   const bool ic = use_im2col(g, ce);
   const int bk = pick_tile(g->K), bc = col_tile(g, ic);
   WgradArgs a{};
@@ -550,6 +554,7 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
 
 extern "C" int rn_conv_wgrad_splits(const rn_conv_geom* g, int dtype, int flags) {
   if (!g || !RN_DTYPE_OK(dtype)) return -1;
+  if (rn_wgrad8_applies(g, dtype)) return 0;            // sums its split-K parts itself
   const int ce = dtype == RN_F32 ? 4 : 8;
   const bool ic = use_im2col(g, ce);
   const int bk = pick_tile(g->K), bc = col_tile(g, ic);

@@ -43,6 +43,8 @@ struct IgemmArgs {
   // eight-phase kernels (conv_igemm8.hip): the taps as a separable arithmetic progression, walked with scalar adds.  K tile g = (tap (i, j),
   // 64-channel chunk cc): source byte offset w8_src0 + i w8_si + j w8_sj + 128 cc, weight byte offset w8_wt0 + i w8_wi + j w8_wj + 128 cc
   int w8_src0, w8_si, w8_sj, w8_wt0, w8_wi, w8_wj, w8_cpc;
+  int w8_dp_tiles;         // tiles [0, w8_dp_tiles) are taken whole (round-robin), the rest as stream-K units
+  void* w8_ws;             // stream-K workspace (rn_set_conv_workspace), or NULL
   unsigned w8_magic_nnt;   // floor(2^32 / column tiles): tile -> (row tile, column tile) by multiply-high + one correction
   int dh[MAX_TAPS], dw[MAX_TAPS], widx[MAX_TAPS];
 };

@@ -61,7 +61,7 @@ extern "C" int rn_conv_kernel_names(int pass, int dtype, const rn_conv_geom* g, 
   g_dry = false; g_log_on = was_on; g_log = keep;
   return e;
 }
-extern "C" int rn_version(void) { return 1; }
+extern "C" int rn_version(void) { return RN_ABI_VERSION; }
 
 struct rn_plan {
   std::vector<rn_op> ops;

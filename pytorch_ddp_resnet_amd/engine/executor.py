@@ -29,6 +29,28 @@ def layout_grads(plan: Plan):
     return offsets, max(off, 1)
 
 
+_conv_ws = {}       # device index -> the stream-K workspace of the eight-phase convolution kernels (one per process and device, zero-initialised tickets)
+
+
+def ensure_conv_workspace(device: torch.device):
+    """the convolution kernels' stream-K workspace (csrc/conv_igemm8.hip): allocated once, handed to the library; every engine of the process
+    launches its convolutions on one stream at a time, so one workspace serves them all.  RN_NO_STREAMK=1: none (whole tiles only; A/B)."""
+    L = _lib.lib()
+    if os.environ.get('RN_NO_STREAMK', '0') == '1':
+        L.rn_set_conv_workspace(None, 0)
+        L.rn_set_wgrad8_workspace(None, 0)
+        return None
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    if idx not in _conv_ws:
+        # two regions: forward / data-gradient kernels (launch stream) and the weight-gradient kernel (side stream) run concurrently
+        _conv_ws[idx] = (torch.zeros(int(L.rn_conv_workspace_bytes()), dtype=torch.uint8, device=device),
+                         torch.zeros(int(L.rn_wgrad8_workspace_bytes()), dtype=torch.uint8, device=device))
+    t, tw = _conv_ws[idx]
+    _lib.check(L.rn_set_conv_workspace(C.c_void_p(t.data_ptr()), t.numel()))
+    _lib.check(L.rn_set_wgrad8_workspace(C.c_void_p(tw.data_ptr()), tw.numel()))
+    return t, tw
+
+
 class Engine:
     def __init__(self, plan: Plan, device: torch.device, compute_dtype: torch.dtype):
         if device.type != 'cuda':
@@ -39,6 +61,7 @@ class Engine:
         self.rn_dtype = {torch.float32: ir.RN_F32, torch.bfloat16: ir.RN_BF16, torch.float16: ir.RN_F16}[compute_dtype]
         assert plan.meta['fp32'] == (compute_dtype == torch.float32)
         self.generation = 0
+        self._conv_ws = ensure_conv_workspace(device)
         # ---- flat gradient buffer, laid out in the order the backward produces the gradients ----
         self.grad_offsets, total = layout_grads(plan)
         self._grad_slots = {s.key: s for s in plan.slots if s.role == 'grad'}

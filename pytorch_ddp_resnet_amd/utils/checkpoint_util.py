@@ -13,7 +13,7 @@ channels_last in memory, which ``load_state_dict``'s ``copy_`` and ``state_dict(
 """
 import os
 import re
-from typing import Dict, Optional
+from typing import Any, Dict, Optional
 
 import torch
 
@@ -90,3 +90,75 @@ def save_checkpoints(checkpoint_dir: str, checkpointables: Dict[str, object], st
     for k, c in checkpointables.items():
         if c is not None:
             save_checkpoint(checkpoint_dir, k, c, steps)
+
+
+# ---- checkpoint strategies (/root/reference/resnet/utils/checkpoint_util.py:140-222): WHEN rank 0 writes.  Modules with `_batch_step` / `_epoch_step`
+# (and `_lowest_loss`) buffers, so their state_dict is the reference's `checkpoint_strategy_{steps}.pth` ----
+class CheckpointStrategy(torch.nn.Module):
+    def __init__(self, unit: str):
+        assert unit in ('batch', 'epoch')
+        super().__init__()
+        self._unit = unit
+        self.register_buffer('_batch_step', torch.tensor(0))
+        self.register_buffer('_epoch_step', torch.tensor(0))
+
+    @property
+    def unit(self) -> str:
+        return self._unit
+
+    @property
+    def batch_step(self) -> int:
+        return int(self._batch_step.item())
+
+    @property
+    def epoch_step(self) -> int:
+        return int(self._epoch_step.item())
+
+    def step(self, unit: str) -> None:
+        assert unit in ('batch', 'epoch')
+        buf = self._batch_step if unit == 'batch' else self._epoch_step
+        buf.add_(1)
+
+    def observe(self, **kwargs) -> bool:
+        raise NotImplementedError
+
+
+class FrequencyCheckpointStrategy(CheckpointStrategy):
+    """eligible every `frequency`-th observation of its own unit (counted from 0, so the first one is)."""
+
+    def __init__(self, unit: str, frequency: int, **kwargs):
+        super().__init__(unit)
+        self._frequency = int(frequency)
+
+    def observe(self, unit: str, **kwargs) -> bool:
+        cond = getattr(self, f"{unit}_step") % self._frequency == 0
+        self.step(unit)
+        return bool(cond) if self.unit == unit else False
+
+
+class PerformanceCheckpointStrategy(CheckpointStrategy):
+    """eligible when the observed loss of its own unit is the lowest so far."""
+
+    def __init__(self, unit: str, **kwargs):
+        super().__init__(unit)
+        self.register_buffer('_lowest_loss', torch.tensor(float('inf')))
+
+    @property
+    def lowest_loss(self) -> float:
+        return float(self._lowest_loss.item())
+
+    def observe(self, unit: str, loss: float, **kwargs) -> bool:
+        cond = loss < self.lowest_loss
+        self.step(unit)
+        if self.unit != unit:
+            return False
+        if cond:
+            self._lowest_loss.fill_(float(loss))
+        return bool(cond)
+
+
+def get_checkpoint_strategy(checkpoint_strategy_cls_name: str, checkpoint_strategy_args: Optional[Dict[str, Any]]) -> CheckpointStrategy:
+    cls = {'FrequencyCheckpointStrategy': FrequencyCheckpointStrategy, 'PerformanceCheckpointStrategy': PerformanceCheckpointStrategy}.get(checkpoint_strategy_cls_name)
+    if cls is None:
+        raise AttributeError(f"module 'checkpoint_util' has no attribute '{checkpoint_strategy_cls_name}'")
+    return cls(**(checkpoint_strategy_args or {}))

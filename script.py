@@ -21,6 +21,7 @@ from pytorch_ddp_resnet_amd.algos.evaluation import evaluation_loop
 from pytorch_ddp_resnet_amd.algos.training import training_loop
 from pytorch_ddp_resnet_amd.ddp import GradReducer, broadcast_parameters
 from pytorch_ddp_resnet_amd.utils.amp import GradScaler
+from pytorch_ddp_resnet_amd.utils.checkpoint_util import ddp_keys, get_checkpoint_strategy, maybe_load_checkpoints
 from pytorch_ddp_resnet_amd.utils.config_util import ConfigParser
 from pytorch_ddp_resnet_amd.utils.optim_util import get_optimizer, get_scheduler
 
@@ -98,8 +99,18 @@ def setup(rank, config):
     reducer = GradReducer(classifier, world) if world > 1 else None
     optimizer = get_optimizer(config.get('optimizer_cls_name'), classifier, config.get('optimizer_args'))
     scheduler = get_scheduler(config.get('scheduler_cls_name'), optimizer, config.get('scheduler_args'))
+    # resume (/root/reference/script.py:80-94): every checkpointable from its newest `{kind}_{steps}.pth`; the classifier through DDP's `module.` key
+    # scheme, so files written by the reference (or by this trainer) load into either.  All ranks read the same files.
+    cfg = dict(config)
+    checkpoint_strategy = None
+    if cfg.get('checkpoint_strategy_cls_name'):
+        checkpoint_strategy = get_checkpoint_strategy(cfg['checkpoint_strategy_cls_name'], cfg.get('checkpoint_strategy_args'))
+    kinds = {'checkpoint_strategy': checkpoint_strategy, 'classifier': ddp_keys(classifier), 'optimizer': optimizer, 'scheduler': scheduler, 'scaler': scaler}
+    if config.get('mode') != 'train':
+        kinds = {'classifier': kinds['classifier']}         # evaluation reads the weights only: a directory holding just classifier_{steps}.pth is enough
+    global_step = maybe_load_checkpoints(config.get('checkpoint_dir'), kinds, map_location=device, steps=None)
     return dict(device=device, dl_train=dl_train, dl_test=dl_test, classifier=classifier, optimizer=optimizer, scheduler=scheduler,
-                reducer=reducer, global_step=0, scaler=scaler, sampler_train=sampler_train)
+                reducer=reducer, global_step=global_step, scaler=scaler, sampler_train=sampler_train, checkpoint_strategy=checkpoint_strategy)
 
 
 def train(rank, config):
@@ -110,6 +121,8 @@ def train(rank, config):
 
 def evaluate(rank, config):
     system = setup(rank, config)
+    if system['global_step'] == 0 and rank == 0:
+        print("WARNING: no classifier checkpoint under " + str(config.get('checkpoint_dir')) + ": evaluating randomly initialised weights")
     metrics = evaluation_loop(config.get('world_size'), system['device'], system['dl_test'], system['classifier'])
     if rank == 0:
         print(f"Test metrics: {metrics}")

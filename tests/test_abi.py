@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 30
     for n in sorted(names):
         assert hasattr(L, n), f'{n} declared in rn_hip.h but not exported'
-    assert L.rn_version() >= 1
+    assert L.rn_version() == _lib.ABI_VERSION
     assert isinstance(L.rn_last_error(), bytes)
 
 

@@ -308,6 +308,91 @@ def test_igemm8_production_operand_sets(g, ops, dtype):
         assert ran[1] == {'none': 'igemm8<256x256:bnb>', 'res': 'igemm8<256x256:bnb+res>', 'acc': 'igemm8<256x256:bnb+acc>'}[ops[1]], ran
 
 
+WGRAD8 = 1 << 30                     # rn_set_variant: the eight-phase weight-gradient kernel at any size (its rule wants >= 8 K tiles per workgroup)
+WGRAD8_SMALL = [
+    (2, 16, 16, 256, 256, 3, 1, 1),      # 9 taps x one 256 x 256 tile, 8 K tiles each: padding taps, cuts between and inside tiles
+    (4, 14, 14, 256, 512, 1, 1, 0),      # dense 1x1, two output-channel tiles, pixel tail (784 = 12 x 64 + 16)
+    (2, 28, 28, 256, 256, 3, 2, 1),      # stride 2
+    (2, 14, 14, 512, 256, 1, 2, 0),      # stride-2 1x1 (projection shortcut), two input-channel tiles
+    (1, 7, 7, 256, 256, 3, 1, 1),        # ONE K tile per tile (49 pixels)
+]
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('g', WGRAD8_SMALL)
+def test_wgrad8_on_small_geometries(g, dtype):
+    """the eight-phase weight-gradient kernel (conv_wgrad8.hip): transposed fragment reads, per-K-tile pixel decode, stream-K with ticketed sums."""
+    ran = run_conv_case(g, dtype, variant=WGRAD8 | IGEMM8)
+    assert ran[-1] == 'wgrad8<256x256>', ran
+
+
+def test_wgrad8_exact_integers_and_accumulate():
+    """integer operands: bit for bit; a second launch with RN_F_ACCUM doubles the gradient exactly."""
+    g = (2, 16, 16, 256, 256, 3, 1, 1)
+    N, Hh, W, C, K, k, s_, p = g
+    eng, sl = _one_op_engine(ir.OP_CONV_WGRAD, g, dict(x=((N, Hh, W, C), 'T'), dy=((N, Hh, W, K), 'T'), dw=((K, 3, 3, C), 'f32'), ws=((0,), 'u8')))
+    rng = np.random.RandomState(0)
+    xv = rng.randint(-3, 4, size=(N, Hh, W, C)).astype(np.float32)
+    dv = rng.randint(-2, 3, size=(N, Hh, W, K)).astype(np.float32)
+    eng.tensors[sl['x']].copy_(torch.from_numpy(xv).to(torch.float16)); eng.tensors[sl['dy']].copy_(torch.from_numpy(dv).to(torch.float16))
+    eng.bind({})
+    L = _lib.lib()
+    L.rn_set_variant(WGRAD8)
+    try:
+        L.rn_kernel_log(1)
+        eng.run(0, 1, 0)
+        torch.cuda.synchronize()
+        assert 'wgrad8<256x256>' in L.rn_kernel_log_read().decode()
+    finally:
+        L.rn_kernel_log(0)
+        L.rn_set_variant(0)
+    ref = torch.nn.grad.conv2d_weight(_nchw(torch.from_numpy(xv)), (K, C, 3, 3), _nchw(torch.from_numpy(dv)), 1, 1).permute(0, 2, 3, 1)
+    assert torch.equal(eng.tensors[sl['dw']].cpu(), ref.contiguous())
+
+
+STREAMK = [
+    (29, 16, 16, 256, 256, 3, 1, 1),     # 29 tiles x 36 K tiles over 256 workgroups: every tile cut into ~9 parts (multi-part ticketed sums)
+    (37, 32, 32, 256, 512, 1, 1, 0),     # 148 x 2 = 296 tiles: 256 + 40 tiles as stream-K units of a 4-K-tile reduction, cuts inside and between tiles
+    (128, 14, 14, 512, 512, 3, 1, 1),    # the production case: 196 tiles of 72 K tiles, 55 units per workgroup
+]
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('g', STREAMK)
+def test_igemm8_stream_k(g, dtype):
+    """grids that are no multiple of the CU count: the last rounds are cut into K-tile units (stream-K) and cut tiles are summed through the workspace by
+    the last-arriving workgroup, in slice order.  Results against the reference, AND bit-identical between two runs (the sum order is fixed)."""
+    import gpu_harness as h                               # noqa: F401  (engines set the workspace)
+    ran = run_conv_case(g, dtype, variant=IGEMM8)
+    assert ran[0].startswith('igemm8<256x256:'), ran
+
+
+def test_igemm8_stream_k_is_reproducible_and_equals_whole_tiles():
+    """same convolution three times: stream-K twice (bit-identical: parts are added in slice order whoever arrives last) and with whole tiles only
+    (rn_set_variant 1 << 28): equal to fp32 rounding of the differently ordered K sums."""
+    g = (29, 16, 16, 256, 256, 3, 1, 1)
+    N, Hh, W, C, K, k, s_, p = g
+    eng, sl = _one_op_engine(ir.OP_CONV_FWD, g, dict(x=((N, Hh, W, C), 'T'), w_fwd=((K, k * k, C), 'T'), y=((N, Hh, W, K), 'T')))
+    rng = np.random.RandomState(3)
+    eng.tensors[sl['x']].copy_(torch.from_numpy(rng.randn(N, Hh, W, C).astype(np.float32)).to(torch.float16))
+    eng.tensors[sl['w_fwd']].copy_(torch.from_numpy((rng.randn(K, k * k, C) * 0.02).astype(np.float32)).to(torch.float16))
+    eng.bind({})
+    L = _lib.lib()
+    outs = []
+    try:
+        for v in (IGEMM8, IGEMM8, IGEMM8 | (1 << 28)):
+            L.rn_set_variant(v)
+            eng.tensors[sl['y']].zero_()
+            eng.run(0, 1, 0)
+            torch.cuda.synchronize()
+            outs.append(eng.tensors[sl['y']].float().cpu().clone())
+    finally:
+        L.rn_set_variant(0)
+    assert torch.equal(outs[0], outs[1])
+    assert float((outs[0] - outs[2]).abs().max()) <= 2e-3 * float(outs[2].abs().max())
+    assert not torch.equal(outs[2], torch.zeros_like(outs[2]))
+
+
 @pytest.mark.parametrize('g', [(2, 16, 16, 128, 256, 3, 1, 1), (3, 14, 14, 64, 256, 1, 1, 0)])
 def test_igemm8_exact_integers(g):
     """integer operands: the eight-phase kernel must equal the reference bit for bit (fragment <-> pixel / channel maps, tap walk, stage toggling)."""

@@ -1,6 +1,7 @@
 """Host-side mirrors of the reference interface around the hot path: config surface, metrics, factories (CPU), and the
 script.py entrypoint + step harness end to end on one GPU."""
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -94,6 +95,67 @@ def test_script_entrypoint_single_gpu(tmp_path, capsys):
         (script.train if mode == 'train' else script.evaluate)(0, config)
     out = capsys.readouterr().out
     assert 'global step: 2' in out and 'Test metrics' in out
+
+
+@pytest.mark.gpu
+def test_script_saves_and_resumes(tmp_path, capsys):
+    """script.py train: rank 0 writes {checkpoint_strategy, classifier, optimizer, scheduler, scaler}_{steps}.pth at the reference's points
+    (/root/reference/resnet/algos/training.py:129-139,161-171); a second run RESUMES at that step (script.py:84-94) instead of starting over."""
+    import yaml
+    import script
+    run = tmp_path / 'tiny'
+    run.mkdir()
+    cfg = yaml.safe_load(open(os.path.join(ROOT, 'models_dir', 'resnet-v1-20_cifar10', 'config.yaml')))
+    cfg.update(world_size=1, master_addr='127.0.0.1', master_port='29519', max_steps=2, batch_size=16,
+               checkpoint_strategy_cls_name='FrequencyCheckpointStrategy', checkpoint_strategy_args=dict(unit='batch', frequency=1))
+    yaml.safe_dump(cfg, open(run / 'config.yaml', 'w'))
+    argv = ['--mode', 'train', '--models_dir', str(tmp_path), '--run_name', 'tiny', '--data_dir', 'synthetic']
+    script.train(0, script.get_config(script.create_argparser().parse_args(argv)))
+    files = sorted(os.listdir(run / 'checkpoints'))
+    for kind in ('checkpoint_strategy', 'classifier', 'optimizer', 'scheduler', 'scaler'):
+        assert f'{kind}_2.pth' in files, files                # saved after step index 1 as steps = 2
+    sd = torch.load(run / 'checkpoints' / 'classifier_2.pth')
+    assert all(k.startswith('module.') for k in sd)            # DistributedDataParallel's key scheme, as the reference writes it
+    capsys.readouterr()
+    cfg['max_steps'] = 4
+    yaml.safe_dump(cfg, open(run / 'config.yaml', 'w'))
+    script.train(0, script.get_config(script.create_argparser().parse_args(argv)))
+    out = capsys.readouterr().out
+    assert 'Loaded classifier checkpoint' in out and 'with step 2' in out
+    assert 'global step: 2...' in out and 'global step: 3...' in out and 'global step: 0...' not in out      # resumed, not restarted
+    assert 'classifier_4.pth' in os.listdir(run / 'checkpoints')
+
+
+@pytest.mark.gpu
+def test_script_eval_reads_a_reference_checkpoint(tmp_path, capsys):
+    """script.py --mode eval over a checkpoint directory WRITTEN BY THE REFERENCE (tests/golden/ckpt): the classifier is restored (no
+    'Running from scratch' for it) and the logits of the golden evaluation batch are the reference's (g9_checkpoint.npz: eval_logits)."""
+    import shutil
+    import numpy as np
+    import yaml
+    import script
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    from filler import fill
+    run = tmp_path / 'ck'
+    (run / 'checkpoints').mkdir(parents=True)
+    shutil.copy(os.path.join(ROOT, 'tests', 'golden', 'ckpt', 'classifier_3.pth'), run / 'checkpoints' / 'classifier_3.pth')
+    cfg = yaml.safe_load(open(os.path.join(ROOT, 'models_dir', 'resnet-v1-20_cifar10', 'config.yaml')))
+    cfg.update(world_size=1, master_addr='127.0.0.1', master_port='29521', batch_size=16, compute_dtype='fp32',
+               architecture_spec='c3,16,3,1,1 r1 r1 r1 n a ap8,1,0 fc64,10', preact=True, use_proj=True, dropout_prob=0.0)
+    yaml.safe_dump(cfg, open(run / 'config.yaml', 'w'))
+    args = script.create_argparser().parse_args(['--mode', 'eval', '--models_dir', str(tmp_path), '--run_name', 'ck', '--data_dir', 'synthetic'])
+    config = script.get_config(args)
+    system = script.setup(0, config)
+    try:
+        assert system['global_step'] == 3
+        g = np.load(os.path.join(ROOT, 'tests', 'golden', 'g9_checkpoint.npz'))
+        m = system['classifier'].eval()
+        with torch.no_grad():
+            lg = m(torch.from_numpy(fill((4, 3, 32, 32), 701)).cuda())
+        assert np.abs(lg.cpu().numpy() - g['eval_logits']).max() < 1e-4 * np.abs(g['eval_logits']).max()
+    finally:
+        torch.distributed.destroy_process_group()
+    assert 'Loaded classifier checkpoint' in capsys.readouterr().out
 
 
 @pytest.mark.gpu
