@@ -109,9 +109,6 @@ void rn_set_variant(int v);
  * zero (tile tickets; the kernels leave them zero), owned by the caller, used by one stream at a time.  NULL (default): whole tiles only. */
 size_t rn_conv_workspace_bytes(void);
 int rn_set_conv_workspace(void* p, size_t bytes);
-/* the same for the 256 x 256 weight-gradient kernel (csrc/conv_wgrad8.hip); its own memory: weight gradients run on the plan's side stream */
-size_t rn_wgrad8_workspace_bytes(void);
-int rn_set_wgrad8_workspace(void* p, size_t bytes);
 /* which convolution kernel ran: rn_kernel_log(1) starts (and clears) a per-thread log of the instantiations the conv launchers
  * pick ("igemm_dma<128x160>", "wgrad<160x160>", ...), rn_kernel_log_read() returns them comma-separated, rn_kernel_log(0) stops.
  * rn_conv_kernel_names: the names a geometry WOULD select (pass 0 forward, 1 dgrad, 2 wgrad), without launching anything

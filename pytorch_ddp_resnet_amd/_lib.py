@@ -65,8 +65,6 @@ def lib():
     L.rn_set_variant.argtypes = [i32]
     L.rn_conv_workspace_bytes.restype = sz
     L.rn_set_conv_workspace.argtypes = [vp, sz]
-    L.rn_wgrad8_workspace_bytes.restype = sz
-    L.rn_set_wgrad8_workspace.argtypes = [vp, sz]
     L.rn_augment_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
     L.rn_amp_check_unscale.argtypes = [vp, C.c_int64, vp, vp, vp]
     L.rn_kernel_log.argtypes = [i32]

@@ -569,18 +569,22 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
         const int parts = w_last - w_first + 1;
         f32x4* slots = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.w8_ws) + SK_CNT_BYTES);
         constexpr size_t SLOT = (size_t)RT * CT * 512;       // f32x4 per slot: register-major, thread-minor (every access 16 bytes per lane, coalesced)
-        f32x4* mine = slots + (size_t)(wv * 2 + pseg) * SLOT + tid;
+        // the part goes out WRITE-THROUGH (sc1 buffer stores: the bytes leave this XCD's L2 at once), so publishing it needs no release fence -- a
+        // fence here writes back the whole L2 (256 KiB of fresh lines per workgroup, 32 workgroups per XCD: tens of microseconds, measured)
+        {
+          const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(slots), 0, 0x7FFFFFF0, 0x00020000);
+          const unsigned mine_off = (unsigned)(((size_t)(wv * 2 + pseg) * SLOT + tid) * 16);
 #pragma unroll
-        for (int i = 0; i < RT; ++i)
+          for (int i = 0; i < RT; ++i)
 #pragma unroll
-          for (int j = 0; j < CT; ++j) mine[(size_t)(i * CT + j) * 512] = acc[i][j];
+            for (int j = 0; j < CT; ++j)
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, acc[i][j]), wsr, (int)(mine_off + (unsigned)((i * CT + j) * 512 * 16)), 0, 16);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains, then the workgroup meets, then ONE lane releases and signals
         __syncthreads();
         int* cnt = reinterpret_cast<int*>(a.w8_ws) + pt_sk;
         volatile int* flagw = reinterpret_cast<volatile int*>(&smem[2 * STG + TAP_INTS / 4 + 8 * 16]);
         if (tid == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (keep: the compiler may drop the fence's own wait)
           *flagw = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         __syncthreads();
@@ -680,13 +684,16 @@ template <typename T> int launch8(IgemmArgs& a, hipStream_t s) {
   rn_note_kernel("igemm8<256x%d:%s>", BN, EPN[ep8_mode(a)]);
   if (rn_dry_run()) return 0;
   const int ntiles = cdiv(a.M, 256) * (a.Kd / BN);
-  // data-parallel rounds, then stream-K over the last (1 + fraction) rounds -- when the grid wastes more than 8 % of its last round, a workspace is
-  // set (rn_set_conv_workspace) and every workgroup still gets a few K tiles.  rn_set_variant 1 << 28: never (A/B).
+  // stream-K (tiles cut into K-tile unit ranges, cut tiles summed through the workspace) only where whole tiles cannot occupy the chip: grids of at most
+  // half the CUs.  On larger grids the fp32 parts (256 KiB written + re-read per cut) cost what the saved tail round buys -- measured on the WRN-50-2
+  // shapes at batch 256: 3x3 512@14 237 vs 230 us, 1024@7 231 vs 219, 1x1 2048 -> 512 164 vs 111.  rn_set_variant 1 << 28: never;
+  // 1 << 31: wherever the grid is no multiple of the CU count (tests of the mixed data-parallel + stream-K walk).
   int grid = ntiles < SK_GRID ? ntiles : SK_GRID;
   a.w8_dp_tiles = ntiles;
   a.w8_ws = g_sk_ws;
   const int rem = ntiles % SK_GRID, full = ntiles / SK_GRID;
-  if (rem != 0 && g_sk_ws && g_sk_ws_bytes >= SK_CNT_BYTES + 2 * SK_GRID * SK_SLOT_BYTES && !(g_rn_variant & (1 << 28)) && (double)ntiles / ((full + 1) * SK_GRID) < 0.92) {
+  const bool sk_forced = (g_rn_variant & (1u << 31)) != 0;
+  if (rem != 0 && g_sk_ws && g_sk_ws_bytes >= SK_CNT_BYTES + 2 * SK_GRID * SK_SLOT_BYTES && !(g_rn_variant & (1 << 28)) && (sk_forced || 2 * ntiles <= SK_GRID)) {
     const int sk_tiles = full >= 1 ? SK_GRID + rem : rem;
     const long units = (long)sk_tiles * a.nk;
     if (units >= 4L * SK_GRID && units * SK_GRID < (1L << 31) && sk_tiles <= (int)(SK_CNT_BYTES / 4)) {

@@ -14,8 +14,8 @@
 
 extern int g_rn_variant;   // conv_igemm.hip (rn_set_variant)
 // conv_wgrad8.hip: the eight-phase kernel for channel counts that are multiples of 256 (stream-K, sums in-kernel: no slabs, no reduction launch)
-int rn_wgrad8_applies(const rn_conv_geom* g, int dtype);
-int rn_launch_wgrad8(const void* x, const void* dy, float* dw, int flags, int dtype, const rn_conv_geom* g, hipStream_t s);
+int rn_wgrad8_splits(const rn_conv_geom* g, int dtype);
+int rn_launch_wgrad8(const void* x, const void* dy, float* out, int splits, int dtype, const rn_conv_geom* g, hipStream_t s);
 
 namespace {
 
@@ -479,7 +479,9 @@ extern "C" size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g) {
     const size_t need = (size_t)wgrad_splits(g, bk, bc, ic, wgrad_capacity(bk, bc, ce)) * g->K * g->R * g->S * g->C * sizeof(float);
     if (need > best) best = need;
   }
-  return best;
+  const int w8 = rn_wgrad8_splits(g, RN_F16);             // the eight-phase kernel's own split count (16-bit engines)
+  const size_t need8 = w8 > 0 ? (size_t)w8 * g->K * g->R * g->S * g->C * sizeof(float) : 0;
+  return need8 > best ? need8 : best;
 }
 
 extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void* ws, size_t ws_bytes, int flags, int dtype,
@@ -490,7 +492,7 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   RN_CHECK_ARG(g->C % ce == 0 && g->K % ce == 0, "rn_conv_wgrad: C=%d, K=%d must be multiples of %d", g->C, g->K, ce);
   RN_CHECK_ARG(g->R == g->S && g->R * g->S <= MAX_TAPS, "rn_conv_wgrad: kernel %dx%d unsupported", g->R, g->S);
   RN_CHECK_ARG((long)g->N * g->P * g->Q < (1L << 31), "rn_conv_wgrad: too many pixels");
-  if (rn_wgrad8_applies(g, dtype)) return rn_launch_wgrad8(x, dy, dw_krsc, flags, dtype, g, as_stream(s));
+  const int w8 = rn_wgrad8_splits(g, dtype);            // > 0: the eight-phase kernel with that many pixel splits (its slabs take the same reduction)
   const bool ic = use_im2col(g, ce);
   const int bk = pick_tile(g->K), bc = col_tile(g, ic);
   WgradArgs a{};
@@ -512,7 +514,7 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   // (26 per WRN-28-10 step); with an eighth of the slots left free they dispatch at once.  rn_set_variant 1 << 24: full round.
   const int round = (g_rn_variant & (1 << 23)) ? 512 : wgrad_capacity(bk, bc, ce);       // 1 << 23: the fixed 512-workgroup round (A/B)
   const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? round / 8 * 7 : round;
-  a.splits = wgrad_splits(g, bk, bc, ic, capacity);
+  a.splits = w8 > 0 ? w8 : wgrad_splits(g, bk, bc, ic, capacity);
   a.rows_per_split = ((a.M + a.splits - 1) / a.splits + 31) / 32 * 32;
   a.kt = cdiv(g->K, bk); a.ct = cdiv(ic ? g->R * g->S * g->C : g->C, bc);
   const size_t n = (size_t)g->K * a.RS * g->C;
@@ -523,7 +525,8 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   }
   a.out = direct ? dw_krsc : reinterpret_cast<float*>(ws);
   int e = 0;
-  RN_BY_DTYPE(dtype, e = dispatch_w<T_>(a, bk, bc, as_stream(s)));
+  if (w8 > 0) e = rn_launch_wgrad8(x, dy, a.out, a.splits, dtype, g, as_stream(s));
+  else RN_BY_DTYPE(dtype, e = dispatch_w<T_>(a, bk, bc, as_stream(s)));
   if (e) return e;
   if (!direct) {
     const long n4 = (long)(n / 4);
@@ -554,13 +557,13 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
 
 extern "C" int rn_conv_wgrad_splits(const rn_conv_geom* g, int dtype, int flags) {
   if (!g || !RN_DTYPE_OK(dtype)) return -1;
-  if (rn_wgrad8_applies(g, dtype)) return 0;            // sums its split-K parts itself
   const int ce = dtype == RN_F32 ? 4 : 8;
   const bool ic = use_im2col(g, ce);
   const int bk = pick_tile(g->K), bc = col_tile(g, ic);
   const int round = (g_rn_variant & (1 << 23)) ? 512 : wgrad_capacity(bk, bc, ce);
   const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? round / 8 * 7 : round;
-  const int splits = wgrad_splits(g, bk, bc, ic, capacity);
+  const int w8 = rn_wgrad8_splits(g, dtype);
+  const int splits = w8 > 0 ? w8 : wgrad_splits(g, bk, bc, ic, capacity);
   if (splits == 1 && !(flags & RN_F_ACCUM)) return 0;
   const long n4 = (long)g->K * g->R * g->S * g->C / 4;
   return reduce_is_wide(splits, n4) ? splits : -1;

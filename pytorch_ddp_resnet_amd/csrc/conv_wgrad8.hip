@@ -11,21 +11,17 @@
 //     eight pixel rows one transposed read touches land on sixteen distinct 16-byte slots;
 //   * the pixel walk is the K loop: every K tile a lane decodes the two pixels it copies (magic division; tap shift and padding become out-of-range
 //     DMA offsets = zeros); the dy rows are dense;
-//   * the reduction is long (M / 64 K tiles) and the tiles are few (K/256 x C/256 x taps), so ALL work is stream-K: the tiles' K tiles are cut into
-//     equal contiguous unit ranges, one per workgroup; a cut tile is summed through the workspace by whoever draws its last ticket, in slice order
-//     (conv_igemm8.hip has the protocol) -- no slab round trip through a second kernel, bitwise reproducible.
+//   * the reduction is long (M / 64 K tiles) and the tiles are few (K/256 x C/256 x taps): the pixels are cut into S equal splits (S from a cost model:
+//     rounds of 256 workgroups x K tiles per split vs the slab traffic), work item = (split, tile), split-major, so the workgroups that run side by
+//     side on one XCD read the SAME pixels for different tiles and share them through its L2 (with contiguous K-tile ranges per workgroup -- a stream-K
+//     split, tried first -- every workgroup streams its own pixels and the kernel is bound by the Infinity Cache: 2.7 us per K tile instead of 1.4);
+//     each item writes its fp32 tile into slab [split] in the gradient's own layout and the fixed-order reduction kernels of conv_wgrad.hip sum the
+//     slabs (bitwise reproducible; S = 1 writes the gradient directly).
 // Epilogue: the products are taken with x as the MFMA row operand, so a lane holds four consecutive input channels of one output channel: one
 // 16-byte fp32 store (or load-add-store when accumulating) per accumulator tile.
 #include "igemm_shared.h"
 
-static void* g_wg8_ws = nullptr;
-static size_t g_wg8_ws_bytes = 0;
-
 namespace {
-
-constexpr size_t WG8_CNT_BYTES = 4096;
-constexpr int WG8_GRID = 256;
-constexpr size_t WG8_SLOT_BYTES = (size_t)512 * 128 * 4;
 
 template <int N> __device__ inline void wait_lgkm8() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory"); }
 __device__ inline void raw_barrier8() {
@@ -43,8 +39,9 @@ struct Wg8Args {
   int M, nk;               // output pixels; K tiles of 64 pixels
   int nct, ntiles;         // column (input-channel) tiles; tiles = K/256 * C/256 * taps
   unsigned magic_pq, magic_q;
-  int accum, dense;        // dense: 1x1, stride 1, no padding (pixel m reads x pixel m)
-  void* ws;
+  int dense;               // 1x1, stride 1, no padding (pixel m reads x pixel m)
+  int splits, per;         // pixel splits, K tiles per split; slab s at dw + s * slab_stride
+  long slab_stride;        // K * RS * C floats (0 when splits == 1: dw is the gradient itself)
 };
 
 template <typename T> struct Tr16;
@@ -69,7 +66,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const Wg8Args a) {
   constexpr int ES = 2, RT = 8, CT = 4, QR = 4, QC = 2, AI = 2, BI = 2;
   constexpr int STGB = 65536;                                // bytes per stage: A0 | A1 | B0 | B1 (16 KiB each); the stage toggles by XOR
   constexpr int HALF = 16384;
-  __shared__ uint4 smem[2 * STGB / 16 + 1];                  // two stages | one ticket word
+  __shared__ uint4 smem[2 * STGB / 16];                      // two stages
   const char* lds = reinterpret_cast<const char*>(&smem[0]);
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);
 
@@ -98,13 +95,9 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const Wg8Args a) {
 #pragma unroll
   for (int j = 0; j < QC; ++j) fb[j] = 2 * HALF + frow + ((((4 * wn + 2 * j) ^ ff) | (tp >> 1)) << 4);
 
-  // ---- stream-K work list ----
-  const int G = gridDim.x;
-  const unsigned U = (unsigned)a.ntiles * (unsigned)nk;
-  const int wv = (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3);
-  const unsigned su0 = (unsigned)wv * U / (unsigned)G, su1 = (unsigned)(wv + 1) * U / (unsigned)G;
-  unsigned su = su0;
-
+  // ---- work list: item = (split, tile), split-major; workgroup b takes items remap(b), remap(b + G), ... where remap hands each XCD class (b % 8) a
+  // contiguous eighth of the item order, its workgroups interleaved: XCD-mates run neighbouring items = the same split, different tiles ----
+  const int G = gridDim.x, nitems = a.ntiles * a.splits;
   int dh = 0, dw_ = 0;                                       // the current tile's tap
   unsigned a_base = 0, b_base = 0;                           // + channel offsets of the tile
   auto decode = [&](int g, Rows8& r) {                       // the lane's two pixels of K tile g
@@ -225,18 +218,18 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const Wg8Args a) {
     raw_barrier8();
   };
 
-  int ptile = -1, pseg = 0, pwhole = 0;                      // the segment whose accumulators are still in registers
-  for (;;) {
-    int tile = 0, kb = 0, ke = 0, seg = 0;
-    const bool more = su < su1;                              // wave-uniform
+  int ptile = -1, psplit = 0;                                // the item whose accumulators are still in registers
+  for (int it = 0;; ++it) {
+    const int vb = it * G + (int)blockIdx.x;
+    const bool more = vb < nitems;                           // wave-uniform
+    int tile = 0, split = 0, kb = 0, ke = 0;
     if (more) {
-      tile = (int)(su / (unsigned)nk);
-      kb = (int)(su - (unsigned)tile * (unsigned)nk);
-      ke = min(nk, kb + (int)(su1 - su));
-      seg = su == su0 ? 0 : 1;
-      su += (unsigned)(ke - kb);
+      const int xcd = vb & 7, q = nitems >> 3, r = nitems & 7;
+      const int item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+      split = item / a.ntiles; tile = item - split * a.ntiles;
+      kb = split * a.per; ke = min(nk, kb + a.per);
     }
-    const int nseg = ke - kb;
+    const int nseg = ke - kb;                                // >= 1 (launcher: per * (splits - 1) < nk)
     Rows8 r0{}, r1{};
     if (more) {
       const int t = tile % a.RS, rest = tile / a.RS, ct = rest % a.nct, kt_ = rest / a.nct;
@@ -247,70 +240,16 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const Wg8Args a) {
       issue_b(0, lds0, r0); issue_a(0, lds0, r0); issue_b(1, lds0, r0); issue_a(1, lds0, r0);
       if (nseg > 1) { decode(kb + 1, r1); issue_b(0, lds0 + STGB, r1); issue_a(0, lds0 + STGB, r1); issue_b(1, lds0 + STGB, r1); }
     }
-    if (ptile >= 0) {
-      bool finish = true;
-      if (!pwhole) {                                         // a part of a cut tile: publish, draw a ticket; the last arriver sums the parts in slice order
-        const unsigned uf = (unsigned)ptile * (unsigned)nk;
-        const int w_first = (int)(((uf + 1u) * (unsigned)G - 1u) / U), w_last = (int)(((uf + (unsigned)nk) * (unsigned)G - 1u) / U);
-        const int parts = w_last - w_first + 1;
-        f32x4* slots = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.ws) + WG8_CNT_BYTES);
-        constexpr size_t SLOT = (size_t)RT * CT * 512;
-        f32x4* mine = slots + (size_t)(wv * 2 + pseg) * SLOT + tid;
+    if (ptile >= 0) {        // acc[i][j][r]: input channel c0 + 128 wm + 16 i + 4 lq + r, output channel k0 + 64 wn + 16 j + l16
+      const int t = ptile % a.RS, rest = ptile / a.RS, ct = rest % a.nct, kt_ = rest / a.nct;
+      const int c0 = ct * 256 + 128 * wm + 4 * lq, k0 = kt_ * 256 + 64 * wn + l16;
+      float* out = a.dw + (size_t)psplit * a.slab_stride;
+#pragma unroll
+      for (int j = 0; j < CT; ++j) {
+        float* row = out + ((size_t)(k0 + 16 * j) * a.RS + t) * a.C + c0;
 #pragma unroll
         for (int i = 0; i < RT; ++i)
-#pragma unroll
-          for (int j = 0; j < CT; ++j) mine[(size_t)(i * CT + j) * 512] = acc[i][j];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int* cnt = reinterpret_cast<int*>(a.ws) + ptile;
-        volatile int* flagw = reinterpret_cast<volatile int*>(&smem[2 * STGB / 16]);
-        if (tid == 0) {
-          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          *flagw = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        __syncthreads();
-        finish = *flagw == parts - 1;
-        if (finish) {
-          if (tid == 0) {
-            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-          __syncthreads();
-#pragma unroll
-          for (int i = 0; i < RT; ++i)
-#pragma unroll
-            for (int j = 0; j < CT; ++j)
-#pragma unroll
-              for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-          for (int sl = 0; sl < parts; ++sl) {
-            const int wq = w_first + sl;
-            const int sq = (int)(((unsigned)wq * U / (unsigned)G) / (unsigned)nk) == ptile ? 0 : 1;
-            const f32x4* src = slots + (size_t)(wq * 2 + sq) * SLOT + tid;
-#pragma unroll
-            for (int i = 0; i < RT; ++i)
-#pragma unroll
-              for (int j = 0; j < CT; ++j) acc[i][j] += src[(size_t)(i * CT + j) * 512];
-          }
-        } else {
-          __syncthreads();
-        }
-      }
-      if (finish) {                                          // acc[i][j][r]: input channel c0 + 128 wm + 16 i + 4 lq + r, output channel k0 + 64 wn + 16 j + l16
-        const int t = ptile % a.RS, rest = ptile / a.RS, ct = rest % a.nct, kt_ = rest / a.nct;
-        const int c0 = ct * 256 + 128 * wm + 4 * lq, k0 = kt_ * 256 + 64 * wn + l16;
-#pragma unroll
-        for (int j = 0; j < CT; ++j) {
-          float* row = a.dw + ((size_t)(k0 + 16 * j) * a.RS + t) * a.C + c0;
-#pragma unroll
-          for (int i = 0; i < RT; ++i) {
-            float4* o = reinterpret_cast<float4*>(row + 16 * i);
-            float4 v = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-            if (a.accum) { const float4 old = *o; v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
-            *o = v;
-          }
-        }
+          *reinterpret_cast<float4*>(row + 16 * i) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
       }
     }
     if (!more) break;
@@ -338,36 +277,43 @@ __global__ __launch_bounds__(512, 2) void wgrad8_kernel(const Wg8Args a) {
     }
     ktile(std::integral_constant<int, 0>{}, sx, prev, prev);
     if (wave < 4) raw_barrier8();
-    ptile = tile; pseg = seg; pwhole = (kb == 0 && ke == nk) ? 1 : 0;
+    ptile = tile; psplit = split;
   }
 }
 
 }  // namespace
 
-extern "C" size_t rn_wgrad8_workspace_bytes(void) { return WG8_CNT_BYTES + 2 * WG8_GRID * WG8_SLOT_BYTES; }
-// workspace of the eight-phase weight-gradient kernel (tile tickets, zero; then fp32 partial tiles): as rn_set_conv_workspace, but its own memory -- the
-// plan executor runs weight gradients on a side stream beside the data gradients
-extern "C" int rn_set_wgrad8_workspace(void* p, size_t bytes) {
-  g_wg8_ws = p; g_wg8_ws_bytes = p ? bytes : 0;
-  return 0;
+// pixel splits for the eight-phase kernel: minimise rounds x K tiles per split (1.4 us each) + slab traffic (written once, read once, ~4 TB/s)
+static int wgrad8_pick_splits(long ntiles, long nk, double n_floats) {
+  int best = 1;
+  double best_cost = 1e30;
+  const long smax = nk / 4 < 128 ? (nk / 4 < 1 ? 1 : nk / 4) : 128;
+  for (long S = 1; S <= smax; ++S) {
+    const long per = (nk + S - 1) / S;
+    if (per * (S - 1) >= nk) continue;                                       // an empty last split
+    const long rounds = (ntiles * S + 255) / 256;
+    const double cost = rounds * per * 1.4 + (S > 1 ? S * n_floats * 8.0 / 4.0e6 : 0.0) + (S > 1 ? 6.0 : 0.0);
+    if (cost < best_cost - 1e-9) { best_cost = cost; best = (int)S; }
+  }
+  return best;
 }
 
-// 1 when rn_conv_wgrad takes the eight-phase kernel for this geometry (it then needs no slab workspace and no reduction launch)
-int rn_wgrad8_applies(const rn_conv_geom* g, int dtype) {
+// 0: rn_conv_wgrad does not take the eight-phase kernel for this geometry; S >= 1: it does, with S pixel splits (S > 1: slabs + the reduction kernels)
+int rn_wgrad8_splits(const rn_conv_geom* g, int dtype) {
   if (dtype != RN_BF16 && dtype != RN_F16) return 0;
   if (g_rn_variant & (1 << 29)) return 0;                                      // A/B: never
-  if (!g_wg8_ws || g_wg8_ws_bytes < WG8_CNT_BYTES + 2 * WG8_GRID * WG8_SLOT_BYTES) return 0;
   if (g->C % 256 || g->K % 256 || g->R != g->S) return 0;
   const long M = (long)g->N * g->P * g->Q;
   if ((double)g->N * g->H * g->W * g->C * 2 >= 4.0e9 || (double)M * g->K * 2 >= 4.0e9) return 0;      // 32-bit DMA offsets
   const long nk = (M + 63) / 64, ntiles = (long)(g->K / 256) * (g->C / 256) * g->R * g->S;
-  if (ntiles > (long)(WG8_CNT_BYTES / 4) || ntiles * nk * WG8_GRID >= (1L << 31)) return 0;
-  return (ntiles * nk >= 8L * WG8_GRID || (g_rn_variant & (1 << 30))) ? 1 : 0;  // every workgroup gets a few K tiles (1 << 30: any size, tests)
+  if (ntiles * nk < 8L * 256 && !(g_rn_variant & (1 << 30))) return 0;        // too small to fill the chip (1 << 30: any size, tests)
+  return wgrad8_pick_splits(ntiles, nk, (double)g->K * g->R * g->S * g->C);
 }
 
-int rn_launch_wgrad8(const void* x, const void* dy, float* dw, int flags, int dtype, const rn_conv_geom* g, hipStream_t s) {
+// out: the gradient itself (splits == 1) or the slab region [splits][K][RS][C]
+int rn_launch_wgrad8(const void* x, const void* dy, float* out, int splits, int dtype, const rn_conv_geom* g, hipStream_t s) {
   Wg8Args a{};
-  a.x = x; a.dy = dy; a.dw = dw;
+  a.x = x; a.dy = dy; a.dw = out;
   a.N = g->N; a.H = g->H; a.W = g->W; a.C = g->C; a.P = g->P; a.Q = g->Q; a.K = g->K;
   a.stride = g->stride; a.pad = g->pad; a.S = g->S; a.RS = g->R * g->S;
   a.M = g->N * g->P * g->Q; a.nk = (a.M + 63) / 64;
@@ -375,14 +321,13 @@ int rn_launch_wgrad8(const void* x, const void* dy, float* dw, int flags, int dt
   const unsigned long long pq = (unsigned long long)g->P * g->Q;
   a.magic_pq = pq <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / pq);
   a.magic_q = g->Q <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned)g->Q);
-  a.accum = (flags & RN_F_ACCUM) ? 1 : 0;
   a.dense = (a.RS == 1 && g->stride == 1 && g->pad == 0 && g->H == g->P && g->W == g->Q) ? 1 : 0;
-  a.ws = g_wg8_ws;
+  a.splits = splits; a.per = (a.nk + splits - 1) / splits;
+  a.slab_stride = splits > 1 ? (long)g->K * a.RS * g->C : 0;
   rn_note_kernel("wgrad8<256x256>");
   if (rn_dry_run()) return 0;
-  long units = (long)a.ntiles * a.nk;
-  int grid = WG8_GRID;
-  while (grid > 8 && units < 2L * grid) grid -= 8;                              // (tests on tiny shapes: at least two K tiles per workgroup)
+  const long items = (long)a.ntiles * splits;
+  const int grid = items < 256 ? (int)items : 256;
   if (dtype == RN_BF16) hipLaunchKernelGGL((wgrad8_kernel<bf16_t>), dim3(grid), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((wgrad8_kernel<f16_t>), dim3(grid), dim3(512), 0, s, a);
   RN_CHECK_LAUNCH("wgrad8");

@@ -409,6 +409,7 @@ template <int CPRT> __device__ inline int swz_t(int row, int chunk) {
 }
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
+typedef unsigned v4u32 __attribute__((ext_vector_type(4)));
 
 // raw buffer descriptor (stride 0, bounds-checked on num_records bytes), built from wave-uniform values only
 __device__ inline v4i32 make_desc(const void* base, size_t bytes) {

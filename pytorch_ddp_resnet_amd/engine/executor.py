@@ -38,17 +38,13 @@ def ensure_conv_workspace(device: torch.device):
     L = _lib.lib()
     if os.environ.get('RN_NO_STREAMK', '0') == '1':
         L.rn_set_conv_workspace(None, 0)
-        L.rn_set_wgrad8_workspace(None, 0)
         return None
     idx = device.index if device.index is not None else torch.cuda.current_device()
     if idx not in _conv_ws:
-        # two regions: forward / data-gradient kernels (launch stream) and the weight-gradient kernel (side stream) run concurrently
-        _conv_ws[idx] = (torch.zeros(int(L.rn_conv_workspace_bytes()), dtype=torch.uint8, device=device),
-                         torch.zeros(int(L.rn_wgrad8_workspace_bytes()), dtype=torch.uint8, device=device))
-    t, tw = _conv_ws[idx]
+        _conv_ws[idx] = torch.zeros(int(L.rn_conv_workspace_bytes()), dtype=torch.uint8, device=device)
+    t = _conv_ws[idx]
     _lib.check(L.rn_set_conv_workspace(C.c_void_p(t.data_ptr()), t.numel()))
-    _lib.check(L.rn_set_wgrad8_workspace(C.c_void_p(tw.data_ptr()), tw.numel()))
-    return t, tw
+    return t
 
 
 class Engine:

@@ -321,9 +321,9 @@ WGRAD8_SMALL = [
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 @pytest.mark.parametrize('g', WGRAD8_SMALL)
 def test_wgrad8_on_small_geometries(g, dtype):
-    """the eight-phase weight-gradient kernel (conv_wgrad8.hip): transposed fragment reads, per-K-tile pixel decode, stream-K with ticketed sums."""
+    """the eight-phase weight-gradient kernel (conv_wgrad8.hip): transposed fragment reads, per-K-tile pixel decode, pixel splits into slabs."""
     ran = run_conv_case(g, dtype, variant=WGRAD8 | IGEMM8)
-    assert ran[-1] == 'wgrad8<256x256>', ran
+    assert 'wgrad8<256x256>' in ran, ran
 
 
 def test_wgrad8_exact_integers_and_accumulate():
@@ -350,6 +350,7 @@ def test_wgrad8_exact_integers_and_accumulate():
     assert torch.equal(eng.tensors[sl['dw']].cpu(), ref.contiguous())
 
 
+STREAMK_ANY = -(1 << 31)             # rn_set_variant bit 31 (as a C int): stream-K on every grid that is no multiple of the CU count
 STREAMK = [
     (29, 16, 16, 256, 256, 3, 1, 1),     # 29 tiles x 36 K tiles over 256 workgroups: every tile cut into ~9 parts (multi-part ticketed sums)
     (37, 32, 32, 256, 512, 1, 1, 0),     # 148 x 2 = 296 tiles: 256 + 40 tiles as stream-K units of a 4-K-tile reduction, cuts inside and between tiles
@@ -363,7 +364,7 @@ def test_igemm8_stream_k(g, dtype):
     """grids that are no multiple of the CU count: the last rounds are cut into K-tile units (stream-K) and cut tiles are summed through the workspace by
     the last-arriving workgroup, in slice order.  Results against the reference, AND bit-identical between two runs (the sum order is fixed)."""
     import gpu_harness as h                               # noqa: F401  (engines set the workspace)
-    ran = run_conv_case(g, dtype, variant=IGEMM8)
+    ran = run_conv_case(g, dtype, variant=IGEMM8 | STREAMK_ANY)
     assert ran[0].startswith('igemm8<256x256:'), ran
 
 
@@ -380,7 +381,7 @@ def test_igemm8_stream_k_is_reproducible_and_equals_whole_tiles():
     L = _lib.lib()
     outs = []
     try:
-        for v in (IGEMM8, IGEMM8, IGEMM8 | (1 << 28)):
+        for v in (IGEMM8 | STREAMK_ANY, IGEMM8 | STREAMK_ANY, IGEMM8 | (1 << 28)):
             L.rn_set_variant(v)
             eng.tensors[sl['y']].zero_()
             eng.run(0, 1, 0)

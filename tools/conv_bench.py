@@ -10,6 +10,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from pytorch_ddp_resnet_amd import _lib
 
 L = _lib.lib()
+from pytorch_ddp_resnet_amd.engine.executor import ensure_conv_workspace
+_WS = ensure_conv_workspace(torch.device('cuda', 0))          # stream-K / wgrad8 workspaces, as an Engine sets them
 vp = C.c_void_p
 L.rn_conv_fwd.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.POINTER(_lib.RnConvGeom), vp, vp]
 L.rn_conv_dgrad.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_lib.RnConvGeom), vp, vp]
@@ -32,6 +34,7 @@ def run(which, iters, variants, dtype=torch.bfloat16):
         dy = torch.randn(N, H, W, K, device='cuda').to(dtype)
         dx = torch.empty(N, H, W, Cc, device='cuda', dtype=dtype)
         dw = torch.empty(K, ks * ks, Cc, device='cuda')
+        L.rn_set_variant(0)                                 # the workspace is sized for the shipped selection
         wsb = int(L.rn_conv_wgrad_ws_bytes(C.byref(g)))
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device='cuda')
         rn = {torch.bfloat16: 1, torch.float16: 2, torch.float32: 0}[dtype]
