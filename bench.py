@@ -37,8 +37,11 @@ HBM_PEAK_GBS = 8000.0
 
 
 def conv_flops(op):
+    """ALGORITHMIC flops of a convolution launch (2 per MAC of the reference's layer): the stem runs on the MFMA path with its 3 image
+    channels zero-padded to one 16-byte chunk (C = 4 / 8 in the op) -- the padding is not work."""
     d = op.dim
-    return 2.0 * d['N'] * d['P'] * d['Q'] * d['K'] * d['R'] * d['S'] * d['C']
+    c = 3 if d['C'] <= 8 else d['C']
+    return 2.0 * d['N'] * d['P'] * d['Q'] * d['K'] * d['R'] * d['S'] * c
 
 
 def conv_bytes(op, ir, elem):
@@ -111,6 +114,19 @@ def _cpu_model():
     return 'unknown'
 
 
+def self_launch(n):
+    """one rank per GPU through torch.distributed.run (rendezvous on 127.0.0.1, a free port), same arguments; returns the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={n}', '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -138,6 +154,10 @@ def main():
         cfg['batch'] = args.batch
     if args.dropout is not None:
         cfg['p'] = args.dropout
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        # `python bench.py --gpus N` started as the N=1 command is: launch the N ranks ourselves, as CHILD processes of torch.distributed.run, BEFORE this
+        # process has touched the GPU (nothing above initialises HIP), relay their output and exit with their code -- never re-exec a process
+        raise SystemExit(self_launch(args.gpus))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))

@@ -154,9 +154,13 @@ class GradReducer:
                 # forked so far; the compute stream keeps issuing the data-gradient chain (round 1 joined the compute stream here)
                 eng.side_wait(self._comm_stream)
             with torch.cuda.stream(self._comm_stream):
-                buf.mul_(1.0 / self.world)                       # pre-scale: SUM of pre-scaled == mean, no extra pass after
-                if self.world > 1:
-                    self._work.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                if self.world > 1 and dist.get_backend(self.group) == 'nccl':
+                    # RCCL averages inside the collective (ReduceOp.AVG): no scaling pass over the bucket at all
+                    self._work.append(dist.all_reduce(buf, op=dist.ReduceOp.AVG, group=self.group, async_op=True))
+                else:                                            # gloo has no AVG: pre-scale, then SUM (rehearsals of the multi-rank path on one GPU)
+                    buf.mul_(1.0 / self.world)
+                    if self.world > 1:
+                        self._work.append(dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
         else:
             buf.mul_(1.0 / self.world)
             if self.world > 1:

@@ -332,3 +332,26 @@ def test_learns_a_separable_problem_end_to_end(dtype):
         x, y = batch(512)
         acc = float((m(x).argmax(1) == y).float().mean())
     assert acc > 0.95, (acc, losses)
+
+
+@pytest.mark.gpu
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no WORLD_SIZE in the environment (the form of the N = 1 command) spawns the two ranks itself -- children of
+    torch.distributed.run, started before the parent touches the GPU -- and prints ONE JSON line; rehearsed with both ranks on this box's one GPU
+    (RN_BENCH_REHEARSAL=1: collectives through gloo).  A failing child makes the parent exit non-zero."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT')}
+    env['RN_BENCH_REHEARSAL'] = '1'
+    r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1', '--workload', 'rn20', '--no-parity',
+                        '--no-cpu-baseline', '--also', ''], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out['n_gpus'] == 2 and out['value'] > 0 and out['config']['parallelism'] == 'dp2'
+    bad = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '1', '--workload', 'rn20', '--dtype', 'nope'],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0

@@ -3,6 +3,8 @@ reference's golden vectors (G4) and the oracle.  Tolerances (relative to the ten
   fp32 engine: logits 1e-4, loss 1e-5, gradients 1e-3, BN running stats 1e-4  (north-star bound: logits 1e-3)
   bf16 engine: logits 5e-2, identical argmax on the golden batches, gradients 1.5e-1 (bf16 storage of activations
   and gradients through up to 20 layers; reported, not hidden: see DESIGN.md 'Precision')."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -288,5 +290,61 @@ def test_graph_replay_survives_a_reducer(golden):
     assert outs['plain'][1] == 2                                   # forward + backward
     assert outs['reducer'][2] >= 3 and outs['reducer'][1] >= 3     # several buckets -> several captured backward ranges
     for a, b in zip(outs['plain'][0], outs['reducer'][0]):
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
+def test_capture_survives_a_thread_that_synchronises(golden):
+    """The executor captures plan ranges in `thread_local` error mode (engine/executor.py:_replay).  What failed in round 2 was the DEFAULT (global)
+    mode: while the launch thread captured a backward range, a collective backend's own thread (gloo's device-to-host copy / the RCCL watchdog's event
+    query) called a synchronising HIP API, which in global mode invalidates every capture in the process -- hipErrorStreamCaptureInvalidated, one run in
+    four of the two-rank test.  Here that situation is made on purpose: a helper thread records events on its own stream and issues stream / event
+    queries and stream / event synchronisations (the calls those backend threads make) in a tight loop for the whole time the main thread warms up,
+    captures and replays the forward and backward graphs.  The capture must succeed, graphs must be in use, and the replayed steps must equal the
+    eager ones bit for bit.  (A DEVICE-wide hipDeviceSynchronize from another thread is refused -- hipErrorStreamCaptureUnsupported -- and invalidates the
+    capture even in thread_local mode: tried here first; nothing in the product or in the collective backends calls it from a second thread.)"""
+    import threading
+    cfg = MODELS['rn20']
+    g = golden('g4_rn20')
+    shapes, st, x, y, nesterov = model_inputs(g, cfg)
+    xt, yt = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+
+    def steps(m, n):
+        res = []
+        for step in range(n):
+            for p_ in m.parameters():
+                p_.grad = None
+            torch.nn.functional.cross_entropy(m(xt + 0.01 * step), yt).backward()
+            torch.cuda.synchronize()
+            res.append({k: p_.grad.detach().clone() for k, p_ in m.named_parameters()})
+        return res
+
+    os.environ['RN_NO_GRAPHS'] = '1'
+    try:
+        eager = steps(build(cfg, st, 'fp32').train(), 4)
+    finally:
+        del os.environ['RN_NO_GRAPHS']
+    stop, calls = threading.Event(), [0]
+    side = torch.cuda.Stream()
+
+    def pest():
+        ev = torch.cuda.Event()
+        while not stop.is_set():
+            ev.record(side)
+            side.query(); ev.query(); ev.synchronize(); side.synchronize()
+            calls[0] += 1
+
+    th = threading.Thread(target=pest, daemon=True)
+    th.start()
+    try:
+        m = build(cfg, st, 'fp32').train()
+        got = steps(m, 4)                                   # step 0 eager warm-up, step 1 captures, steps 2-3 replay
+    finally:
+        stop.set()
+        th.join()
+    eng = next(e for k, e in m._engines.items() if k[1] and k[2])
+    assert calls[0] > 10
+    assert sum(1 for v in eng._graphs.values() if isinstance(v, torch.cuda.CUDAGraph)) == 2
+    for a, b in zip(eager, got):
         for k in a:
             assert torch.equal(a[k], b[k]), k
