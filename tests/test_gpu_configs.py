@@ -111,10 +111,40 @@ def test_wrn28_10_batch128_16bit(dtype, bound):
     r = rel(logits, lg)
     agree = float((logits.argmax(1) == lg.argmax(1)).float().mean())
     finite = all(bool(torch.isfinite(g).all()) for g in grads.values())
-    print(f'wrn-28-10 b128 {dtype}: logits rel err {r:.3e}, argmax agreement {agree:.4f}, gradients finite {finite}')
+    # the metric is forward + BACKWARD: the timed engine's gradients against the float64 oracle, in total and per parameter (L2, relative; a parameter
+    # whose true gradient is ~0 -- the stem bias in front of a BatchNorm -- is measured against 1e-3 of the total norm instead of its own)
+    g64 = oracle_step(cfg, st, x, y, 10)[2]
+    gtot = float(torch.sqrt(sum((g ** 2).sum() for g in g64.values())))
+    gerr = float(torch.sqrt(sum(((grads[k] - g64[k]) ** 2).sum() for k in g64)))
+    per = {k: float((grads[k] - g64[k]).norm() / max(float(g64[k].norm()), 1e-3 * gtot)) for k in g64}
+    worst = max(per, key=per.get)
+    print(f'wrn-28-10 b128 {dtype}: logits rel err {r:.3e}, argmax agreement {agree:.4f}, gradients finite {finite}, '
+          f'gradient L2 rel err total {gerr / gtot:.3e}, worst parameter {worst} {per[worst]:.3e}, median {sorted(per.values())[len(per) // 2]:.3e}')
     assert r < bound and finite
     if dtype == 'fp16':
         assert agree == 1.0
+        # Measured (round 3, tools/probes/autocast_probe.py on the same weights and batch): this engine 5.0e-4 on the logits and 3.6e-2 on the gradients;
+        # PyTorch-ROCm's own autocast(float16) step -- the reference's GPU arithmetic, script.py:63 / training.py:95-110 -- 8.8e-4 and 4.4e-2; the fp32
+        # engine 8.9e-4 on the gradients (torch fp32 on the GPU: 1.0e-3).  The net amplifies rounding ~7,500x at random init (fp32: 6e-8 -> 4.5e-4), so
+        # fp16 STORAGE of activations and activation gradients (2^-11) lands at a few per cent whoever does it.  Bounds: the reference's own figure.
+        ac_logits, ac_grad = _autocast_reference(cfg, st, x, y, g64)
+        print(f'    torch autocast(fp16) on the GPU, same case: logits rel err {rel(ac_logits, lg):.3e}, gradient L2 rel err {ac_grad / gtot:.3e}')
+        assert gerr / gtot < 6e-2, gerr / gtot
+        assert gerr < 1.25 * ac_grad + 1e-3 * gtot, (gerr / gtot, ac_grad / gtot)
+        assert per[worst] < 0.5, (worst, per[worst])
+
+
+def _autocast_reference(cfg, st, x, y, g64):
+    """the torch port of the reference step on the GPU under torch.autocast(float16) with a loss scale: what the REFERENCE computes on a GPU."""
+    tst = tm.make_trainable({k: v.clone().cuda() for k, v in st.items()})
+    net = tm.TorchResNet(cfg['spec'], cfg['preact'], cfg['use_proj'])
+    with torch.autocast('cuda', dtype=torch.float16):
+        lg = net.forward(tst, x.cuda(), train=True)
+        loss = torch.nn.functional.cross_entropy(lg.float(), y.cuda())
+    (loss * 1024.0).backward()
+    torch.cuda.synchronize()
+    gerr = float(torch.sqrt(sum(((tst[k].grad.double().cpu() / 1024.0 - g64[k]) ** 2).sum() for k in g64)))
+    return lg.detach().double().cpu(), gerr
 
 
 # ---------------------------------------------------------------------------------------------------- config 4
@@ -207,8 +237,46 @@ def test_wrn50_2b_batch256_replicated_batch_property(dtype):
         assert gn_err < 4 * noise['grad_total'] + 1e-3 * gn_ref
         assert (logits[:8].argmax(1) == lg.argmax(1)).all()
     else:
-        # fp16 unit roundoff is 2^13 x fp32's; observed amplification on this case: ~1000x the fp32 noise
-        assert r < 2500 * noise['logits'] and rep < 1e-5 and abs(loss - met['loss']) < 1e-2
+        # fp16 here = what the reference's own autocast(float16) forward gives on this net (2.3e-2 on 32 distinct images, measured in
+        # test_wrn50_2b_fp16_on_a_well_conditioned_batch, where the bound is taken from a live autocast run): a fixed ceiling above that figure
+        assert r < 4e-2 and rep < 1e-5 and abs(loss - met['loss']) < 1e-2
+
+
+def test_wrn50_2b_fp16_on_a_well_conditioned_batch():
+    """config 5 in the TIMED arithmetic (fp16) on a batch that is not degenerate: 32 DISTINCT images at 224 x 224, forward in train mode, against the
+    float64 torch-CPU port -- beside the fp32 engine and PyTorch-ROCm's own autocast(float16) forward (the reference's GPU arithmetic, script.py:63).
+    Measured (round 3, tools/probes/autocast_probe50.py): fp32 engine 2.4e-5 (torch fp32: 2.3e-5 CPU, 2.5e-5 GPU); fp16 engine 2.06e-2; torch autocast
+    2.29e-2.  The fp16 error is not lost at a stage: against the fp32 engine the block outputs differ by 3.6e-4 after the stem and by a further factor
+    of ~1.3 per bottleneck block, up to 8.7e-2 after the sixteenth -- this net (v1 bottlenecks, random init) amplifies ANY rounding ~400x (fp32's 6e-8
+    becomes 2.4e-5), so 2^-11 storage lands at 2e-2 whoever does it.  The north star's 1e-3 on this configuration is met by the fp32 engine; the fp16
+    engine is held to the reference's own GPU arithmetic, not to a widened constant."""
+    cfg = CONFIGS['wrn-50-2b']
+    st = tm.init_state(cfg['spec'], False, True, seed=0)
+    x, y = inputs(cfg, 32, 1000, seed=4321)
+    net = tm.TorchResNet(cfg['spec'], cfg['preact'], cfg['use_proj'])
+    with torch.no_grad():
+        l64 = net.forward({k: (v.clone().double() if v.is_floating_point() else v.clone()) for k, v in st.items()}, x.double(), train=True)
+        l32 = net.forward({k: v.clone() for k, v in st.items()}, x, train=True).double()
+        with torch.autocast('cuda', dtype=torch.float16):
+            lac = net.forward({k: v.clone().cuda() for k, v in st.items()}, x.cuda(), train=True).double().cpu()
+    torch.cuda.empty_cache()
+    from pytorch_ddp_resnet_amd import ResNet
+    out = {}
+    for dtype in ('fp32', 'fp16'):
+        m = ResNet(cfg['spec'], cfg['preact'], cfg['use_proj'], 0.0, compute_dtype=dtype)
+        m.load_state_dict({k: v.clone() for k, v in st.items()})
+        m = m.cuda().train()
+        with torch.no_grad():
+            out[dtype] = m(x.cuda()).double().cpu()
+        del m
+        torch.cuda.empty_cache()
+    r32, r16, rt, rac = rel(out['fp32'], l64), rel(out['fp16'], l64), rel(l32, l64), rel(lac, l64)
+    agree = float((out['fp16'].argmax(1) == l64.argmax(1)).float().mean())
+    print(f'wrn-50-2b b32 (distinct images): logits rel err fp16 engine {r16:.3e}, torch autocast(fp16) {rac:.3e}, fp32 engine {r32:.3e}, torch fp32 {rt:.3e}; '
+          f'argmax agreement fp16 {agree:.3f}')
+    assert r32 < max(1e-4, 4 * rt) and (out['fp32'].argmax(1) == l64.argmax(1)).all()       # the parity engine: north star with a 40x margin
+    assert r16 < 1.25 * rac + 1e-3, (r16, rac)                                                # the timed engine: no worse than the reference's own GPU arithmetic
+    assert agree >= 0.9
 
 
 # ---------------------------------------------------------------------------------------------------- fused loss / AMP
