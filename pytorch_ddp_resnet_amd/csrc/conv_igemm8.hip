@@ -120,7 +120,7 @@ __device__ inline float row_sum16(float x) {
 enum { EP8_PLAIN = 0, EP8_RES = 1, EP8_ACC = 2, EP8_BNB = 4, EP8_GEN = 8 };
 
 template <typename T, int RT, int MODE>
-__device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw, int kw, int lane, float* lds_mean) {
+__device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw, int kw, int lane, float* lds_mean, bool upper, int pair_floats) {
   constexpr int CE = 8;
   constexpr bool GEN = MODE == EP8_GEN;
   constexpr bool C_RES = (MODE & EP8_RES) != 0, C_ACC = (MODE & EP8_ACC) != 0, C_BNB = (MODE & EP8_BNB) != 0;
@@ -272,15 +272,33 @@ __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw
       }
     }
   }
-  if (want_stats) {                              // one partial row per wave (16 RT = RN_CONV_STATS_ROWS output rows)
-    static_assert(16 * RT == RN_CONV_STATS_ROWS, "a wave's block is one partial-sum row");
+  if (want_stats) {                              // one partial row per RN_CONV_STATS_ROWS = 128 output rows
+    static_assert(16 * RT == RN_CONV_STATS_ROWS || 32 * RT == RN_CONV_STATS_ROWS, "a wave's block is one partial-sum row, or half of one");
 #pragma unroll
     for (int e = 0; e < 16; ++e) { s0[e] = row_sum16(s0[e]); s1[e] = row_sum16(s1[e]); }
+    if constexpr (32 * RT == RN_CONV_STATS_ROWS) {
+      // 64-row waves (BN = 128): the wave of the row's upper half hands its sums to its partner (the wave WN below it) through its LDS corner; every
+      // wave of the workgroup is here (uniform control flow), so a workgroup barrier orders the exchange; it waits for LDS traffic only
+      if (upper && l16 == 0) {
+#pragma unroll
+        for (int e = 0; e < 16; e += 4) {
+          *reinterpret_cast<float4*>(lds_mean + 32 * lq + e) = make_float4(s0[e], s0[e + 1], s0[e + 2], s0[e + 3]);
+          *reinterpret_cast<float4*>(lds_mean + 32 * lq + 16 + e) = make_float4(s1[e], s1[e + 1], s1[e + 2], s1[e + 3]);
+        }
+      }
+      lds_barrier();
+      if (!upper) {
+        const float* other = lds_mean + pair_floats + 32 * lq;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { s0[e] += other[e]; s1[e] += other[16 + e]; }
+      }
+      lds_barrier();                             // the corner is free again (the next tile's means)
+    }
     if (bn_bwd) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) s1[e] *= a.bn_coef[3 * a.Kd + kc + e];
     }
-    if (l16 == 0 && mw < a.M) {
+    if (l16 == 0 && !upper && mw < a.M) {
       float* out = a.stats + ((size_t)(a.tile_base + mw / RN_CONV_STATS_ROWS) * 2) * a.Kd + kc;
 #pragma unroll
       for (int e = 0; e < 16; e += 4) {
@@ -307,7 +325,7 @@ __host__ __device__ inline int ep8_mode(const IgemmArgs& a) {
 template <typename T, int BN, int EPM>
 __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
   constexpr int BM = 256, ES = 2;
-  constexpr int WM = 2, WN = 4;                             // 2 x 4 waves of 128 x 64
+  constexpr int WM = BN == 256 ? 2 : 4, WN = 8 / WM;        // 2 x 4 waves of 128 x 64 (BN = 256), 4 x 2 waves of 64 x 64 (BN = 128)
   constexpr int WTM = BM / WM, WTN = BN / WN;
   constexpr int RT = WTM / 16, CT = WTN / 16;               // 16 x 16 accumulator tiles of a wave: pixel tiles x channel tiles
   constexpr int QR = RT / 2, QC = CT / 2;                   // ... of a quadrant
@@ -315,8 +333,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
   constexpr int AI = 2, BI = BN / 128;                      // DMA instructions per wave and half-tile (A: 128 rows, B: BN/2 rows)
   constexpr int STG = 4096;                                 // uint4 per stage: 64 KiB (A0 | A1 | B0 | B1), power of two: the stage toggles by XOR
   constexpr int A_H = 1024, B_0 = 2048, B_H = BN * 4;       // uint4 offsets: second A half, B, second B half
-  static_assert(sizeof(T) == ES && BN == 256 && CT == 4 && B_0 + 2 * B_H <= STG, "tile");
-  __shared__ uint4 smem[2 * STG + TAP_INTS / 4 + 8 * 16 + 1];     // stages | tap tables | 64 floats per wave (epilogue8) | one ticket word
+  static_assert(sizeof(T) == ES && (BN == 256 || BN == 128) && CT == 4 && B_0 + 2 * B_H <= STG, "tile");
+  __shared__ uint4 smem[2 * STG + TAP_INTS / 4 + 8 * 32 + 1];     // stages | tap tables | 128 floats per wave (epilogue8) | one ticket word
   int* taps = reinterpret_cast<int*>(&smem[2 * STG]);
 
   // (no blanket preload of the kernel arguments: this kernel is persistent and its epilogues read many of them -- held in SGPRs across the whole
@@ -334,7 +352,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
   const v4i32 rb_desc = make_desc(a.wt, (size_t)a.Kd * a.wrs * a.Cs * ES);
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);
   const int nk = a.nk;
-  float* lds_mean = reinterpret_cast<float*>(&smem[2 * STG + TAP_INTS / 4 + wave * 16]);     // 64 floats per wave (epilogue8)
+  float* lds_mean = reinterpret_cast<float*>(&smem[2 * STG + TAP_INTS / 4 + wave * 32]);     // 128 floats per wave (epilogue8)
   // the launch's epilogue specialisation (wave-uniform, from the kernel arguments)
 
   fill_tap_tables<ES>(a, taps);
@@ -583,7 +601,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains, then the workgroup meets, then ONE lane releases and signals
         __syncthreads();
         int* cnt = reinterpret_cast<int*>(a.w8_ws) + pt_sk;
-        volatile int* flagw = reinterpret_cast<volatile int*>(&smem[2 * STG + TAP_INTS / 4 + 8 * 16]);
+        volatile int* flagw = reinterpret_cast<volatile int*>(&smem[2 * STG + TAP_INTS / 4 + 8 * 32]);
         if (tid == 0) {
           *flagw = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -617,7 +635,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
       }
       if (finish) {
         const int mw = pm0 + wm * WTM, kw = pn0 + wn * WTN;
-        epilogue8<T, RT, EPM>(a, acc, mw, kw, lane, lds_mean);       // the epilogue specialisation is a kernel template parameter: one copy per kernel
+        // (the epilogue specialisation is a kernel template parameter: one copy per kernel; 64-row waves pair up for the statistics row)
+        epilogue8<T, RT, EPM>(a, acc, mw, kw, lane, lds_mean, RT == 4 && (wm & 1), WN * 128);
       }
     }
     stamp(stp, 3);
@@ -675,8 +694,7 @@ bool fill_walk8(IgemmArgs& a) {
   return true;
 }
 
-template <typename T> int launch8(IgemmArgs& a, hipStream_t s) {
-  const int BN = 256;
+template <typename T, int BN> int launch8(IgemmArgs& a, hipStream_t s) {
   if (!fill_walk8(a)) return -1;
   a.nk = a.nt * a.w8_cpc;
   { const unsigned nnt = (unsigned)(a.Kd / BN); a.w8_magic_nnt = nnt <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / nnt); }
@@ -702,12 +720,12 @@ template <typename T> int launch8(IgemmArgs& a, hipStream_t s) {
     }
   }
   switch (ep8_mode(a)) {
-    case EP8_PLAIN: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_PLAIN>), dim3(grid), dim3(512), 0, s, a); break;
-    case EP8_RES: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_RES>), dim3(grid), dim3(512), 0, s, a); break;
-    case EP8_BNB: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_BNB>), dim3(grid), dim3(512), 0, s, a); break;
-    case EP8_BNB | EP8_RES: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_BNB | EP8_RES>), dim3(grid), dim3(512), 0, s, a); break;
-    case EP8_BNB | EP8_ACC: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_BNB | EP8_ACC>), dim3(grid), dim3(512), 0, s, a); break;
-    default: hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_GEN>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_PLAIN: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_PLAIN>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_RES: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_RES>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_BNB: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_BNB | EP8_RES: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB | EP8_RES>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_BNB | EP8_ACC: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB | EP8_ACC>), dim3(grid), dim3(512), 0, s, a); break;
+    default: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_GEN>), dim3(grid), dim3(512), 0, s, a); break;
   }
   RN_CHECK_LAUNCH("igemm8");
   return 0;
@@ -731,12 +749,12 @@ int rn_igemm8_fast(const IgemmArgs& a) { return ep8_mode(a) != EP8_GEN ? 1 : 0; 
 
 int rn_launch_igemm8(const IgemmArgs& a_in, int dtype, hipStream_t s) {
   if (dtype != RN_BF16 && dtype != RN_F16) return -1;
-  if (a_in.Cs % 64 || a_in.Kd % 256 || a_in.M <= 0) return -1;
+  if (a_in.Cs % 64 || a_in.Kd % 128 || a_in.M <= 0) return -1;
   const size_t img_bytes = (size_t)a_in.Hs * a_in.Ws * a_in.Cs * 2;
   const long pq = (long)a_in.Pc * a_in.Qc;
   if ((256 / pq + 3) * (double)img_bytes >= 4.0e9) return -1;                          // per-tile source offsets are 32-bit (descriptor based at the tile's first image)
   if (((double)a_in.Kd + 256.0) * a_in.wrs * a_in.Cs * 2 >= 4.0e9) return -1;
   IgemmArgs a = a_in;
-  if (dtype == RN_BF16) return launch8<bf16_t>(a, s);
-  return launch8<f16_t>(a, s);
+  if (a.Kd % 256 == 0) return dtype == RN_BF16 ? launch8<bf16_t, 256>(a, s) : launch8<f16_t, 256>(a, s);
+  return dtype == RN_BF16 ? launch8<bf16_t, 128>(a, s) : launch8<f16_t, 128>(a, s);           // column tiles of 128: K = 128, 384, 640, ...
 }

@@ -48,7 +48,7 @@ PROD_GEOMS = [
     (128, 16, 16, 64, 64, 3, 2, 1),
 ]
 
-# WRN-50-2 layer shapes at a batch that keeps >= 160 tiles of 256 x 256, i.e. the eight-phase kernels (conv_igemm8.hip) the full-batch configuration
+# WRN-50-2 layer shapes at a batch that keeps >= 192 tiles of 256 x 256, i.e. the eight-phase kernels (conv_igemm8.hip) the full-batch configuration
 # launches; run with every operand set those kernels are specialised for (tests/test_gpu_production_tiles.py::test_igemm8_production_operand_sets)
 IGEMM8_GEOMS = [
     (128, 14, 14, 512, 512, 3, 1, 1),     # 3x3 @14, forward and data gradient: 196 tiles, 72 K tiles
@@ -56,6 +56,8 @@ IGEMM8_GEOMS = [
     (64, 28, 28, 1024, 256, 1, 1, 0),     # 1x1 reduce
     (128, 28, 28, 512, 512, 3, 2, 1),     # stride-2 3x3 forward (its data gradient: four parity classes on the 128-row kernels)
     (64, 56, 56, 512, 1024, 1, 2, 0),     # stride-2 projection shortcut, forward
+    (16, 56, 56, 128, 128, 3, 1, 1),      # stage 1 of WRN-50-2: 128 output channels -> column tiles of 128 (igemm8<256x128>), 196 tiles
+    (16, 56, 56, 512, 128, 1, 1, 0),      # 1x1 reduce to 128 channels (forward 256x128 tiles; data gradient 256x256)
 ]
 
 # the full-batch configurations whose every convolution must select a tile that PROD_GEOMS (or the small geometries of

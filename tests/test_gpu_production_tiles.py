@@ -286,6 +286,18 @@ def test_igemm8_on_small_geometries(g, dtype):
 
 @pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
 @pytest.mark.parametrize('merge', ['none', 'res', 'acc'])
+@pytest.mark.parametrize('g', [(3, 16, 16, 128, 128, 3, 1, 1), (3, 14, 14, 256, 384, 1, 1, 0), (2, 28, 28, 128, 128, 3, 2, 1)])
+def test_igemm8_column_tiles_of_128(g, merge, dtype):
+    """output channels that are a multiple of 128 but not of 256 take 256 x 128 tiles (4 x 2 waves of 64 x 64; two waves share a BatchNorm statistics
+    row and combine their sums through LDS): forward and data gradient, every operand set, strided parity classes through the general epilogue."""
+    ran = run_conv_case(g, dtype, variant=IGEMM8, fwd_res=(merge == 'none'), dgrad_merge=merge)
+    assert ran[0].startswith('igemm8<256x128:'), ran
+    if g[3] % 256:
+        assert all(n.startswith('igemm8<256x128:') for n in ran if n.startswith('igemm')), ran
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('merge', ['none', 'res', 'acc'])
 @pytest.mark.parametrize('g', [(2, 16, 16, 256, 256, 3, 1, 1), (3, 14, 14, 256, 512, 1, 1, 0)])
 def test_igemm8_epilogue_specialisations(g, merge, dtype):
     """every operand set the eight-phase kernel is specialised for: forward without a residual (plain) and the three data-gradient forms
@@ -295,17 +307,17 @@ def test_igemm8_epilogue_specialisations(g, merge, dtype):
     assert ran[1] == {'none': 'igemm8<256x256:bnb>', 'res': 'igemm8<256x256:bnb+res>', 'acc': 'igemm8<256x256:bnb+acc>'}[merge], ran
 
 
-@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
-@pytest.mark.parametrize('ops', [(True, 'none'), (False, 'res'), (False, 'acc')])
+@pytest.mark.parametrize('ops,dtype', [((True, 'none'), 'fp16'), ((True, 'none'), 'bf16'), ((False, 'res'), 'fp16'), ((False, 'acc'), 'fp16')])
 @pytest.mark.parametrize('g', IGEMM8_GEOMS)
 def test_igemm8_production_operand_sets(g, ops, dtype):
     """the eight-phase kernels at production grids (>= 160 persistent tiles, the shipped selection rule), with every operand set the full-batch
     WRN-50-2 configuration launches them with: forward +- identity residual; data gradient with the BatchNorm-backward sums alone, with the
     shortcut gradient as residual, accumulating into dx.  The kernel that ran is asserted against the launchers' own choice."""
     ran = run_conv_case(g, dtype, fwd_res=ops[0], dgrad_merge=ops[1])
-    assert ran[0] == ('igemm8<256x256:res>' if ops[0] else 'igemm8<256x256:plain>'), ran
+    bn_f, bn_d = (256 if g[4] % 256 == 0 else 128), (256 if g[3] % 256 == 0 else 128)
+    assert ran[0] == f'igemm8<256x{bn_f}:' + ('res>' if ops[0] else 'plain>'), ran
     if g[6] == 1:
-        assert ran[1] == {'none': 'igemm8<256x256:bnb>', 'res': 'igemm8<256x256:bnb+res>', 'acc': 'igemm8<256x256:bnb+acc>'}[ops[1]], ran
+        assert ran[1] == f'igemm8<256x{bn_d}:' + {'none': 'bnb>', 'res': 'bnb+res>', 'acc': 'bnb+acc>'}[ops[1]], ran
 
 
 WGRAD8 = 1 << 30                     # rn_set_variant: the eight-phase weight-gradient kernel at any size (its rule wants >= 8 K tiles per workgroup)
