@@ -192,7 +192,7 @@ def main():
                        'preact': cfg['preact'], 'use_proj': cfg['use_proj'], 'dropout_prob': cfg['p'], 'batch_per_gpu': cfg['batch'],
                        'global_batch': cfg['batch'] * world, 'parallelism': f'dp{world}',
                        'timed_region': 'fwd + CE loss/top-k + bwd + grad all-reduce' + (' (no optimizer step)' if args.optimizer == 'none' else f' + SGD step ({args.optimizer})'),
-                       'sync_bn': bool(args.sync_bn), 'loss_scale': res['loss_scale'], **({'host_input': True} if args.host_input else {})},
+                       'sync_bn': bool(args.sync_bn), 'loss_scale': res['loss_scale'], 'grads_finite': res['grads_finite'], **({'host_input': True} if args.host_input else {})},
             'step_ms_spread': res['spread'],
             'roofline': res['roof'],
         }
@@ -302,6 +302,8 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
         evs[i + 1].record()                                  # per-step spread only; nothing synchronises inside the region
     fence()
     dt = time.perf_counter() - t0
+    eng_t = next(e for k, e in model._engines.items() if k[1] and k[2])
+    grads_finite = bool(torch.isfinite(eng_t.flat_grad).all())          # after the timed region: the steps that were timed carried finite gradients
     per_step = sorted(evs[i].elapsed_time(evs[i + 1]) for i in range(steps))
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -383,7 +385,7 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
     ls = float(scaler.get_scale()) if scaler is not None else float(loss_scale.item())
     del model, x, y
     torch.cuda.empty_cache()
-    return dict(ms=ms, value=value, spread=spread, roof=roof, loss_scale=ls)
+    return dict(ms=ms, value=value, spread=spread, roof=roof, loss_scale=ls, grads_finite=grads_finite)
 
 
 if __name__ == '__main__':

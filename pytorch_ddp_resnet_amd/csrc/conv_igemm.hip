@@ -675,7 +675,7 @@ template <typename T, int BN> int launch_patch128(const IgemmArgs& a, hipStream_
 // DESIGN.md section 6, round 3): every geometry it covers with a specialised epilogue, once the grid holds enough 256-row tiles (>= 192) to occupy the chip
 // (one persistent workgroup per CU).  Parity classes of stride-2 data gradients (strided destination) stay on the 128-row kernels.
 static bool igemm8_rule(const IgemmArgs& a) {
-  if (a.Cs % 64 || a.Kd % 128) return false;
+  if (a.Kd % 128) return false;
   const long tiles = (long)cdiv(a.M, 256) * (a.Kd / (a.Kd % 256 ? 128 : 256));
   return tiles >= 192 && rn_igemm8_fast(a);          // (160 tiles of 256 x 128 on WRN-28-10's 8 x 8 stage: 89 us vs 70 us for the 128 x 160 kernel)
 }

@@ -117,12 +117,12 @@ __device__ inline float row_sum16(float x) {
 //                    accumulating into the destination (the three forms the block backward of residual_block.py:67-99, :173-215 lowers to)
 //   EP8_GEN          everything else, flags at run time: strided destination (parity classes of a stride-2 data gradient), pad / subsample
 //                    residuals, bias, sums without a mask (slow path: it spills)
-enum { EP8_PLAIN = 0, EP8_RES = 1, EP8_ACC = 2, EP8_BNB = 4, EP8_GEN = 8 };
+enum { EP8_PLAIN = 0, EP8_RES = 1, EP8_ACC = 2, EP8_BNB = 4, EP8_GEN = 8, EP8_BIAS = 16 };     // EP8_BIAS: plain + per-channel bias (the stem convolution, resnet.py:69-75)
 
 template <typename T, int RT, int MODE>
 __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw, int kw, int lane, float* lds_mean, bool upper, int pair_floats) {
   constexpr int CE = 8;
-  constexpr bool GEN = MODE == EP8_GEN;
+  constexpr bool GEN = MODE == EP8_GEN, C_BIAS = MODE == EP8_BIAS;
   constexpr bool C_RES = (MODE & EP8_RES) != 0, C_ACC = (MODE & EP8_ACC) != 0, C_BNB = (MODE & EP8_BNB) != 0;
   constexpr int D = MODE == EP8_RES ? 2 : 1;     // pixel tiles of operand loads in flight ahead of the one being processed (registers decide)
   const int l16 = lane & 15, lq = lane >> 4;
@@ -233,9 +233,12 @@ __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw
       transposed(pt, v);
       const Ops& o = ops[pt];
       if (o.ok) {
-        if (GEN && a.bias) {
+        if (C_BIAS || (GEN && a.bias)) {
 #pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] += a.bias[kc + e];
+          for (int e4 = 0; e4 < 16; e4 += 4) {
+            const float4 bv = *reinterpret_cast<const float4*>(a.bias + kc + e4);
+            v[e4] += bv.x; v[e4 + 1] += bv.y; v[e4 + 2] += bv.z; v[e4 + 3] += bv.w;
+          }
         }
         if (res_same) {
 #pragma unroll
@@ -322,7 +325,9 @@ __host__ __device__ inline int ep8_mode(const IgemmArgs& a) {
   return res ? EP8_RES : EP8_PLAIN;
 }
 
-template <typename T, int BN, int EPM>
+// TC ("tap chunks"): the source has ONE 16-byte chunk per pixel (the 7x7 stem: 3 image channels zero-padded to 8), so a K tile is eight TAPS x one chunk
+// instead of one tap x eight chunks: the 16-byte column a lane copies selects the tap (tap = 8 g + chunk), walked per lane
+template <typename T, int BN, int EPM, bool TC = false>
 __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
   constexpr int BM = 256, ES = 2;
   constexpr int WM = BN == 256 ? 2 : 4, WN = 8 / WM;        // 2 x 4 waves of 128 x 64 (BN = 256), 4 x 2 waves of 64 x 64 (BN = 128)
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
   // (no blanket preload of the kernel arguments: this kernel is persistent and its epilogues read many of them -- held in SGPRs across the whole
   // kernel they spill into VGPR lanes, which the K loop cannot afford; only what the K loop reads is pinned)
   Walk8K wkk;
-  wkk.cpc = a.w8_cpc; wkk.ntw = a.ntw;
+  wkk.cpc = TC ? 0x7FFFFFFF : a.w8_cpc; wkk.ntw = a.ntw;          // TC: cc is the K-tile index itself
   wkk.dsj = (unsigned)(a.w8_sj - a.w8_cpc * 128); wkk.dwj = (unsigned)(a.w8_wj - a.w8_cpc * 128);
   wkk.dsi = (unsigned)(a.w8_si - a.ntw * a.w8_sj); wkk.dwi = (unsigned)(a.w8_wi - a.ntw * a.w8_wj);
   asm volatile("" : "+s"(wkk.cpc), "+s"(wkk.ntw), "+s"(wkk.dsj), "+s"(wkk.dwj), "+s"(wkk.dsi), "+s"(wkk.dwi));
@@ -378,6 +383,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
   // A half h, LDS row r  <->  tile row (r / HR) * WTM + h * HR + r % HR;  B half h, LDS row r  <->  tile column (r / HC) * WTN + h * HC + r % HC.
   unsigned abase[2 * AI];
   unsigned amask[AI];                 // two 16-bit tap masks per register: half 0 low, half 1 high
+  unsigned ahw[TC ? 2 * AI : 1];      // TC: (hb << 16) | wb of the lane's four pixels
+  const int cj0 = p ^ ((lrow >> 1) & 7);      // the logical chunk of this lane's DMA pieces: cj0 for piece 0, cj0 ^ 4 for piece 1 (row 8 q + lrow: (row >> 1) & 7 = 4 q + lrow / 2)
   unsigned bbase[BI];
   int ra_w0 = 0, ra_w1 = 0, ra_w2 = 0;   // the source descriptor of the current tile (based at its first image), as three wave-uniform words
   const unsigned bhalf = (unsigned)((size_t)HC * a.wrs * a.Cs * ES);                      // B half 1 = the columns HC further
@@ -399,6 +406,19 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
         const int c = p ^ ((r >> 1) & 7);
         const int m = m0 + (r / HR) * WTM + h * HR + (r % HR);
         unsigned base = 0, mk = 0;
+        if constexpr (TC) {                                          // base = the pixel itself, mask register = (hb << 16) | wb for the per-tap range checks
+          mk = 0x7FFF0000u;                                          // a row beyond M: every tap out of range
+          if (m < a.M) {
+            int n, pp, q;
+            decode_row(a, m, pq, n, pp, q);
+            const int hb = pp * a.ss, wb = q * a.ss;
+            base = (unsigned)(((n - n_first) * a.Hs + hb) * a.Ws + wb) * rowb;
+            mk = ((unsigned)hb << 16) | (unsigned)wb;
+          }
+          abase[h * AI + jj] = base;
+          ahw[h * AI + jj] = mk;
+          continue;
+        }
         if (m < a.M) {                                               // offsets fit 32 bits (launcher)
           if (a.dense_src) {                                         // 1x1, stride 1: row m reads pixel m, no padding
             base = (unsigned)(m - n_first * pq) * rowb + (unsigned)(c * 16);
@@ -419,7 +439,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
       const int r = 8 * (wave * BI + jj) + lrow;
       const int c = p ^ ((r >> 1) & 7);
       const int k = n0 + (r / HC) * WTN + (r % HC);
-      bbase[jj] = (unsigned)k * (unsigned)a.wrs * rowb + (unsigned)(c * 16);          // Kd % BN == 0 (launcher): every column exists
+      bbase[jj] = (unsigned)k * (unsigned)a.wrs * rowb + (TC ? 0u : (unsigned)(c * 16));          // Kd % BN == 0 (launcher): every column exists
     }
   };
   auto issue_a = [&](int h, unsigned stage_lds, const Walk8& w) {
@@ -429,16 +449,31 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
     const unsigned keep = m0_save();
 #pragma unroll
     for (int jj = 0; jj < AI; ++jj) {
-      const bool ok = (amask[jj] >> (w.t + 16 * h)) & 1u;
-      dma16(ra_desc, ok ? abase[h * AI + jj] + w.src : OOB, stage_lds + (unsigned)((h * A_H) * 16 + (wave * AI + jj) * 1024));
+      if constexpr (TC) {                                   // K tile g = w.cc: this piece's tap = 8 g + chunk -> (i, j) of the tap grid -> shifted pixel, range-checked
+        const int t = 8 * w.cc + (cj0 ^ (4 * jj));
+        const int ti = (t * (int)a.w8_magic_ntw) >> 16, tj = t - ti * a.ntw;
+        const int dh = a.dh[0] + ti, dw = a.dw[0] + tj;
+        const unsigned hw = ahw[h * AI + jj];
+        const bool ok = t < a.nt && (unsigned)((int)(hw >> 16) + dh) < (unsigned)a.Hs && (unsigned)((int)(hw & 0xFFFFu) + dw) < (unsigned)a.Ws;
+        dma16(ra_desc, ok ? abase[h * AI + jj] + (unsigned)((dh * a.Ws + dw) * 16) : OOB, stage_lds + (unsigned)((h * A_H) * 16 + (wave * AI + jj) * 1024));
+      } else {
+        const bool ok = (amask[jj] >> (w.t + 16 * h)) & 1u;
+        dma16(ra_desc, ok ? abase[h * AI + jj] + w.src : OOB, stage_lds + (unsigned)((h * A_H) * 16 + (wave * AI + jj) * 1024));
+      }
     }
     m0_restore(keep);
   };
   auto issue_b = [&](int h, unsigned stage_lds, const Walk8& w) {
     const unsigned keep = m0_save();
 #pragma unroll
-    for (int jj = 0; jj < BI; ++jj)
-      dma16(rb_desc, bbase[jj] + (h ? bhalf : 0u) + w.wt, stage_lds + (unsigned)((B_0 + h * B_H) * 16 + (wave * BI + jj) * 1024));
+    for (int jj = 0; jj < BI; ++jj) {
+      if constexpr (TC) {                                   // weights [K][taps][8 channels]: tap 8 g + chunk of this row, zeros beyond the last tap
+        const int t = 8 * w.cc + (cj0 ^ (4 * (jj & 1)));
+        dma16(rb_desc, t < a.nt ? bbase[jj] + (h ? bhalf : 0u) + (unsigned)(t * 16) : OOB, stage_lds + (unsigned)((B_0 + h * B_H) * 16 + (wave * BI + jj) * 1024));
+      } else {
+        dma16(rb_desc, bbase[jj] + (h ? bhalf : 0u) + w.wt, stage_lds + (unsigned)((B_0 + h * B_H) * 16 + (wave * BI + jj) * 1024));
+      }
+    }
     m0_restore(keep);
   };
 
@@ -571,7 +606,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
       stamp(stp, 1);
       // prologue: the segment's first K tile whole, then B0 / A0 / B1 of its second (the state every K tile's phase 1 starts from).  Every wave has
       // left the previous segment's K loop (its closing rendezvous), so both stages are free.
-      walk8_seek(a, wk, kb);
+      if constexpr (TC) { wk.i = wk.j = wk.t = 0; wk.src = wk.wt = 0u; wk.cc = kb; } else walk8_seek(a, wk, kb);
       issue_b(0, lds0, wk); issue_a(0, lds0, wk); issue_b(1, lds0, wk); issue_a(1, lds0, wk);
       walk8_advance(wkk, wk);
       if (nseg > 1) { issue_b(0, lds0 + STG * 16, wk); issue_a(0, lds0 + STG * 16, wk); issue_b(1, lds0 + STG * 16, wk); }
@@ -744,17 +779,54 @@ extern "C" int rn_set_conv_workspace(void* p, size_t bytes) {
 
 // geometry the eight-phase kernel covers: 16-bit elements, channel count a multiple of 64 (a K tile never straddles a tap), output channels a
 // multiple of the column tile, 1..16 taps in a separable progression, 32-bit tile offsets; the grid rule (enough tiles for the chip) is the caller's
+// the 7x7 (or any <= 64-tap) stem: one 16-byte chunk per source pixel, forward convolution with unit tap steps, bias and / or statistics, nothing else fused
+static bool stem_capable(const IgemmArgs& a) {
+  if (a.Cs != 8 || a.Kd % 256 || a.nt < 1 || a.nt > 64 || a.nth * a.ntw != a.nt || a.ntw < 1) return false;
+  if (a.ds != 1 || a.res.mode != RN_RES_NONE || a.accum || a.bn_x) return false;
+  for (int i = 0; i < a.nth; ++i)
+    for (int j = 0; j < a.ntw; ++j) {
+      const int t = i * a.ntw + j;
+      if (a.dh[t] != a.dh[0] + i || a.dw[t] != a.dw[0] + j || a.widx[t] != t) return false;
+    }
+  return true;
+}
+
 // 1: the geometry is one the eight-phase kernel covers with a specialised (spill-free) epilogue; 0: not covered, or only by its general epilogue
-int rn_igemm8_fast(const IgemmArgs& a) { return ep8_mode(a) != EP8_GEN ? 1 : 0; }
+int rn_igemm8_fast(const IgemmArgs& a) {
+  if (a.Cs == 8) return stem_capable(a) ? 1 : 0;
+  return (a.Cs % 64 == 0 && a.Kd % 128 == 0 && ep8_mode(a) != EP8_GEN) ? 1 : 0;
+}
+
+template <typename T> static int launch8_stem(IgemmArgs& a, hipStream_t s) {
+  a.nk = (a.nt + 7) / 8;
+  a.w8_cpc = 1;
+  a.w8_magic_ntw = (unsigned)((65536 + a.ntw - 1) / a.ntw);
+  { const unsigned nnt = (unsigned)(a.Kd / 256); a.w8_magic_nnt = nnt <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / nnt); }
+  rn_note_kernel("igemm8<256x256:stem%s>", a.bias ? "+bias" : "");
+  if (rn_dry_run()) return 0;
+  const int ntiles = cdiv(a.M, 256) * (a.Kd / 256);
+  const int grid = ntiles < SK_GRID ? ntiles : SK_GRID;
+  a.w8_dp_tiles = ntiles;
+  a.w8_ws = nullptr;
+  if (a.bias) hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_BIAS, true>), dim3(grid), dim3(512), 0, s, a);
+  else hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_PLAIN, true>), dim3(grid), dim3(512), 0, s, a);
+  RN_CHECK_LAUNCH("igemm8 stem");
+  return 0;
+}
 
 int rn_launch_igemm8(const IgemmArgs& a_in, int dtype, hipStream_t s) {
   if (dtype != RN_BF16 && dtype != RN_F16) return -1;
-  if (a_in.Cs % 64 || a_in.Kd % 128 || a_in.M <= 0) return -1;
+  if (a_in.M <= 0) return -1;
   const size_t img_bytes = (size_t)a_in.Hs * a_in.Ws * a_in.Cs * 2;
   const long pq = (long)a_in.Pc * a_in.Qc;
   if ((256 / pq + 3) * (double)img_bytes >= 4.0e9) return -1;                          // per-tile source offsets are 32-bit (descriptor based at the tile's first image)
   if (((double)a_in.Kd + 256.0) * a_in.wrs * a_in.Cs * 2 >= 4.0e9) return -1;
   IgemmArgs a = a_in;
+  if (a.Cs == 8) {
+    if (!stem_capable(a)) return -1;
+    return dtype == RN_BF16 ? launch8_stem<bf16_t>(a, s) : launch8_stem<f16_t>(a, s);
+  }
+  if (a.Cs % 64 || a.Kd % 128) return -1;
   if (a.Kd % 256 == 0) return dtype == RN_BF16 ? launch8<bf16_t, 256>(a, s) : launch8<f16_t, 256>(a, s);
   return dtype == RN_BF16 ? launch8<bf16_t, 128>(a, s) : launch8<f16_t, 128>(a, s);           // column tiles of 128: K = 128, 384, 640, ...
 }

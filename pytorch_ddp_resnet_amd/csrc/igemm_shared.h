@@ -45,6 +45,7 @@ struct IgemmArgs {
   int w8_src0, w8_si, w8_sj, w8_wt0, w8_wi, w8_wj, w8_cpc;
   int w8_dp_tiles;         // tiles [0, w8_dp_tiles) are taken whole (round-robin), the rest as stream-K units
   void* w8_ws;             // stream-K workspace (rn_set_conv_workspace), or NULL
+  unsigned w8_magic_ntw;   // ceil(2^16 / ntw): tap -> (row, column) of the tap grid for taps < 64 (the stem's per-lane tap walk)
   unsigned w8_magic_nnt;   // floor(2^32 / column tiles): tile -> (row tile, column tile) by multiply-high + one correction
   int dh[MAX_TAPS], dw[MAX_TAPS], widx[MAX_TAPS];
 };

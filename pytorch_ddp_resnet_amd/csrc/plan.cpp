@@ -48,11 +48,15 @@ extern "C" int rn_conv_kernel_names(int pass, int dtype, const rn_conv_geom* g, 
   static float dummy[8];
   void* p = dummy;                              // never dereferenced: the launchers return before launching
   // fused_epilogue is a set of flags naming the launch's operand set (the eight-phase kernels are specialised per set): 1 = fused BatchNorm sums
-  // (forward: statistics of the output; data gradient: the backward sums over x and the mask), 2 = identity residual, 4 = accumulate into dx
+  // (forward: statistics of the output; data gradient: the backward sums over x and the mask), 2 = identity residual, 4 = accumulate into dx, 8 = per-channel bias (forward: the stem)
   rn_conv_epilogue ep{(float*)p, nullptr, nullptr, nullptr, 1.f, nullptr};
-  const bool fused = (fused_epilogue & 1) != 0, res = (fused_epilogue & 2) != 0, acc = (fused_epilogue & 4) != 0;
+  const bool fused = (fused_epilogue & 1) != 0, res = (fused_epilogue & 2) != 0, acc = (fused_epilogue & 4) != 0, bias = (fused_epilogue & 8) != 0;
   int e;
-  if (pass == 0) e = rn_conv_fwd(p, p, p, res ? p : nullptr, res ? RN_RES_SAME : RN_RES_NONE, res ? g->K : 0, dtype, g, fused ? &ep : nullptr, nullptr);
+  if (pass == 0) {
+    if (bias) ep.bias = (const float*)p;
+    if (!fused) ep.partial = nullptr;
+    e = rn_conv_fwd(p, p, p, res ? p : nullptr, res ? RN_RES_SAME : RN_RES_NONE, res ? g->K : 0, dtype, g, (fused || bias) ? &ep : nullptr, nullptr);
+  }
   else if (pass == 1) {
     ep.bn_x = p; ep.bn_mask = p; ep.bn_coef = (const float*)p;
     e = rn_conv_dgrad(p, p, p, res ? p : nullptr, res ? RN_RES_SAME : RN_RES_NONE, res ? g->C : 0, acc ? RN_F_ACCUM : 0, dtype, g, fused ? &ep : nullptr, nullptr);

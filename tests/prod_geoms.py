@@ -60,6 +60,9 @@ IGEMM8_GEOMS = [
     (16, 56, 56, 512, 128, 1, 1, 0),      # 1x1 reduce to 128 channels (forward 256x128 tiles; data gradient 256x256)
 ]
 
+# the ImageNet stems on the eight-phase kernel's tap-chunk mode (bias + statistics, no residual): tests/test_gpu_production_tiles.py::test_igemm8_stem
+STEM8_GEOMS = [(8, 224, 224, 0, 512, 7, 2, 3), (8, 224, 224, 0, 256, 7, 2, 3)]
+
 # the full-batch configurations whose every convolution must select a tile that PROD_GEOMS (or the small geometries of
 # test_gpu_kernels.py) also selects
 CONFIGS = {

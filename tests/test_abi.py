@@ -127,8 +127,11 @@ def test_hot_kernels_keep_their_occupancy():
         # eight-phase kernels: 8 waves = two per SIMD (<= 256 registers), one persistent workgroup per CU; the specialised epilogues must not spill --
         # a scratch reload in an epilogue waits for every store in flight (vmcnt is in order), which was measured as a 2x slower data gradient
         for ep in (0, 1, 4):                                                  # plain, + residual, BatchNorm-backward sums
-            k = find(f'igemm8_kernelI{dt}Li256ELi{ep}E')
+            k = find(f'igemm8_kernelI{dt}Li256ELi{ep}ELb0E')
             assert k['Occupancy'] >= 2 and k['VGPRs'] <= 256 and k['LDS Size'] <= LDS_CU and k['ScratchSize'] == 0, (ep, k)
+        for ep in (0, 16):                                                    # the stem (tap-chunk) form: plain / + bias
+            k = find(f'igemm8_kernelI{dt}Li256ELi{ep}ELb1E')
+            assert k['Occupancy'] >= 2 and k['VGPRs'] <= 256 and k['ScratchSize'] == 0, (ep, k)
         k = find(f'wgrad8_kernelI{dt}E')
         assert k['Occupancy'] >= 2 and k['VGPRs'] <= 256 and k['LDS Size'] <= LDS_CU and k['ScratchSize'] == 0, k
     spilling = ('igemm8_kernel',)          # its bnb+res / bnb+acc / general epilogues spill a few registers (known): checked above per mode

@@ -19,7 +19,7 @@ from filler import fill
 from pytorch_ddp_resnet_amd import _lib
 from pytorch_ddp_resnet_amd.engine import ir
 from pytorch_ddp_resnet_amd.engine.lowering import conv_stats_rows
-from prod_geoms import PROD_GEOMS, IGEMM8_GEOMS, geom, resolve
+from prod_geoms import PROD_GEOMS, IGEMM8_GEOMS, STEM8_GEOMS, geom, resolve
 
 pytestmark = pytest.mark.gpu
 
@@ -404,6 +404,56 @@ def test_igemm8_stream_k_is_reproducible_and_equals_whole_tiles():
     assert torch.equal(outs[0], outs[1])
     assert float((outs[0] - outs[2]).abs().max()) <= 2e-3 * float(outs[2].abs().max())
     assert not torch.equal(outs[2], torch.zeros_like(outs[2]))
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('g,variant', [(STEM8_GEOMS[0], 0), (STEM8_GEOMS[1], 0), ((3, 40, 56, 8, 256, 7, 2, 3), IGEMM8), ((2, 32, 32, 8, 256, 3, 1, 1), IGEMM8),
+                                       ((1, 19, 23, 8, 512, 5, 2, 2), IGEMM8)])
+def test_igemm8_stem(g, variant, dtype):
+    """the top-level Conv2d(3 -> K, bias=True) (resnet.py:69-75) on the eight-phase kernel: one 16-byte chunk per pixel, a K tile = eight taps, the
+    tap walked per lane (tap = 8 g + chunk), taps beyond the last and out-of-image taps zero-filled; bias and BatchNorm statistics in the epilogue.
+    The two ImageNet stems at the shipped selection rule, and small 7x7 / 3x3 / 5x5 shapes (odd sizes, one or several K tiles) forced."""
+    import gpu_harness as h
+    from pytorch_ddp_resnet_amd.engine.executor import Engine
+    g = resolve(g, False)
+    N, Hh, W, C, K, k, s_, p = g
+    gm = geom(*g)
+    P, Q = gm['P'], gm['Q']
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, Hh, W, C)); wf = b.slot('wf', (K, k * k, C)); y = b.slot('y', (N, P, Q, K))
+    st = b.slot('st', (conv_stats_rows(gm), 2, K), 'f32'); bias = b.slot('bias', (K,), 'f32')
+    b.op(ir.OP_CONV_FWD, buf=dict(x=x, w_fwd=wf, y=y, res=-1, stats=st, bias=bias), dim=dict(gm, res_mode=0, res_C=0))
+    plan = b.plan(False)
+    plan.meta['dtype'] = dtype
+    xv = _round(fill((N, Hh, W, C), 2), dtype)
+    xv[..., 3:] = 0                                              # the padded channels of the image are zero
+    wv = _round(fill((K, k, k, C), 1, (3.0 / (3 * k * k)) ** 0.5), dtype)
+    bv = torch.from_numpy(fill((K,), 9, 0.5))
+    eng = Engine(plan, h.DEV, TORCH_DT[dtype])
+    for name, v in dict(x=xv, wf=wv.reshape(K, k * k, C), bias=bv).items():
+        t = eng.tensors[plan.slot_of[name]]
+        t.copy_(v.reshape(t.shape).to(t.dtype))
+    eng.bind({})
+    L = _lib.lib()
+    L.rn_set_variant(variant)
+    try:
+        L.rn_kernel_log(1)
+        eng.run(0, 1, 0)
+        torch.cuda.synchronize()
+        ran = L.rn_kernel_log_read().decode().split(',')
+        want = _lib.conv_kernel_names(0, RN_DT[dtype], gm, fused_epilogue=9)
+    finally:
+        L.rn_kernel_log(0)
+        L.rn_set_variant(0)
+    assert ran == want == ['igemm8<256x256:stem+bias>'], (ran, want)
+    yo = eng.tensors[plan.slot_of['y']].float().cpu()
+    ref = _nhwc(F.conv2d(_nchw(xv), wv.permute(0, 3, 1, 2).contiguous(), bv, s_, p))
+    err = float((yo - ref).abs().max() / ref.abs().max())
+    assert err < TOL[dtype], (err, g, dtype)
+    ys = yo.double().reshape(-1, K)
+    s0, s1 = eng.tensors[plan.slot_of['st']].double().cpu().sum(0)
+    assert float((s0 - ys.sum(0)).abs().max()) < 2e-5 * float(ys.abs().sum(0).max())
+    assert float((s1 - (ys * ys).sum(0)).abs().max()) < 2e-5 * float((ys * ys).sum(0).max())
 
 
 @pytest.mark.parametrize('g', [(2, 16, 16, 128, 256, 3, 1, 1), (3, 14, 14, 64, 256, 1, 1, 0)])

@@ -11,7 +11,7 @@ import pytest
 from pytorch_ddp_resnet_amd import _lib
 from pytorch_ddp_resnet_amd.engine import ir
 from pytorch_ddp_resnet_amd.engine.lowering import lower
-from prod_geoms import PROD_GEOMS, IGEMM8_GEOMS, CONFIGS, geom, resolve
+from prod_geoms import PROD_GEOMS, IGEMM8_GEOMS, STEM8_GEOMS, CONFIGS, geom, resolve
 
 pytestmark = pytest.mark.skipif(not os.path.exists(_lib.LIB_PATH), reason='librn_hip.so not built')
 
@@ -37,6 +37,9 @@ def _tested_names(dtype):
         # operand sets of tests/test_gpu_production_tiles.py::run_conv_case: forward = statistics + identity residual, data gradient = BatchNorm-backward sums
         for p, fl in ((0, 3), (1, 1), (2, 0)):
             names.update(_lib.conv_kernel_names(p, dtype, geom(*g), fused_epilogue=fl))
+    for g in STEM8_GEOMS:                      # test_igemm8_stem: the stem convolution with its bias and statistics
+        if dtype != ir.RN_F32:
+            names.update(_lib.conv_kernel_names(0, dtype, geom(*resolve(g, False)), fused_epilogue=9))
     for g in IGEMM8_GEOMS:                     # test_igemm8_production_operand_sets: every operand set
         if dtype == ir.RN_F32:
             break
@@ -54,6 +57,8 @@ def _op_flags(op):
         fl |= 2
     if op.kind == ir.OP_CONV_DGRAD and (op.flags & ir.F_ACCUM):
         fl |= 4
+    if b.get('bias', -1) >= 0:
+        fl |= 8
     return fl
 
 
