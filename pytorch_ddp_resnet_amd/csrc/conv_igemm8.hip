@@ -117,18 +117,18 @@ __device__ inline float row_sum16(float x) {
 //                    accumulating into the destination (the three forms the block backward of residual_block.py:67-99, :173-215 lowers to)
 //   EP8_GEN          everything else, flags at run time: strided destination (parity classes of a stride-2 data gradient), pad / subsample
 //                    residuals, bias, sums without a mask (slow path: it spills)
-enum { EP8_PLAIN = 0, EP8_RES = 1, EP8_ACC = 2, EP8_BNB = 4, EP8_GEN = 8, EP8_BIAS = 16 };     // EP8_BIAS: plain + per-channel bias (the stem convolution, resnet.py:69-75)
+enum { EP8_PLAIN = 0, EP8_RES = 1, EP8_ACC = 2, EP8_BNB = 4, EP8_GEN = 8, EP8_BIAS = 16, EP8_STRIDED = 32 };   // EP8_STRIDED: destination pixel (2p + oh, 2q + ow): a parity class of a stride-2 data gradient     // EP8_BIAS: plain + per-channel bias (the stem convolution, resnet.py:69-75)
 
 template <typename T, int RT, int MODE>
 __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw, int kw, int lane, float* lds_mean, bool upper, int pair_floats) {
   constexpr int CE = 8;
-  constexpr bool GEN = MODE == EP8_GEN, C_BIAS = MODE == EP8_BIAS;
+  constexpr bool GEN = MODE == EP8_GEN, C_BIAS = MODE == EP8_BIAS, C_STRIDED = (MODE & EP8_STRIDED) != 0;
   constexpr bool C_RES = (MODE & EP8_RES) != 0, C_ACC = (MODE & EP8_ACC) != 0, C_BNB = (MODE & EP8_BNB) != 0;
   constexpr int D = MODE == EP8_RES ? 2 : 1;     // pixel tiles of operand loads in flight ahead of the one being processed (registers decide)
   const int l16 = lane & 15, lq = lane >> 4;
   const int kc = kw + 16 * lq;                   // after the transpose this lane owns channels kc .. kc + 15 of its pixel
   T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
-  const bool dense = !GEN || ((a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME));
+  const bool dense = !C_STRIDED && (!GEN || ((a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME)));
   const bool want_stats = a.stats != nullptr;
   const bool bn_bwd = C_BNB || (GEN && want_stats && a.bn_x != nullptr);
   const bool has_mask = C_BNB || (GEN && a.bn_mask != nullptr);
@@ -314,6 +314,9 @@ __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw
 
 // the launch's epilogue specialisation (host and device agree: the launcher's rule reads it too)
 __host__ __device__ inline int ep8_mode(const IgemmArgs& a) {
+  const bool bnb = a.stats != nullptr && a.bn_x != nullptr && a.bn_mask != nullptr;
+  if (a.ds == 2 && a.res.mode == RN_RES_NONE && !a.bias && bnb)        // a parity class of a stride-2 data gradient with the BatchNorm-backward sums
+    return EP8_BNB | EP8_STRIDED | (a.accum ? EP8_ACC : 0);
   const bool dense = (a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME) && !a.bias;
   if (!dense) return EP8_GEN;
   const bool res = a.res.mode == RN_RES_SAME, acc = a.accum != 0;
@@ -734,7 +737,8 @@ template <typename T, int BN> int launch8(IgemmArgs& a, hipStream_t s) {
   a.nk = a.nt * a.w8_cpc;
   { const unsigned nnt = (unsigned)(a.Kd / BN); a.w8_magic_nnt = nnt <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / nnt); }
   static const char* const EPN[] = {"plain", "res", "?", "?", "bnb", "bnb+res", "bnb+acc", "?", "gen"};
-  rn_note_kernel("igemm8<256x%d:%s>", BN, EPN[ep8_mode(a)]);
+  const int epm = ep8_mode(a);
+  rn_note_kernel("igemm8<256x%d:%s%s>", BN, EPN[epm & 15], (epm & EP8_STRIDED) ? "/s2" : "");
   if (rn_dry_run()) return 0;
   const int ntiles = cdiv(a.M, 256) * (a.Kd / BN);
   // stream-K (tiles cut into K-tile unit ranges, cut tiles summed through the workspace) only where whole tiles cannot occupy the chip: grids of at most
@@ -760,6 +764,8 @@ template <typename T, int BN> int launch8(IgemmArgs& a, hipStream_t s) {
     case EP8_BNB: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB>), dim3(grid), dim3(512), 0, s, a); break;
     case EP8_BNB | EP8_RES: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB | EP8_RES>), dim3(grid), dim3(512), 0, s, a); break;
     case EP8_BNB | EP8_ACC: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB | EP8_ACC>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_BNB | EP8_STRIDED: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB | EP8_STRIDED>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_BNB | EP8_ACC | EP8_STRIDED: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB | EP8_ACC | EP8_STRIDED>), dim3(grid), dim3(512), 0, s, a); break;
     default: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_GEN>), dim3(grid), dim3(512), 0, s, a); break;
   }
   RN_CHECK_LAUNCH("igemm8");

@@ -58,6 +58,7 @@ IGEMM8_GEOMS = [
     (64, 56, 56, 512, 1024, 1, 2, 0),     # stride-2 projection shortcut, forward
     (16, 56, 56, 128, 128, 3, 1, 1),      # stage 1 of WRN-50-2: 128 output channels -> column tiles of 128 (igemm8<256x128>), 196 tiles
     (16, 56, 56, 512, 128, 1, 1, 0),      # 1x1 reduce to 128 channels (forward 256x128 tiles; data gradient 256x256)
+    (64, 56, 56, 128, 128, 3, 2, 1),      # WRN-50-2 spec A: stride-2 3x3 with 128 channels (parity classes on 256x128 tiles, strided epilogue)
 ]
 
 # the ImageNet stems on the eight-phase kernel's tap-chunk mode (bias + statistics, no residual): tests/test_gpu_production_tiles.py::test_igemm8_stem
