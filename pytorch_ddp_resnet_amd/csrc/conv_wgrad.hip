@@ -305,6 +305,26 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restr
   }
 }
 
+// the same in-order sum (slab 0 + slab 1 + ... : the same bits) for the LARGE gradients of the eight-phase weight-gradient kernel (up to 9.4 M floats per
+// slab): one thread per output chunk and four slabs' loads in flight before the four in-order adds -- the loop above walks the slabs one dependent
+// load at a time and was 81 us per launch on average in the WRN-50-2 profile (41 launches per step)
+__global__ __launch_bounds__(256) void wgrad_reduce_mlp_kernel(const float* __restrict__ ws, float* __restrict__ dw, long n, int splits, int accum) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (n >> 2)) return;
+  float4 s = reinterpret_cast<const float4*>(ws)[i];
+  int k = 1;
+  for (; k + 3 < splits; k += 4) {
+    float4 v[4];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) v[l] = reinterpret_cast<const float4*>(ws + (size_t)(k + l) * n)[i];
+#pragma unroll
+    for (int l = 0; l < 4; ++l) add4(s, v[l]);
+  }
+  for (; k < splits; ++k) add4(s, reinterpret_cast<const float4*>(ws + (size_t)k * n)[i]);
+  if (accum) add4(s, reinterpret_cast<float4*>(dw)[i]);
+  reinterpret_cast<float4*>(dw)[i] = s;
+}
+
 // The sums of reduce_wide_body below (sixteen interleaved partial sums per output, then those in order: the SAME bits) by ONE thread per
 // output chunk with sixteen accumulators: sixteen independent, fully coalesced loads per step.  For outputs large enough to fill the chip
 // with a thread each (WRN-28-10's 160 -> 160 3x3: 57,600 chunks x 43 slabs took 34 us as 3,600 workgroups of 16 x 16 threads with two
@@ -542,6 +562,9 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
     } else if (reduce_is_wide(a.splits, n4)) {
       const int blocks = reduce_wide_blocks(n4);
       hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(blocks), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), dw_krsc, (long)n,
+                         a.splits, (flags & RN_F_ACCUM) ? 1 : 0);
+    } else if (w8 > 0 && n4 >= 65536) {                  // the eight-phase kernel's large slabs: a thread per chunk, four slabs in flight (same sums)
+      hipLaunchKernelGGL(wgrad_reduce_mlp_kernel, dim3((int)((n4 + 255) / 256)), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), dw_krsc, (long)n,
                          a.splits, (flags & RN_F_ACCUM) ? 1 : 0);
     } else {
       int blocks = (int)((n4 + 255) / 256);
