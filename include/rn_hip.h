@@ -101,7 +101,7 @@ typedef struct rn_plan rn_plan;
 const char* rn_last_error(void);
 /* ABI version: bumped with EVERY change of an entry point's signature or meaning; a binding refuses a library of another version (a stale
  * librn_hip.so would otherwise take shifted pointer / integer arguments).  3: round 3 (operand-set flags of rn_conv_kernel_names, workspaces). */
-#define RN_ABI_VERSION 3
+#define RN_ABI_VERSION 4
 int rn_version(void);
 /* kernel-variant switch for A/B measurements (tools/conv_bench.py; bits documented in csrc/conv_igemm.hip); 0 = shipped */
 void rn_set_variant(int v);
@@ -274,6 +274,18 @@ int rn_bn_pool_bwd_reduce(const void* dy, const unsigned char* argmax, const voi
                           int H, int W, int C, int k, int stride, int pad, int flags, rn_stream s);
 int rn_bn_pool_bwd_apply(const void* dy, const unsigned char* argmax, const void* x, const float* coef, const float* dsum, void* dx, int dtype, int N,
                          int H, int W, int C, int k, int stride, int pad, int flags, double count, rn_stream s);
+/* rn_bn_pool_fwd that also keeps xsel[N][P][Q][C] = the input element that won each window; with it the backward sums are taken at pooled
+ * resolution (dy and xsel, 2 x 1/4 of the map, instead of the map + dy + argmax): partial rows for rn_bn_bwd_finalize as rn_bn_pool_bwd_reduce
+ * leaves them (1 <= nblk <= 8192, npix = N * P * Q).  Windows are added unrounded, the gather form rounds each pixel's summed gradient to the
+ * compute dtype first: equal in fp32 up to summation order, within the dtype's rounding otherwise. */
+int rn_bn_pool_fwd_sel(const void* x, const float* coef, void* y, unsigned char* argmax, void* xsel, int dtype, int N, int H, int W, int C, int k,
+                       int stride, int pad, int flags, rn_stream s);
+int rn_bn_pool_bwd_reduce_sel(const void* dy, const void* xsel, const float* coef, float* partial, int nblk, int dtype, long npix, int C, int flags,
+                              rn_stream s);
+/* the same pass, also leaving sums_partial[rows][2][C] = per-workgroup (sum dx, 0) of the stored gradient (rows = its grid, 1..8192):
+ * the bias gradient of a biased producer (the ImageNet stem convolution, resnet.py:111) through rn_bn_bwd_finalize, without another pass over dx */
+int rn_bn_pool_bwd_apply_sums(const void* dy, const unsigned char* argmax, const void* x, const float* coef, const float* dsum, void* dx, float* sums_partial,
+                              int rows, int dtype, int N, int H, int W, int C, int k, int stride, int pad, int flags, double count, rn_stream s);
 
 /* logits[n,o] = b[o] + sum_c W[o,c] * mean_{hw} x[n,hw,c];  feat: [N][C] fp32 scratch kept for backward */
 int rn_pool_fc_fwd(const void* x, const float* w, const float* b, float* feat, float* logits, int dtype, int N, int HW,

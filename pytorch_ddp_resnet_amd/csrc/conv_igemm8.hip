@@ -191,9 +191,12 @@ __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw
     // BatchNorm-backward second sum: sum g * xhat = invstd * sum g * (x - mean): only the mean is held per channel, invstd multiplies the row sum
     // The means of this lane row's 16 channels are parked in a wave-private corner of LDS (64 floats per wave) and re-read per pixel tile: sixteen
     // registers the BatchNorm-backward specialisations do not have (LDS reads do not touch vmcnt; a scratch reload would wait for the stores in flight).
+    // The 1 / std of the same channels wait next to them (floats 64..127 of the corner) until the sums are scaled: a vector load issued behind the tile's
+    // stores would have to wait for every one of them (vmcnt counts in issue order).
     float* lm = lds_mean + 16 * lq;
     if (bn_bwd) {
       if (l16 < 4) *reinterpret_cast<float4*>(lm + 4 * l16) = *reinterpret_cast<const float4*>(a.bn_coef + 2 * a.Kd + kc + 4 * l16);
+      else if (l16 < 8) *reinterpret_cast<float4*>(lm + 64 + 4 * (l16 - 4)) = *reinterpret_cast<const float4*>(a.bn_coef + 3 * a.Kd + kc + 4 * (l16 - 4));
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // same wave writes and reads: program order + the wait
     }
     struct Ops { bool ok; size_t off; int n, hd, wd; Chunk<T> cr[2], co[2], cx[2], cm[2]; };
@@ -279,6 +282,15 @@ __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw
     static_assert(16 * RT == RN_CONV_STATS_ROWS || 32 * RT == RN_CONV_STATS_ROWS, "a wave's block is one partial-sum row, or half of one");
 #pragma unroll
     for (int e = 0; e < 16; ++e) { s0[e] = row_sum16(s0[e]); s1[e] = row_sum16(s1[e]); }
+    float istd[16];
+    if (MODE != EP8_PLAIN && bn_bwd) {           // parked at the top of the epilogue; read before the corner is reused below
+#pragma unroll
+      for (int e4 = 0; e4 < 16; e4 += 4) {
+        const float4 iv = *reinterpret_cast<const float4*>(lds_mean + 64 + 16 * lq + e4);
+        istd[e4] = iv.x; istd[e4 + 1] = iv.y; istd[e4 + 2] = iv.z; istd[e4 + 3] = iv.w;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
     if constexpr (32 * RT == RN_CONV_STATS_ROWS) {
       // 64-row waves (BN = 128): the wave of the row's upper half hands its sums to its partner (the wave WN below it) through its LDS corner; every
       // wave of the workgroup is here (uniform control flow), so a workgroup barrier orders the exchange; it waits for LDS traffic only
@@ -297,9 +309,9 @@ __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw
       }
       lds_barrier();                             // the corner is free again (the next tile's means)
     }
-    if (bn_bwd) {
+    if (MODE != EP8_PLAIN && bn_bwd) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) s1[e] *= a.bn_coef[3 * a.Kd + kc + e];
+      for (int e = 0; e < 16; ++e) s1[e] *= istd[e];
     }
     if (l16 == 0 && !upper && mw < a.M) {
       float* out = a.stats + ((size_t)(a.tile_base + mw / RN_CONV_STATS_ROWS) * 2) * a.Kd + kc;
@@ -616,6 +628,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
     }
     stamp(stp, 2);
     // the previous segment leaves the registers while this one's first K tiles are in flight (ONE call site: the epilogue is large)
+    bool stores_behind = false;
     if (pm0 >= 0) {
       bool finish = true;
       if (pt_sk >= 0) {
@@ -672,6 +685,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
         }
       }
       if (finish) {
+        stores_behind = pm0 + BM <= a.M;                     // a whole tile: every lane stores its 2 x RT chunks of the tile, whatever else the epilogue does
         const int mw = pm0 + wm * WTM, kw = pn0 + wn * WTN;
         // (the epilogue specialisation is a kernel template parameter: one copy per kernel; 64-row waves pair up for the statistics row)
         epilogue8<T, RT, EPM>(a, acc, mw, kw, lane, lds_mean, RT == 4 && (wm & 1), WN * 128);
@@ -685,9 +699,14 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
       for (int j = 0; j < CT; ++j)
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
-    // vmcnt counts in issue order: behind the epilogue's stores this wait also drains them, all but the youngest (conservative: the compiler's
-    // stores are not counted by hand)
-    if (nseg > 1) wait_vmcnt<AI + 2 * BI>(); else wait_vmcnt<0>();
+    // vmcnt counts in issue order, and the epilogue's stores are YOUNGER than this segment's first loads: the wait names them too, or the first K tile
+    // would start only once the previous tile has drained to memory.  Counted: the 2 x RT tile stores of a whole tile (a lower bound -- the sums' stores
+    // are not counted, which only makes the wait stricter); a ragged tile or a stream-K part that stored nothing waits as before.
+    if (nseg > 1) {
+      if (stores_behind && !a.w8_drain) wait_vmcnt<AI + 2 * BI + 2 * RT>(); else wait_vmcnt<AI + 2 * BI>();
+    } else {
+      wait_vmcnt<0>();
+    }
     raw_barrier();
     if (wave >= 4) raw_barrier();                           // the second wave group runs one barrier behind
     stamp(stp, 4);
@@ -747,6 +766,7 @@ template <typename T, int BN> int launch8(IgemmArgs& a, hipStream_t s) {
   // 1 << 31: wherever the grid is no multiple of the CU count (tests of the mixed data-parallel + stream-K walk).
   int grid = ntiles < SK_GRID ? ntiles : SK_GRID;
   a.w8_dp_tiles = ntiles;
+  a.w8_drain = (g_rn_variant & (1 << 26)) ? 1 : 0;
   a.w8_ws = g_sk_ws;
   const int rem = ntiles % SK_GRID, full = ntiles / SK_GRID;
   const bool sk_forced = (g_rn_variant & (1u << 31)) != 0;
@@ -813,6 +833,7 @@ template <typename T> static int launch8_stem(IgemmArgs& a, hipStream_t s) {
   const int ntiles = cdiv(a.M, 256) * (a.Kd / 256);
   const int grid = ntiles < SK_GRID ? ntiles : SK_GRID;
   a.w8_dp_tiles = ntiles;
+  a.w8_drain = (g_rn_variant & (1 << 26)) ? 1 : 0;
   a.w8_ws = nullptr;
   if (a.bias) hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_BIAS, true>), dim3(grid), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((igemm8_kernel<T, 256, EP8_PLAIN, true>), dim3(grid), dim3(512), 0, s, a);

@@ -239,9 +239,16 @@ __device__ inline int xcd_band(int b, int G) { return (G & 7) ? b : (b & 7) * (G
 // exist in memory: the forward pools relu(x * scale + shift) on the fly (each value rounded to the compute dtype BEFORE the comparison,
 // so the argmax is the one the unfused pair picks), the backward gathers the pooled gradient through the stored argmax bytes where the
 // unfused pair would read maxpool_bwd's output.
+// Waves per SIMD the two register-heavy forms are asked to fit (second __launch_bounds__ argument; 1 = the compiler's own choice).  fp16 only, where it
+// was measured on the 112 x 112 x 512 map of WRN-50-2-B: the forward that also keeps the winners sat at 130 registers (3 waves; 2.16 ms), at 128 with two
+// spilled dwords it runs 4 waves (1.99 ms); the apply pass with column sums 177 registers (2 waves; 1.98 ms) -> 168 + two spilled dwords, 3 waves (1.75 ms).
+// bf16 needs more temporaries (44 bytes of scratch under the same request, 2.6 ms): left to the compiler.
+template <typename T> struct PoolWaves { static constexpr int FWD = 1, APPLY_SUMS = 1; };
+template <> struct PoolWaves<f16_t> { static constexpr int FWD = 4, APPLY_SUMS = 3; };
+
 template <typename T, int KS>                               // KS = 3: the 3 x 3 window unrolled, its nine loads issued before the first comparison
-__global__ __launch_bounds__(NT) void bn_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ coef, T* __restrict__ y, unsigned char* __restrict__ idx,
-                                                         int N, int H, int W, int C, int P, int Q, int k, int stride, int pad, int relu) {
+__global__ __launch_bounds__(NT, (KS == 3 ? PoolWaves<T>::FWD : 1)) void bn_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ coef, T* __restrict__ y, unsigned char* __restrict__ idx,
+                                                         T* __restrict__ xsel, int N, int H, int W, int C, int P, int Q, int k, int stride, int pad, int relu) {
   constexpr int CE = Elem<T>::CE;
   const int CC = C / CE;
   const long n = (long)N * P * Q * CC;
@@ -253,15 +260,16 @@ __global__ __launch_bounds__(NT) void bn_pool_fwd_kernel(const T* __restrict__ x
     const int nn = (int)(pix / P);
     float sc[CE], sh[CE], m[CE];
     __attribute__((aligned(8))) unsigned char am[CE];
+    Chunk<T> win;                                          // the input element that won each window (xsel: the backward's sums read it instead of the whole map)
 #pragma unroll
-    for (int e = 0; e < CE; ++e) { sc[e] = coef[cg * CE + e]; sh[e] = coef[C + cg * CE + e]; m[e] = -FLT_MAX; am[e] = 255; }
+    for (int e = 0; e < CE; ++e) { sc[e] = coef[cg * CE + e]; sh[e] = coef[C + cg * CE + e]; m[e] = -FLT_MAX; am[e] = 255; win.e[e] = Elem<T>::from_f(0.f); }
     auto offer = [&](const Chunk<T>& c, int pos) {
 #pragma unroll
       for (int e = 0; e < CE; ++e) {
         float v = fmaf(Elem<T>::to_f(c.e[e]), sc[e], sh[e]);
         if (relu) v = fmaxf(v, 0.f);
         v = Elem<T>::to_f(Elem<T>::from_f(v));              // what bn_apply would have stored
-        if (v > m[e] || am[e] == 255) { m[e] = v; am[e] = (unsigned char)pos; }
+        if (v > m[e] || am[e] == 255) { m[e] = v; am[e] = (unsigned char)pos; win.e[e] = c.e[e]; }
       }
     };
     if constexpr (KS == 3) {
@@ -295,12 +303,15 @@ __global__ __launch_bounds__(NT) void bn_pool_fwd_kernel(const T* __restrict__ x
       if constexpr (CE == 8) *reinterpret_cast<uint2*>(idx + i * CE) = *reinterpret_cast<const uint2*>(am);
       else *reinterpret_cast<unsigned*>(idx + i * CE) = *reinterpret_cast<const unsigned*>(am);
     }
+    if (xsel) store_chunk<T>(xsel + i * CE, win);
   }
 }
 
 // backward, gather form (as maxpool_bwd_kernel: one workgroup walks image rows, threads walk (w, channel chunk); NT % (C / CE) == 0, so a
 // thread keeps ONE channel chunk).  g = [x * scale + shift > 0] * sum of dy over the windows whose argmax is this element.
 // APPLY 0: partial[blockIdx][2][C] = (sum g, sum g * xhat);   APPLY 1: dx = scale * (g - dsum0 / count - xhat * dsum1 / count)
+// APPLY 2: as 1, and partial[blockIdx][2][C] = (sum dx, 0) of the STORED values -- the per-channel sums a biased producer (the
+// ImageNet stem convolution) needs for its bias gradient, which otherwise cost one more pass over the 3.3 GB gradient (bn_stats)
 template <typename T, int APPLY>
 struct BnPoolBack {                                         // what a thread does with one input pixel's chunk once its gathered gradient is known
   static constexpr int CE = Elem<T>::CE;
@@ -330,12 +341,22 @@ struct BnPoolBack {                                         // what a thread doe
       if (relu && !(fmaf(xv, sc[e], sh[e]) > 0.f)) gg = 0.f;
       if (APPLY) {
         co.e[e] = Elem<T>::from_f(__fmaf_rn(ka[e], gg, __fmaf_rn(kb[e], xv, kc[e])));
+        if (APPLY == 2) s0[e] += Elem<T>::to_f(co.e[e]);   // (the second row of the partials stays 0: nobody reads a sum of squares of this gradient)
       } else {
         const float xh = (xv - mean[e]) * invstd[e];
         s0[e] += gg; s1[e] += gg * xh;
       }
     }
     if (APPLY) store_chunk<T>(dx_at, co);
+  }
+  __device__ void window(const Chunk<T>& cx, const Chunk<T>& cd, int relu) {     // one pooling window: its winner's input value and its gradient (APPLY 0)
+#pragma unroll
+    for (int e = 0; e < CE; ++e) {
+      const float xv = Elem<T>::to_f(cx.e[e]);
+      float gg = Elem<T>::to_f(cd.e[e]);
+      if (relu && !(fmaf(xv, sc[e], sh[e]) > 0.f)) gg = 0.f;
+      s0[e] += gg; s1[e] += gg * ((xv - mean[e]) * invstd[e]);
+    }
   }
   __device__ void flush(float* __restrict__ partial, int C, int CC, int cg) {      // the workgroup's row of partial sums: lanes of one chunk through LDS
     __shared__ float red[2][NT][CE + 1];
@@ -402,7 +423,7 @@ __global__ __launch_bounds__(NT) void bn_pool_bwd_kernel(const T* __restrict__ d
       bk.pixel(cx, g, relu, dx + xo);
     }
   }
-  if (!APPLY) bk.flush(partial, C, CC, cg);
+  if (APPLY != 1) bk.flush(partial, C, CC, cg);
 }
 
 // the geometry every shipped spec has ("mp3,2,1" on an even map): a thread owns the 2 x 2 input pixels (2a..2a+1, 2b..2b+1) of one channel
@@ -410,7 +431,7 @@ __global__ __launch_bounds__(NT) void bn_pool_bwd_kernel(const T* __restrict__ d
 // per-pixel gather issues up to 4 for one, and all 12 loads are in flight before the first use.  A pixel adds its windows in the same
 // order (p major, q minor) as the per-pixel kernel, so both give the same bits.
 template <typename T, int APPLY>
-__global__ __launch_bounds__(NT) void bn_pool_bwd_quad_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx, const T* __restrict__ x,
+__global__ __launch_bounds__(NT, (APPLY == 2 ? PoolWaves<T>::APPLY_SUMS : 1)) void bn_pool_bwd_quad_kernel(const T* __restrict__ dy, const unsigned char* __restrict__ idx, const T* __restrict__ x,
                                                               const float* __restrict__ coef, const float* __restrict__ dsum, float* __restrict__ partial,
                                                               T* __restrict__ dx, int N, int H, int W, int C, int relu, int train, float inv_count) {
   constexpr int CE = Elem<T>::CE;
@@ -451,7 +472,36 @@ __global__ __launch_bounds__(NT) void bn_pool_bwd_quad_kernel(const T* __restric
       bk.pixel(cx[3], g[3], relu, dx + x10 + C);
     }
   }
-  if (!APPLY) bk.flush(partial, C, CC, cg);
+  if (APPLY != 1) bk.flush(partial, C, CC, cg);
+}
+
+// the backward sums at POOLED resolution: with the winning input element of every window kept by the forward (xsel), sum g and sum g * xhat are sums
+// over the windows -- g of an input element is the sum of the pooled gradients whose argmax it is, masked by ITS sign, and every one of those windows
+// stored that same element -- so the pass reads the pooled gradient and xsel (2 x 1/4 of the map) instead of the map, the gradient and the argmax
+// bytes.  (The gather kernels round a pixel's summed gradient to the compute dtype before using it, as the unfused chain stores it; here the windows
+// are added unrounded: a difference below the dtype's rounding per element, none in fp32.)  Row b of partial = windows b, b + nblk, ... in blocks of
+// NT / (C / CE) pixels; NT % (C / CE) == 0, so a thread keeps one channel chunk.
+template <typename T>
+__global__ __launch_bounds__(NT) void bn_pool_bwd_reduce_sel_kernel(const T* __restrict__ dy, const T* __restrict__ xsel, const float* __restrict__ coef,
+                                                                    float* __restrict__ partial, long npix, int C, int relu) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE, cg = threadIdx.x % CC, lanes = NT / CC;
+  BnPoolBack<T, 0> bk;
+  bk.init(coef, nullptr, C, cg, 1, 0.f);
+  const long step = (long)gridDim.x * lanes;
+  long p = (long)xcd_band(blockIdx.x, gridDim.x) * lanes + threadIdx.x / CC;
+  for (; p + 3 * step < npix; p += 4 * step) {                // four windows in flight per thread (adds in window order)
+    Chunk<T> d[4], xs[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const size_t o = (size_t)(p + u * step) * C + cg * CE; d[u] = load_chunk<T>(dy + o); xs[u] = load_chunk<T>(xsel + o); }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) bk.window(xs[u], d[u], relu);
+  }
+  for (; p < npix; p += step) {
+    const size_t o = (size_t)p * C + cg * CE;
+    bk.window(load_chunk<T>(xsel + o), load_chunk<T>(dy + o), relu);
+  }
+  bk.flush(partial, C, CC, cg);
 }
 
 // ---- global average pool: feat[n][c] = mean_{hw} x[n][hw][c] ------------------------------------------------
@@ -943,20 +993,39 @@ extern "C" int rn_maxpool_bwd(const void* dy, const unsigned char* argmax, void*
 }
 
 // fused BatchNorm-apply (+ReLU) + MaxPool: C / CE must divide 256; nblk (backward reduce) = workgroups = partial rows
-extern "C" int rn_bn_pool_fwd(const void* x, const float* coef, void* y, unsigned char* argmax, int dtype, int N, int H, int W, int C, int k, int stride,
-                              int pad, int flags, rn_stream s) {
+static int bn_pool_fwd(const void* x, const float* coef, void* y, unsigned char* argmax, void* xsel, int dtype, int N, int H, int W, int C, int k, int stride,
+                       int pad, int flags, rn_stream s) {
   if (int e = check_pool(dtype, N, H, W, C, k, stride, pad, "rn_bn_pool_fwd")) return e;
   RN_CHECK_ARG(x && coef && y && k * k < 255, "rn_bn_pool_fwd: bad argument");
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
   const long n = (long)N * P * Q * (C / (dtype == RN_F32 ? 4 : 8));
   if (k == 3) {
-    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_fwd_kernel<T_, 3>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const T_*)x, coef, (T_*)y, argmax, N, H, W, C, P, Q,
+    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_fwd_kernel<T_, 3>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const T_*)x, coef, (T_*)y, argmax, (T_*)xsel, N, H, W, C, P, Q,
                                           k, stride, pad, (flags & RN_F_RELU) ? 1 : 0));
   } else {
-    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_fwd_kernel<T_, 0>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const T_*)x, coef, (T_*)y, argmax, N, H, W, C, P, Q,
+    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_fwd_kernel<T_, 0>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const T_*)x, coef, (T_*)y, argmax, (T_*)xsel, N, H, W, C, P, Q,
                                           k, stride, pad, (flags & RN_F_RELU) ? 1 : 0));
   }
   RN_CHECK_LAUNCH("bn_pool_fwd");
+  return 0;
+}
+extern "C" int rn_bn_pool_fwd(const void* x, const float* coef, void* y, unsigned char* argmax, int dtype, int N, int H, int W, int C, int k, int stride,
+                              int pad, int flags, rn_stream s) {
+  return bn_pool_fwd(x, coef, y, argmax, nullptr, dtype, N, H, W, C, k, stride, pad, flags, s);
+}
+extern "C" int rn_bn_pool_fwd_sel(const void* x, const float* coef, void* y, unsigned char* argmax, void* xsel, int dtype, int N, int H, int W, int C, int k,
+                                  int stride, int pad, int flags, rn_stream s) {
+  RN_CHECK_ARG(xsel != nullptr, "rn_bn_pool_fwd_sel: null xsel");
+  return bn_pool_fwd(x, coef, y, argmax, xsel, dtype, N, H, W, C, k, stride, pad, flags, s);
+}
+extern "C" int rn_bn_pool_bwd_reduce_sel(const void* dy, const void* xsel, const float* coef, float* partial, int nblk, int dtype, long npix, int C, int flags,
+                                         rn_stream s) {
+  RN_CHECK_ARG(dy && xsel && coef && partial && npix > 0 && nblk > 0 && nblk <= 8192, "rn_bn_pool_bwd_reduce_sel: bad argument");
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype) && C > 0 && C % (dtype == RN_F32 ? 4 : 8) == 0 && NT % (C / (dtype == RN_F32 ? 4 : 8)) == 0,
+               "rn_bn_pool_bwd_reduce_sel: C=%d (C / chunk must divide %d)", C, NT);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_reduce_sel_kernel<T_>), dim3(nblk), dim3(NT), 0, as_stream(s), (const T_*)dy, (const T_*)xsel, coef, partial, npix, C,
+                                        (flags & RN_F_RELU) ? 1 : 0));
+  RN_CHECK_LAUNCH("bn_pool_bwd_reduce_sel");
   return 0;
 }
 static int bn_pool_bwd(const void* dy, const unsigned char* argmax, const void* x, const float* coef, const float* dsum, float* partial, int nblk, void* dx,
@@ -967,7 +1036,7 @@ static int bn_pool_bwd(const void* dy, const unsigned char* argmax, const void* 
   const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
   const int relu = (flags & RN_F_RELU) ? 1 : 0;
   const bool quad = k == 3 && stride == 2 && pad == 1 && H % 2 == 0 && W % 2 == 0 && !(g_rn_variant & (1 << 25));
-  if (partial) {
+  if (partial && !dx) {
     RN_CHECK_ARG(nblk > 0 && nblk <= N * H, "%s: nblk out of range", who);
     if (quad) {
       RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_quad_kernel<T_, 0>), dim3(nblk), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, nullptr,
@@ -979,14 +1048,26 @@ static int bn_pool_bwd(const void* dy, const unsigned char* argmax, const void* 
   } else {
     const int train = (flags & RN_F_TRAIN) ? 1 : 0;
     RN_CHECK_ARG((dsum || !train) && dx && count > 0, "%s: bad argument", who);
+    RN_CHECK_ARG(!partial || (nblk > 0 && nblk <= 8192), "%s: %d rows of column sums (1..8192)", who, nblk);
+    // with column sums the caller's row count IS the grid (one partial row per workgroup); the loops are grid-stride, any grid is correct
     if (quad) {
-      const int grid = (int)std::min<long>((long)N * (H / 2), 8192);
-      RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_quad_kernel<T_, 1>), dim3(grid), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, dsum,
-                                            nullptr, (T_*)dx, N, H, W, C, relu, train, (float)(1.0 / count)));
+      const int grid = partial ? nblk : (int)std::min<long>((long)N * (H / 2), 8192);
+      if (partial) {
+        RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_quad_kernel<T_, 2>), dim3(grid), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, dsum,
+                                              partial, (T_*)dx, N, H, W, C, relu, train, (float)(1.0 / count)));
+      } else {
+        RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_quad_kernel<T_, 1>), dim3(grid), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, dsum,
+                                              nullptr, (T_*)dx, N, H, W, C, relu, train, (float)(1.0 / count)));
+      }
     } else {
-      const int grid = (int)std::min<long>((long)N * H, 8192);
-      RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_kernel<T_, 1>), dim3(grid), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, dsum, nullptr,
-                                            (T_*)dx, N, H, W, C, P, Q, k, stride, pad, relu, train, (float)(1.0 / count)));
+      const int grid = partial ? nblk : (int)std::min<long>((long)N * H, 8192);
+      if (partial) {
+        RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_kernel<T_, 2>), dim3(grid), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, dsum, partial,
+                                              (T_*)dx, N, H, W, C, P, Q, k, stride, pad, relu, train, (float)(1.0 / count)));
+      } else {
+        RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_pool_bwd_kernel<T_, 1>), dim3(grid), dim3(NT), 0, as_stream(s), (const T_*)dy, argmax, (const T_*)x, coef, dsum, nullptr,
+                                              (T_*)dx, N, H, W, C, P, Q, k, stride, pad, relu, train, (float)(1.0 / count)));
+      }
     }
   }
   RN_CHECK_LAUNCH(who);
@@ -1000,6 +1081,11 @@ extern "C" int rn_bn_pool_bwd_reduce(const void* dy, const unsigned char* argmax
 extern "C" int rn_bn_pool_bwd_apply(const void* dy, const unsigned char* argmax, const void* x, const float* coef, const float* dsum, void* dx, int dtype, int N,
                                     int H, int W, int C, int k, int stride, int pad, int flags, double count, rn_stream s) {
   return bn_pool_bwd(dy, argmax, x, coef, dsum, nullptr, 0, dx, dtype, N, H, W, C, k, stride, pad, flags, count, s, "rn_bn_pool_bwd_apply");
+}
+extern "C" int rn_bn_pool_bwd_apply_sums(const void* dy, const unsigned char* argmax, const void* x, const float* coef, const float* dsum, void* dx, float* sums_partial,
+                                         int rows, int dtype, int N, int H, int W, int C, int k, int stride, int pad, int flags, double count, rn_stream s) {
+  RN_CHECK_ARG(sums_partial != nullptr, "rn_bn_pool_bwd_apply_sums: null sums_partial");
+  return bn_pool_bwd(dy, argmax, x, coef, dsum, sums_partial, rows, dx, dtype, N, H, W, C, k, stride, pad, flags, count, s, "rn_bn_pool_bwd_apply_sums");
 }
 
 extern "C" int rn_pool_fc_fwd(const void* x, const float* w, const float* b, float* feat, float* logits, int dtype, int N, int HW, int C, int O, rn_stream s) {

@@ -314,11 +314,18 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
       return rn_img_to_nhwc((const float*)B(0), B(1), dt, d[0], d[1], d[2], d[3], d[4], s);
     case RN_OP_PACK_STEM_W:
       return rn_pack_stem_w((const float*)B(0), B(1), dt, d[0], d[1], d[2], d[3], s);
-    case RN_OP_BN_POOL_FWD:            /* x coef y argmax | N H W C k stride pad */
+    case RN_OP_BN_POOL_FWD:            /* x coef y argmax xsel | N H W C k stride pad */
+      if (B(4))
+        return rn_bn_pool_fwd_sel(B(0), (const float*)B(1), B(2), (unsigned char*)B(3), B(4), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], o.flags, s);
       return rn_bn_pool_fwd(B(0), (const float*)B(1), B(2), (unsigned char*)B(3), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], o.flags, s);
-    case RN_OP_BN_POOL_BWD_REDUCE:     /* dy argmax x coef partial | N H W C k stride pad nblk */
+    case RN_OP_BN_POOL_BWD_REDUCE:     /* dy argmax x coef partial xsel | N H W C k stride pad nblk npix */
+      if (B(5))
+        return rn_bn_pool_bwd_reduce_sel(B(0), B(5), (const float*)B(3), (float*)B(4), d[7], dt, (long)d[8], d[3], o.flags, s);
       return rn_bn_pool_bwd_reduce(B(0), (const unsigned char*)B(1), B(2), (const float*)B(3), (float*)B(4), d[7], dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], o.flags, s);
-    case RN_OP_BN_POOL_BWD_APPLY:      /* dy argmax x coef dsum dx | N H W C k stride pad count */
+    case RN_OP_BN_POOL_BWD_APPLY:      /* dy argmax x coef dsum dx sums | N H W C k stride pad count rows */
+      if (B(6))
+        return rn_bn_pool_bwd_apply_sums(B(0), (const unsigned char*)B(1), B(2), (const float*)B(3), (const float*)B(4), B(5), (float*)B(6), d[8], dt, d[0], d[1], d[2], d[3],
+                                         d[4], d[5], d[6], o.flags, (double)d[7], s);
       return rn_bn_pool_bwd_apply(B(0), (const unsigned char*)B(1), B(2), (const float*)B(3), (const float*)B(4), B(5), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6],
                                   o.flags, (double)d[7], s);
     case RN_OP_UNPACK_STEM_DW:

@@ -50,9 +50,9 @@ OP_FIELDS = {
     OP_IMG_TO_NHWC:     ('x out', 'N C H W CP', ''),
     OP_PACK_STEM_W:     ('w w_padded', 'K RS C CP', ''),
     OP_UNPACK_STEM_DW:  ('dw_padded dw', 'K RS C CP', ''),
-    OP_BN_POOL_FWD:     ('x coef y argmax', 'N H W C k stride pad', ''),
-    OP_BN_POOL_BWD_REDUCE: ('dy argmax x coef partial', 'N H W C k stride pad nblk', ''),
-    OP_BN_POOL_BWD_APPLY:  ('dy argmax x coef dsum dx', 'N H W C k stride pad count', ''),
+    OP_BN_POOL_FWD:     ('x coef y argmax xsel', 'N H W C k stride pad', ''),
+    OP_BN_POOL_BWD_REDUCE: ('dy argmax x coef partial xsel', 'N H W C k stride pad nblk npix', ''),
+    OP_BN_POOL_BWD_APPLY:  ('dy argmax x coef dsum dx sums', 'N H W C k stride pad count rows', ''),
 }
 
 GEOM = 'N H W C P Q K R S stride pad'.split()

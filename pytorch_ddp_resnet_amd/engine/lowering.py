@@ -99,6 +99,8 @@ class Lowering:
         self._ws_need = []              # geometries of ops that share the workspace slot
         self.fwd_packs: List[Op] = []   # weight-pack ops, emitted in front of the forward
         self._stats_of: Dict[int, Tuple[int, int]] = {}    # tensor slot -> (partial slot, rows) written by its producer's epilogue
+        self._wants_colsum = set()                         # outputs of biased convolutions: their gradient's per-channel sums are the bias gradient
+        self._colsum_of: Dict[int, Tuple[int, int]] = {}   # gradient slot -> (partial slot, rows) left by the pass that wrote it
         self._tail_bn: Dict[int, dict] = {}                # output slot of a BN(+add)+ReLU -> its record: the consumer's dgrad reduces its backward sums
         self._dpart_of: Dict[int, Tuple[int, int]] = {}    # gradient tensor slot -> BN-backward partial sums from the dgrad epilogue
         self._site_of: Dict[int, Tuple[float, int, bool]] = {}   # BN_APPLY output slot -> (dropout p, site, mask recomputable)
@@ -456,6 +458,7 @@ class Lowering:
                         part = self.f32(pre + ':stats', (rows, 2, c.cout))
                         self._stats_of[y.s] = (part, rows)
                     self.fwd.append(Op(ir.OP_CONV_FWD, buf=dict(x=xp.s, w_fwd=wp, y=y.s, res=-1, stats=part, bias=b), dim=dict(g, res_mode=0, res_C=0), note=pre))
+                    self._wants_colsum.add(y.s)           # whoever writes d(y) may leave its per-channel sums (the bias gradient) behind
 
                     def stem_back(dy: T, ops, g=g, xp=xp, pre=pre, cin=c.cin, CP=CP):
                         K, RS = g['K'], g['R'] * g['S']
@@ -464,10 +467,13 @@ class Lowering:
                         self._ws_need.append(('wgrad', dict(g)))
                         dw, db = self.grad(pre + '.weight', (K, g['R'], g['S'], cin)), self.grad(pre + '.bias', (K,))
                         ops.append(Op(ir.OP_UNPACK_STEM_DW, buf=dict(dw_padded=dwp, dw=dw), dim=dict(K=K, RS=RS, C=cin, CP=CP), note=pre))
-                        nblk = bn_partials(dy.M, K)               # bias gradient = per-channel sum of dy
-                        part = self.f32(pre + ':dbpartial', (nblk, 2, K))
                         s2, sq = self.f32(pre + ':dbsum', (2, K)), self.f32(pre + ':dbsq', (K,))       # by-products, unused
-                        ops.append(Op(ir.OP_BN_STATS, buf=dict(x=dy.s, partial=part), dim=dict(M=dy.M, C=K, nblk=nblk), note=pre))
+                        if dy.s in self._colsum_of:               # bias gradient = per-channel sum of dy: left behind by the pass that wrote dy ...
+                            part, nblk = self._colsum_of[dy.s]
+                        else:                                     # ... or one more pass over it
+                            nblk = bn_partials(dy.M, K)
+                            part = self.f32(pre + ':dbpartial', (nblk, 2, K))
+                            ops.append(Op(ir.OP_BN_STATS, buf=dict(x=dy.s, partial=part), dim=dict(M=dy.M, C=K, nblk=nblk), note=pre))
                         ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=s2, dgamma=sq, dbeta=db), dim=dict(nblk=nblk, C=K), note=pre))
                         self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
                         return None
@@ -501,21 +507,31 @@ class Lowering:
                     y = self.act(mpre + ':y', cur.N, P, Q, cur.C)
                     d = dict(N=cur.N, H=cur.H, W=cur.W, C=cur.C, k=k, stride=s, pad=pd)
                     am = self.slot(mpre + ':argmax', 'u8', (cur.N, P, Q, cur.C), 'u8') if self.need_grad else -1
+                    # the window winners' INPUT values: the backward sums are then taken at pooled resolution (2 x 1/4 of the map read instead of the map)
+                    xsel = self.act(mpre + ':xsel', cur.N, P, Q, cur.C).s if (self.need_grad and self.train and os.environ.get('RN_POOL_GATHER_SUMS', '0') != '1') else -1
                     fl = ir.F_RELU if relu else 0
-                    self.fwd.append(Op(ir.OP_BN_POOL_FWD, buf=dict(x=cur.s, coef=coef, y=y.s, argmax=am), dim=d, flags=fl, note=pre))
+                    self.fwd.append(Op(ir.OP_BN_POOL_FWD, buf=dict(x=cur.s, coef=coef, y=y.s, argmax=am, xsel=xsel), dim=d, flags=fl, note=pre))
 
-                    def norm_pool_back(dy: T, ops, x=cur, coef=coef, pre=pre, d=d, am=am, fl=fl):
+                    def norm_pool_back(dy: T, ops, x=cur, coef=coef, pre=pre, d=d, am=am, fl=fl, xsel=xsel):
                         C = x.C
                         nblk = min(x.N * x.H, 2048)
                         part = self.f32(pre + ':dpartial', (nblk, 2, C))
                         dsum = self.f32(pre + ':dsum', (2, C))
                         flt = fl | (ir.F_TRAIN if self.train else 0)
-                        ops.append(Op(ir.OP_BN_POOL_BWD_REDUCE, buf=dict(dy=dy.s, argmax=am, x=x.s, coef=coef, partial=part), dim=dict(d, nblk=nblk), flags=flt, note=pre))
+                        ops.append(Op(ir.OP_BN_POOL_BWD_REDUCE, buf=dict(dy=dy.s, argmax=am, x=x.s, coef=coef, partial=part, xsel=xsel), dim=dict(d, nblk=nblk, npix=dy.M),
+                                      flags=flt, note=pre))
                         dg, db = self.grad(pre + '.weight', (C,)), self.grad(pre + '.bias', (C,))
                         ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=dsum, dgamma=dg, dbeta=db), dim=dict(nblk=nblk, C=C), note=pre))
                         self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
                         dx = self.act(pre + ':dx', x.N, x.H, x.W, C)
-                        ops.append(Op(ir.OP_BN_POOL_BWD_APPLY, buf=dict(dy=dy.s, argmax=am, x=x.s, coef=coef, dsum=dsum, dx=dx.s), dim=dict(d, count=x.M), flags=flt, note=pre))
+                        sums, rows = -1, 0
+                        if x.s in self._wants_colsum and os.environ.get('RN_POOL_NO_COLSUM', '0') != '1':
+                            quad = (d['k'], d['stride'], d['pad']) == (3, 2, 1) and x.H % 2 == 0 and x.W % 2 == 0
+                            rows = min(x.N * (x.H // 2 if quad else x.H), 8192)         # the pass's own grid: one row of sums per workgroup
+                            sums = self.f32(pre + ':dxsums', (rows, 2, C))
+                            self._colsum_of[dx.s] = (sums, rows)
+                        ops.append(Op(ir.OP_BN_POOL_BWD_APPLY, buf=dict(dy=dy.s, argmax=am, x=x.s, coef=coef, dsum=dsum, dx=dx.s, sums=sums), dim=dict(d, count=x.M, rows=rows),
+                                      flags=flt, note=pre))
                         return dx
                     self._back.append(norm_pool_back)
                     cur = y

@@ -29,6 +29,19 @@ def keep_mask(n, p, site, step_seed):
     return h >= thr
 
 
+def pool_winner(x, arg, k, stride, pad):
+    """x[N,H,W,C] gathered at each pooling window's argmax (window-local flat index r*k+s) -> [N,P,Q,C]"""
+    N, H, W, C = x.shape
+    P, Q = arg.shape[1], arg.shape[2]
+    xp = np.zeros((N, H + 2 * pad, W + 2 * pad, C), dtype=x.dtype)
+    xp[:, pad:pad + H, pad:pad + W, :] = x
+    out = np.zeros((N, P, Q, C), dtype=x.dtype)
+    for r in range(k):
+        for s in range(k):
+            out += xp[:, r:r + stride * P:stride, s:s + stride * Q:stride, :] * (arg == r * k + s)
+    return out
+
+
 def res_read(res, mode, N, H, W, C):
     """the residual / merge operand as seen from a destination of shape [N,H,W,C]."""
     if mode == ir.RES_SAME:
@@ -190,6 +203,17 @@ class NumpyPlan:
             put('y', y)
             if op.buf.get('argmax', -1) >= 0:
                 put('argmax', arg.astype(np.uint8))
+            if op.buf.get('xsel', -1) >= 0:                # the input element under each window's argmax
+                put('xsel', pool_winner(B('x'), arg, d['k'], d['stride'], d['pad']))
+        elif k == ir.OP_BN_POOL_BWD_REDUCE and op.buf.get('xsel', -1) >= 0:
+            coef, C, nblk = B('coef'), d['C'], d['nblk']   # sums over the WINDOWS: gradient of a window goes to its winner, masked by the winner's sign
+            g, xs = B('dy').reshape(-1, C), B('xsel').reshape(-1, C)
+            if op.flags & ir.F_RELU:
+                g = g * ((xs * coef[0] + coef[1]) > 0)
+            part = np.zeros((nblk, 2, C), dtype=self.dtype)
+            part[0, 0] = g.sum(0)
+            part[0, 1] = (g * ((xs - coef[2]) * coef[3])).sum(0)
+            put('partial', part)
         elif k in (ir.OP_BN_POOL_BWD_REDUCE, ir.OP_BN_POOL_BWD_APPLY):
             coef = B('coef')
             g = ops.maxpool_bwd(B('dy'), B('argmax').astype(np.int64), d['k'], d['stride'], d['pad'], d['H'], d['W'])
@@ -207,7 +231,12 @@ class NumpyPlan:
                 put('partial', part)
             else:
                 dsum = B('dsum')
-                put('dx', coef[0] * (g - dsum[0] / d['count'] - xhat * (dsum[1] / d['count'])) if op.flags & ir.F_TRAIN else coef[0] * g)
+                dx = coef[0] * (g - dsum[0] / d['count'] - xhat * (dsum[1] / d['count'])) if op.flags & ir.F_TRAIN else coef[0] * g
+                put('dx', dx)
+                if op.buf.get('sums', -1) >= 0:           # per-channel (sum dx, 0): which workgroup row holds what is the kernel's business, the total is not
+                    part = np.zeros((d['rows'], 2, C), dtype=self.dtype)
+                    part[0, 0] = dx.reshape(-1, C).sum(0)             # second row: zeros (no consumer of a sum of squares here)
+                    put('sums', part)
         elif k == ir.OP_MAXPOOL_BWD:
             put('dx', ops.maxpool_bwd(B('dy'), B('argmax').astype(np.int64), d['k'], d['stride'], d['pad'], d['H'], d['W']))
         elif k == ir.OP_POOL_FC_FWD:

@@ -135,7 +135,14 @@ def test_hot_kernels_keep_their_occupancy():
         k = find(f'wgrad8_kernelI{dt}E')
         assert k['Occupancy'] >= 2 and k['VGPRs'] <= 256 and k['LDS Size'] <= LDS_CU and k['ScratchSize'] == 0, k
     spilling = ('igemm8_kernel',)          # its bnb+res / bnb+acc / general epilogues spill a few registers (known): checked above per mode
+    # two fp16 forms of the fused BatchNorm + MaxPool passes trade two spilled dwords for a wave per SIMD (misc.hip PoolWaves: measured 2.16 -> 1.99 ms and
+    # 1.98 -> 1.75 ms on WRN-50-2-B's stem map): the exception holds only while the occupancy it buys is there
+    traded = {'bn_pool_fwd_kernelIDF16_Li3E': 4, 'bn_pool_bwd_quad_kernelIDF16_Li2E': 3}
     for name, k in res.items():
         if any(e in name for e in spilling):
+            continue
+        want = [w for e, w in traded.items() if e in name]
+        if want:
+            assert k.get('ScratchSize', 0) <= 8 and k['Occupancy'] >= want[0], (name, k)
             continue
         assert k.get('ScratchSize', 0) == 0, (name, k)

@@ -451,6 +451,7 @@ def test_bn_relu_maxpool_fused(shape, fp32):
     dy = b.slot('dy', (N, P, Q, C)); nblk = min(N * Hh, 5)
     part = b.slot('part', (nblk, 2, C), 'f32'); dsum = b.slot('dsum', (2, C), 'f32'); dg = b.slot('dg', (C,), 'f32'); db = b.slot('db', (C,), 'f32')
     dx = b.slot('dx', (N, Hh, W, C))
+    rows = min(N * Hh, 7); sums = b.slot('sums', (rows, 2, C), 'f32'); cs = b.slot('cs', (2, C), 'f32'); csq = b.slot('csq', (C,), 'f32'); cdb = b.slot('cdb', (C,), 'f32')
     da2 = b.slot('da2', (N, Hh, W, C)); part2 = b.slot('part2', (nblk, 2, C), 'f32'); dsum2 = b.slot('dsum2', (2, C), 'f32')
     dg2 = b.slot('dg2', (C,), 'f32'); db2 = b.slot('db2', (C,), 'f32'); dx2 = b.slot('dx2', (N, Hh, W, C))
     dpool = dict(N=N, H=Hh, W=W, C=C, k=k, stride=st, pad=pd)
@@ -458,7 +459,15 @@ def test_bn_relu_maxpool_fused(shape, fp32):
     b.op(ir.OP_BN_POOL_FWD, buf=dict(x=x, coef=coef, y=y, argmax=am), dim=dpool, flags=ir.F_RELU)
     b.op(ir.OP_BN_POOL_BWD_REDUCE, buf=dict(dy=dy, argmax=am, x=x, coef=coef, partial=part), dim=dict(dpool, nblk=nblk), flags=fl)
     b.op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=dsum, dgamma=dg, dbeta=db), dim=dict(nblk=nblk, C=C))
-    b.op(ir.OP_BN_POOL_BWD_APPLY, buf=dict(dy=dy, argmax=am, x=x, coef=coef, dsum=dsum, dx=dx), dim=dict(dpool, count=M), flags=fl)
+    # the production form: the forward keeps each window's winning input element, the sums are taken over the windows (pooled resolution)
+    ys = b.slot('ys', (N, P, Q, C)); ams = b.slot('ams', (N, P, Q, C), 'u8', role='u8'); xsel = b.slot('xsel', (N, P, Q, C))
+    parts = b.slot('parts', (nblk, 2, C), 'f32'); dsums = b.slot('dsums', (2, C), 'f32'); dgs = b.slot('dgs', (C,), 'f32'); dbs = b.slot('dbs', (C,), 'f32')
+    b.op(ir.OP_BN_POOL_FWD, buf=dict(x=x, coef=coef, y=ys, argmax=ams, xsel=xsel), dim=dpool, flags=ir.F_RELU)
+    b.op(ir.OP_BN_POOL_BWD_REDUCE, buf=dict(dy=dy, argmax=ams, x=x, coef=coef, partial=parts, xsel=xsel), dim=dict(dpool, nblk=nblk, npix=N * P * Q), flags=fl)
+    b.op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=parts, dsum=dsums, dgamma=dgs, dbeta=dbs), dim=dict(nblk=nblk, C=C))
+    # the apply pass also leaves the per-channel sums of the gradient it stores (the bias gradient of a biased producer, summed by the finalize kernel)
+    b.op(ir.OP_BN_POOL_BWD_APPLY, buf=dict(dy=dy, argmax=am, x=x, coef=coef, dsum=dsum, dx=dx, sums=sums), dim=dict(dpool, count=M, rows=rows), flags=fl)
+    b.op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=sums, dsum=cs, dgamma=csq, dbeta=cdb), dim=dict(nblk=rows, C=C))
     # the unfused chain on the same inputs
     b.op(ir.OP_BN_APPLY, buf=dict(x=x, coef=coef, res=-1, out=a2), dim=dict(N=N, H=Hh, W=W, C=C, res_mode=0, res_C=0), fp=dict(p=0.0), flags=ir.F_RELU)
     b.op(ir.OP_MAXPOOL_FWD, buf=dict(x=a2, y=y2, argmax=am2), dim=dpool)
@@ -475,7 +484,14 @@ def test_bn_relu_maxpool_fused(shape, fp32):
     tol = TOL[fp32]
     assert h.max_rel(hip['y'], ref['y']) < tol
     assert np.array_equal(hip['y'], hip['y2']) and np.array_equal(hip['am'], hip['am2'])          # fused == unfused, bit for bit
+    assert np.array_equal(hip['ys'], hip['y']) and np.array_equal(hip['ams'], hip['am'])
+    for a_, b_ in (('dsums', 'dsum'), ('dgs', 'dg'), ('dbs', 'db')):            # windows added unrounded vs each pixel's sum rounded first
+        assert h.max_rel(hip[a_], hip[b_]) < (1e-5 if fp32 else 5e-3), a_
     for a_, b_ in (('dsum', 'dsum2'), ('dg', 'dg2'), ('db', 'db2'), ('dx', 'dx2')):
         assert h.max_rel(hip[a_], hip[b_]) < 1e-5 if fp32 else h.max_rel(hip[a_], hip[b_]) < 2e-2, a_
+    colsum = hip['dx'].reshape(-1, C).astype(np.float64).sum(0)                # of the STORED gradient; its true value is 0 (BatchNorm removes the mean): absolute bound
+    scale = np.abs(hip['dx']).reshape(-1, C).astype(np.float64).sum(0).max()
+    assert np.abs(hip['cdb'] - colsum).max() <= 1e-5 * scale + 1e-6
     if fp32:       # in 16 bits a window's winner can differ from the float64 interpreter's after rounding (near-ties): the device-side unfused chain above is the reference there
         assert h.max_rel(hip['dsum'], ref['dsum']) < tol and h.max_rel(hip['dx'], ref['dx']) < tol
+        assert h.max_rel(hip['xsel'], ref['xsel']) < tol and h.max_rel(hip['dsums'], ref['dsums']) < tol
