@@ -101,7 +101,7 @@ typedef struct rn_plan rn_plan;
 const char* rn_last_error(void);
 /* ABI version: bumped with EVERY change of an entry point's signature or meaning; a binding refuses a library of another version (a stale
  * librn_hip.so would otherwise take shifted pointer / integer arguments).  3: round 3 (operand-set flags of rn_conv_kernel_names, workspaces). */
-#define RN_ABI_VERSION 4
+#define RN_ABI_VERSION 5
 int rn_version(void);
 /* kernel-variant switch for A/B measurements (tools/conv_bench.py; bits documented in csrc/conv_igemm.hip); 0 = shipped */
 void rn_set_variant(int v);
@@ -238,6 +238,16 @@ int rn_bn_stats(const void* x, float* partial, int nblk, int dtype, int64_t M, i
 int rn_bn_finalize(const float* partial, int nblk, double count, const float* gamma, const float* beta,
                    float* running_mean, float* running_var, int64_t* num_batches_tracked, float* coef, int C,
                    float eps, float momentum, int flags, rn_stream s);
+/* The two finalize kernels with the partial ROWS split over workgroups, for the thousands of rows the fused conv epilogues leave on the ImageNet nets
+ * (one workgroup per 16 channels reads them at a fraction of HBM speed).  rn_bn_fold_bytes(nblk, C): bytes of the caller-owned `fold` buffer such a
+ * launch needs, 0 = this size is not split (call the plain function).  `fold` must be zero before its first use and belong to ONE layer (launches that
+ * may overlap must not share it); the sums are added in a fixed order (bitwise reproducible).  Training mode only for the forward form. */
+size_t rn_bn_fold_bytes(int nblk, int C);
+int rn_bn_finalize_split(const float* partial, int nblk, double count, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, int64_t* num_batches_tracked, float* coef, int C,
+                         float eps, float momentum, int flags, void* fold, size_t fold_bytes, rn_stream s);
+int rn_bn_bwd_finalize_split(const float* partial, int nblk, float* dsum, float* dgamma, float* dbeta, int C, int flags, void* fold, size_t fold_bytes,
+                             rn_stream s);
 /* out = [relu](x*scale+shift [+ res]) [dropout(p)] ; geometry N,H,W of x for the residual mapping */
 int rn_bn_apply(const void* x, const float* coef, const void* res, void* out, int dtype, int N, int H, int W, int C,
                 int res_mode, int res_C, int flags, float drop_p, uint32_t site, uint64_t step_seed, rn_stream s);

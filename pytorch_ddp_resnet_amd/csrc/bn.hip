@@ -90,7 +90,7 @@ __global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, 
 // reduces [nblk][2][C] partials in double: 16 channels x 64 slab-lanes per workgroup (the fused conv epilogues write one
 // partial row per 128 output pixels: up to 1024 rows)
 constexpr int FC = 16, FL = 64;
-__device__ inline void reduce_partials(const float* __restrict__ partial, int nblk, int C, int c, int bl, double& s, double& ss, double (*red)[FL][FC]) {
+__device__ inline void reduce_partials(const float* __restrict__ partial, int nblk, int C, int c, int bl, double& s, double& ss, double (*red)[FL][FC], int b_lo = 0) {
   // fixed-order tree (bitwise reproducible): rows b = bl, bl+64, ... per thread; the 4 row lanes of a wave by shuffles; the 16
   // waves through LDS, 4 per lane group of wave 0, then shuffles again.  The result is valid in threads 0..15 (bl == 0).
   // (a serial 64-step LDS loop here cost ~2.8 us of a 6 us kernel)
@@ -98,7 +98,7 @@ __device__ inline void reduce_partials(const float* __restrict__ partial, int nb
   // memory round trip of its own (16 rows per thread on the 16-channel layers of ResNet-v2-164: 8.1 us for a one-workgroup launch)
   s = 0.0; ss = 0.0;
   if (c < C) {
-    int b = bl;
+    int b = b_lo + bl;                                     // rows [b_lo, nblk)
     for (; b + 7 * FL < nblk; b += 8 * FL) {
       float v0[8], v1[8];
 #pragma unroll
@@ -106,12 +106,22 @@ __device__ inline void reduce_partials(const float* __restrict__ partial, int nb
 #pragma unroll
       for (int u = 0; u < 8; ++u) { s += (double)v0[u]; ss += (double)v1[u]; }
     }
-    for (; b + FL < nblk; b += 2 * FL) {
-      const float a0 = partial[((size_t)b * 2) * C + c], a1 = partial[((size_t)b * 2 + 1) * C + c];
-      const float b0 = partial[((size_t)(b + FL) * 2) * C + c], b1 = partial[((size_t)(b + FL) * 2 + 1) * C + c];
-      s += (double)a0; ss += (double)a1; s += (double)b0; ss += (double)b1;
+    if (b < nblk) {
+      // the remaining 1-7 rows of this thread in ONE round trip: every load issued (a row past the end re-reads the last row and counts as zero -- a
+      // branch around a load would make each one a round trip of its own).  Pairs and singles here took 3-4 dependent trips on the 98-392-row layers
+      // (19-24 us per launch for 1.6-6.4 MB).  Same rows, same order of adds as before.
+      float v0[8], v1[8];
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const int row = min(b + u * FL, nblk - 1);
+        v0[u] = partial[((size_t)row * 2) * C + c]; v1[u] = partial[((size_t)row * 2 + 1) * C + c];
+      }
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const bool in = b + u * FL < nblk;
+        s += in ? (double)v0[u] : 0.0; ss += in ? (double)v1[u] : 0.0;
+      }
     }
-    for (; b < nblk; b += FL) { s += (double)partial[((size_t)b * 2) * C + c]; ss += (double)partial[((size_t)b * 2 + 1) * C + c]; }
   }
   static_assert(FC == 16 && FL == 64, "reduction tree is written for 16 channels x 64 row lanes");
   const int tid = threadIdx.x, cl = tid % FC, wave = tid >> 6, lane = tid & 63;
@@ -170,6 +180,121 @@ __global__ __launch_bounds__(FC * FL) void bn_bwd_finalize_kernel(const float* _
   dsum[C + c] = (float)ss;
   if (accum) { dbeta[c] += (float)s; dgamma[c] += (float)ss; }
   else { dbeta[c] = (float)s; dgamma[c] = (float)ss; }
+}
+
+// ---- the same two kernels with the ROWS split over workgroups.  One workgroup per 16 channels is 8-128 workgroups; on the ImageNet nets the fused
+// conv epilogues leave 1,568-25,088 rows per layer (WRN-50-2-B: 780 MB of partial sums per step), which those few workgroups read at ~1.5 TB/s
+// (17 us per launch, 1.7 ms per step).  Here workgroup (channel group cb, split sp) sums rows [sp, sp + 1) * nblk / S as above, publishes its 2 x 16
+// doubles and draws a ticket; the LAST arriver of a channel group adds the S parts in split order (fixed order: bitwise reproducible, whoever arrives
+// last) and does the finalize arithmetic.  Nobody waits: no spin, no residency assumption.  fold = [counters: ncb ints, padded to 64 B][cb][sp][2][16] doubles,
+// caller-owned, zero before the first launch (the last arriver leaves its counter at zero).  Hand-off as in conv_igemm8.hip: write-through (sc1) stores,
+// drained by the storing wave before its lane 0 draws the ticket; the finisher acquires once and reads the parts with sc1 loads.
+__device__ inline __amdgpu_buffer_rsrc_t fold_rsrc(void* fold) { return __builtin_amdgcn_make_buffer_rsrc(fold, 0, 0x7FFFFFF0, 0x00020000); }
+__host__ __device__ inline int fold_header_bytes(int ncb) { return ((ncb * 4 + 63) / 64) * 64; }
+
+// returns true in EVERY thread of the one workgroup per channel group that finishes; then s / ss hold the totals in threads 0..15
+__device__ inline bool fold_rows(const float* __restrict__ partial, int nblk, int C, void* fold, int S, double& s, double& ss, double (*red)[FL][FC], int* flag) {
+  const int ncb = (C + FC - 1) / FC;
+  const int cb = blockIdx.x % ncb, sp = blockIdx.x / ncb;  // neighbouring workgroups: neighbouring channel groups of the same rows (the two halves of a 128-byte line)
+  const int c = cb * FC + threadIdx.x % FC, bl = threadIdx.x / FC;
+  const int b_lo = (int)((long)sp * nblk / S), b_hi = (int)((long)(sp + 1) * nblk / S);
+  reduce_partials(partial, b_hi, C, c, bl, s, ss, red, b_lo);
+  const __amdgpu_buffer_rsrc_t r = fold_rsrc(fold);
+  const int base = fold_header_bytes(ncb) + ((cb * S + sp) * 2) * FC * 8;
+  typedef unsigned v2u32 __attribute__((ext_vector_type(2)));
+  if (threadIdx.x < FC) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, s), r, base + (int)threadIdx.x * 8, 0, 16);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u32, ss), r, base + (FC + (int)threadIdx.x) * 8, 0, 16);
+  }
+  if (threadIdx.x < 64) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the storing wave drains; its lane 0 signals
+  int* cnt = reinterpret_cast<int*>(fold) + cb;
+  if (threadIdx.x == 0) *flag = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (*flag != S - 1) return false;                        // workgroup-uniform
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // every part has arrived: clean for the next launch
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  s = 0.0; ss = 0.0;
+  if (threadIdx.x < FC) {
+    const int first = fold_header_bytes(ncb) + (cb * S * 2) * FC * 8 + (int)threadIdx.x * 8;
+    int q = 0;
+    for (; q + 4 <= S; q += 4) {                           // four parts in flight, added in split order
+      v2u32 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        a[u] = __builtin_amdgcn_raw_buffer_load_b64(r, first + (q + u) * 2 * FC * 8, 0, 16);
+        b[u] = __builtin_amdgcn_raw_buffer_load_b64(r, first + ((q + u) * 2 + 1) * FC * 8, 0, 16);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s += __builtin_bit_cast(double, a[u]); ss += __builtin_bit_cast(double, b[u]); }
+    }
+    for (; q < S; ++q) {
+      s += __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, first + q * 2 * FC * 8, 0, 16));
+      ss += __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, first + (q * 2 + 1) * FC * 8, 0, 16));
+    }
+  }
+  return true;
+}
+
+__global__ __launch_bounds__(FC * FL) void bn_finalize_split_kernel(const float* __restrict__ partial, int nblk, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
+                                   long long* __restrict__ nbt, float* __restrict__ coef, int C, float eps, float momentum, void* fold, int S) {
+  __shared__ double red[2][FL][FC];
+  __shared__ int flag;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && nbt) nbt[0] += 1;
+  double s, ss;
+  if (!fold_rows(partial, nblk, C, fold, S, s, ss, red, &flag)) return;
+  const int c = (blockIdx.x % ((C + FC - 1) / FC)) * FC + threadIdx.x;
+  if (threadIdx.x >= FC || c >= C) return;
+  const double mean = s / count;
+  double var = ss / count - mean * mean;                  // the arithmetic of bn_finalize_kernel
+  if (var < 0.0) var = 0.0;
+  const double unbiased = var * (count / (count > 1.0 ? count - 1.0 : 1.0));
+  rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mean);
+  rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unbiased);
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const double scale = (double)gamma[c] * invstd;
+  coef[c] = (float)scale;
+  coef[C + c] = (float)((double)beta[c] - mean * scale);
+  coef[2 * C + c] = (float)mean;
+  coef[3 * C + c] = (float)invstd;
+}
+
+__global__ __launch_bounds__(FC * FL) void bn_bwd_finalize_split_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dsum, float* __restrict__ dgamma,
+                                       float* __restrict__ dbeta, int C, int accum, void* fold, int S) {
+  __shared__ double red[2][FL][FC];
+  __shared__ int flag;
+  double s, ss;
+  if (!fold_rows(partial, nblk, C, fold, S, s, ss, red, &flag)) return;
+  const int c = (blockIdx.x % ((C + FC - 1) / FC)) * FC + threadIdx.x;
+  if (threadIdx.x >= FC || c >= C) return;
+  dsum[c] = (float)s;
+  dsum[C + c] = (float)ss;
+  if (accum) { dbeta[c] += (float)s; dgamma[c] += (float)ss; }
+  else { dbeta[c] = (float)s; dgamma[c] = (float)ss; }
+}
+
+// rows split S ways when one workgroup per 16 channels leaves the chip idle: >= 256 rows per part, ~1024 workgroups at most.  Measured
+// (tools/finalize_bench.py, us per launch plain -> split): 25.7 MB of partials 29.9 -> 17.7, 33.6 MB 37.1 -> 21.4, 102.8 MB 103 -> 38, 6.4 MB in 8 channel
+// groups 14.4 -> 11.0; but 3.2 MB 7.6 -> 9.7, 8.4 MB 8.5 -> 9.5, 12.8 MB 10.9 -> 10.6 (the ticket and the finisher cost ~3 us): split from 16 MB, or from 4 MB
+// when the plain kernel would be 8 workgroups or fewer.
+static int fold_splits(int nblk, int C) {
+  const int ncb = cdiv(C, FC);
+  const long bytes = (long)nblk * 2 * C * 4;
+  if (nblk < 512 || !(bytes >= (16l << 20) || (ncb <= 8 && bytes >= (4l << 20)))) return 1;
+  int S = std::min(nblk / 256, std::max(1, 1024 / ncb));
+  S = std::min(S, 64);
+  return S < 2 ? 1 : S;
+}
+extern "C" size_t rn_bn_fold_bytes(int nblk, int C) {
+  if (nblk <= 0 || C <= 0) return 0;
+  const int S = fold_splits(nblk, C);
+  if (S == 1) return 0;
+  const int ncb = cdiv(C, FC);
+  return (size_t)fold_header_bytes(ncb) + (size_t)ncb * S * 2 * FC * 8;
 }
 
 // ---- elementwise passes.  A thread owns ONE 16-byte channel chunk (its per-channel coefficients live in registers for
@@ -475,6 +600,21 @@ extern "C" int rn_bn_finalize(const float* partial, int nblk, double count, cons
   return 0;
 }
 
+extern "C" int rn_bn_finalize_split(const float* partial, int nblk, double count, const float* gamma, const float* beta, float* running_mean,
+                                    float* running_var, int64_t* nbt, float* coef, int C, float eps, float momentum, int flags, void* fold, size_t fold_bytes,
+                                    rn_stream s) {
+  RN_CHECK_ARG(gamma && beta && running_mean && running_var && coef && C > 0, "rn_bn_finalize_split: null pointer");
+  RN_CHECK_ARG((flags & RN_F_TRAIN) && partial && nblk > 0 && count > 0, "rn_bn_finalize_split: training mode with partial sums only");
+  const size_t need = rn_bn_fold_bytes(nblk, C);
+  RN_CHECK_ARG(need > 0, "rn_bn_finalize_split: %d rows x %d channels is not split (rn_bn_fold_bytes says 0): call rn_bn_finalize", nblk, C);
+  RN_CHECK_ARG(fold && fold_bytes >= need, "rn_bn_finalize_split: fold buffer of %zu bytes, %zu needed", fold_bytes, need);
+  const int S = fold_splits(nblk, C);
+  hipLaunchKernelGGL(bn_finalize_split_kernel, dim3(cdiv(C, FC) * S), dim3(FC * FL), 0, as_stream(s), partial, nblk, count, gamma, beta, running_mean, running_var,
+                     (long long*)nbt, coef, C, eps, momentum, fold, S);
+  RN_CHECK_LAUNCH("bn_finalize_split");
+  return 0;
+}
+
 extern "C" int rn_bn_apply(const void* x, const float* coef, const void* res, void* out, int dtype, int N, int H, int W, int C, int res_mode,
                            int res_C, int flags, float drop_p, uint32_t site, uint64_t step_seed, rn_stream s) {
   const long M = (long)N * H * W;
@@ -517,6 +657,19 @@ extern "C" int rn_bn_bwd_finalize(const float* partial, int nblk, float* dsum, f
   RN_CHECK_ARG(partial && dsum && dgamma && dbeta && nblk > 0 && C > 0, "rn_bn_bwd_finalize: bad argument");
   hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FC)), dim3(FC * FL), 0, as_stream(s), partial, nblk, dsum, dgamma, dbeta, C, (flags & RN_F_ACCUM) ? 1 : 0);
   RN_CHECK_LAUNCH("bn_bwd_finalize");
+  return 0;
+}
+
+extern "C" int rn_bn_bwd_finalize_split(const float* partial, int nblk, float* dsum, float* dgamma, float* dbeta, int C, int flags, void* fold, size_t fold_bytes,
+                                        rn_stream s) {
+  RN_CHECK_ARG(partial && dsum && dgamma && dbeta && nblk > 0 && C > 0, "rn_bn_bwd_finalize_split: bad argument");
+  const size_t need = rn_bn_fold_bytes(nblk, C);
+  RN_CHECK_ARG(need > 0, "rn_bn_bwd_finalize_split: %d rows x %d channels is not split (rn_bn_fold_bytes says 0): call rn_bn_bwd_finalize", nblk, C);
+  RN_CHECK_ARG(fold && fold_bytes >= need, "rn_bn_bwd_finalize_split: fold buffer of %zu bytes, %zu needed", fold_bytes, need);
+  const int S = fold_splits(nblk, C);
+  hipLaunchKernelGGL(bn_bwd_finalize_split_kernel, dim3(cdiv(C, FC) * S), dim3(FC * FL), 0, as_stream(s), partial, nblk, dsum, dgamma, dbeta, C,
+                     (flags & RN_F_ACCUM) ? 1 : 0, fold, S);
+  RN_CHECK_LAUNCH("bn_bwd_finalize_split");
   return 0;
 }
 

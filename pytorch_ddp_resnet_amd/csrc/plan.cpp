@@ -258,7 +258,10 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
     }
     case RN_OP_BN_STATS:
       return rn_bn_stats(B(0), (float*)B(1), d[2], dt, d[0], d[1], s);
-    case RN_OP_BN_FINALIZE:
+    case RN_OP_BN_FINALIZE:            /* partial gamma beta running_mean running_var nbt coef fold | nblk count C */
+      if (B(7))
+        return rn_bn_finalize_split((const float*)B(0), d[0], (double)d[1], (const float*)B(1), (const float*)B(2), (float*)B(3), (float*)B(4),
+                                    (int64_t*)B(5), (float*)B(6), d[2], o.fp[0], o.fp[1], o.flags, B(7), p->ws_bytes[o.buf[7]], s);
       return rn_bn_finalize((const float*)B(0), d[0], (double)d[1], (const float*)B(1), (const float*)B(2), (float*)B(3), (float*)B(4),
                             (int64_t*)B(5), (float*)B(6), d[2], o.fp[0], o.fp[1], o.flags, s);
     case RN_OP_BN_APPLY:
@@ -276,7 +279,9 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
       return rn_maxpool_bwd(B(0), (const unsigned char*)B(1), B(2), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], s);
     case RN_OP_BN_BWD_REDUCE:
       return rn_bn_bwd_reduce(B(0), B(1), B(2), (const float*)B(3), (float*)B(4), d[2], dt, d[0], d[1], o.flags, o.fp[0], o.fp[1], o.seed, step_seed, s);
-    case RN_OP_BN_BWD_FINALIZE:
+    case RN_OP_BN_BWD_FINALIZE:        /* partial dsum dgamma dbeta fold | nblk C */
+      if (B(4))
+        return rn_bn_bwd_finalize_split((const float*)B(0), d[0], (float*)B(1), (float*)B(2), (float*)B(3), d[1], o.flags, B(4), p->ws_bytes[o.buf[4]], s);
       return rn_bn_bwd_finalize((const float*)B(0), d[0], (float*)B(1), (float*)B(2), (float*)B(3), d[1], o.flags, s);
     case RN_OP_BN_BWD_APPLY:
       return rn_bn_bwd_apply(B(0), B(1), B(2), (const float*)B(3), (const float*)B(4), B(5), B(6), B(7), dt, d[0], d[1], d[2], d[3], d[4], d[5],

@@ -100,6 +100,8 @@ class Engine:
         for i, sl in enumerate(plan.slots):
             if sl.role == 'ws':                     # the main-stream workspace and the side stream's own
                 _lib.check(self.L.rn_plan_set_bytes(self._h, i, max(ws_bytes, 16)))
+            elif sl.role == 'fold':                 # hand-off buffer of a split finalize (zeroed above): the launch checks its size
+                _lib.check(self.L.rn_plan_set_bytes(self._h, i, int(sl.shape[0]) * 4))
         # ---- deferred weight-gradient slab sums: on thin networks every weight gradient is a ~10 us kernel followed by a ~5 us launch that
         # only adds its split-K slabs (165 of them per ResNet-v2-164 step); with slab regions of their own the sums of a whole range of ops
         # go out as one batched launch at the end of the range (plan.cpp).  RN_NO_DEFER_REDUCE=1: off (A/B).

@@ -30,7 +30,7 @@ OP_FIELDS = {
     OP_PACK_W:          ('w w_fwd w_dgrad', 'K RS C', ''),
     OP_CONV_FWD:        ('x w_fwd y res stats bias', 'geom res_mode res_C', ''),
     OP_BN_STATS:        ('x partial', 'M C nblk', ''),
-    OP_BN_FINALIZE:     ('partial gamma beta running_mean running_var nbt coef', 'nblk count C', 'eps momentum'),
+    OP_BN_FINALIZE:     ('partial gamma beta running_mean running_var nbt coef fold', 'nblk count C', 'eps momentum'),
     OP_BN_APPLY:        ('x coef res out', 'N H W C res_mode res_C', 'p'),
     OP_DROPOUT_FWD:     ('x out', 'n_lo n_hi', 'p'),
     OP_MAXPOOL_FWD:     ('x y argmax', 'N H W C k stride pad', ''),
@@ -38,7 +38,7 @@ OP_FIELDS = {
     OP_POOL_FC_BWD:     ('dlogits feat w dx dw db', 'N HW C O', ''),
     OP_MAXPOOL_BWD:     ('dy argmax dx', 'N H W C k stride pad', ''),
     OP_BN_BWD_REDUCE:   ('dout x mask coef partial', 'M C nblk', 'gscale p'),
-    OP_BN_BWD_FINALIZE: ('partial dsum dgamma dbeta', 'nblk C', ''),
+    OP_BN_BWD_FINALIZE: ('partial dsum dgamma dbeta fold', 'nblk C', ''),
     OP_BN_BWD_APPLY:    ('dout x mask coef dsum add dx g_out', 'N H W C add_mode add_C count', 'gscale p'),
     OP_CONV_DGRAD:      ('dy w_dgrad dx res bn_x bn_mask bn_coef bn_partial', 'geom res_mode res_C', 'gscale'),
     OP_CONV_WGRAD:      ('x dy dw ws', 'geom', ''),
@@ -60,7 +60,7 @@ GEOM = 'N H W C P Q K R S stride pad'.split()
 
 @dataclass
 class Slot:
-    """one device buffer of a plan.  role: 'act' (compute dtype NHWC), 'f32', 'i64', 'param', 'buffer', 'grad',
+    """one device buffer of a plan.  role: 'act' (compute dtype NHWC), 'f32', 'fold' (fp32 words of a split finalize's hand-off buffer; its byte size is told to the plan), 'i64', 'param', 'buffer', 'grad',
     'input', 'labels', 'ws'.  key: reference state_dict key for param/buffer/grad slots."""
     name: str
     role: str

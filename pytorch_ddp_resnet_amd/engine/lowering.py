@@ -67,6 +67,19 @@ def conv_stats_rows(g: dict, dgrad: bool = False) -> int:
     return rows
 
 
+def bn_fold_bytes(nblk: int, C: int) -> int:
+    """bytes of the hand-off buffer of a finalize launch whose partial rows are split over workgroups; 0 = not split (= rn_bn_fold_bytes in the
+    library, csrc/bn.hip fold_splits: checked against it by tests/test_host_surface.py, and by the launch itself)."""
+    ncb = (C + 15) // 16
+    nbytes = nblk * 2 * C * 4
+    if nblk < 512 or not (nbytes >= (16 << 20) or (ncb <= 8 and nbytes >= (4 << 20))):
+        return 0
+    S = min(nblk // 256, max(1, 1024 // ncb), 64)
+    if S < 2:
+        return 0
+    return ((ncb * 4 + 63) // 64) * 64 + ncb * S * 2 * 16 * 8
+
+
 def bn_partials(M: int, C: int) -> int:
     """number of row-slabs a statistics pass is split into (one workgroup each)."""
     rows_per = min(256, max(32, M // 512))        # >= 256 workgroups once M >= 8192
@@ -121,6 +134,11 @@ class Lowering:
 
     def f32(self, name, shape):
         return self.slot(name, 'f32', shape, 'f32')
+
+    def fold(self, name, nblk, C):
+        """the hand-off buffer of ONE finalize op over many partial rows (rows split over workgroups, csrc/bn.hip), or -1: the plain kernel"""
+        nbytes = 0 if os.environ.get('RN_NO_FOLD', '0') == '1' else bn_fold_bytes(nblk, C)
+        return self.slot(name, 'fold', ((nbytes + 3) // 4,), 'f32') if nbytes else -1
 
     def param(self, key, shape):
         if key not in self._named:
@@ -249,12 +267,13 @@ class Lowering:
                 # finalizes over the global row count
                 local = self.f32(pre + ':local', (2, C))
                 sg, sb = self.f32(pre + ':local_g', (C,)), self.f32(pre + ':local_b', (C,))      # by-products, unused
-                self.fwd.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=local, dgamma=sg, dbeta=sb), dim=dict(nblk=nblk, C=C), note=pre))
+                self.fwd.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=local, dgamma=sg, dbeta=sb, fold=self.fold(pre + ':lfold', nblk, C)),
+                                   dim=dict(nblk=nblk, C=C), note=pre))
                 self.fwd_hooks.append(Hook(len(self.fwd), 'allreduce_f32', slot=local))
                 part, nblk = local, 1
                 count = x.M * self.world
             self.fwd.append(Op(ir.OP_BN_FINALIZE, buf=dict(partial=part, gamma=gamma, beta=beta, running_mean=rm,
-                                                           running_var=rv, nbt=nbt, coef=coef),
+                                                           running_var=rv, nbt=nbt, coef=coef, fold=self.fold(pre + ':fold', nblk, C)),
                                dim=dict(nblk=nblk, count=count, C=C), fp=dict(eps=BN_EPS, momentum=BN_MOMENTUM),
                                flags=ir.F_TRAIN, note=pre))
         else:
@@ -302,7 +321,7 @@ class Lowering:
                           dim=dict(M=x.M, C=C, nblk=nblk), fp=dict(gscale=gscale, p=p if mslot < 0 else 0.0), flags=fl, seed=site, note=pre))
         dg, db = self.grad(pre + '.weight', (C,)), self.grad(pre + '.bias', (C,))
         count = x.M
-        ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=dsum, dgamma=dg, dbeta=db), dim=dict(nblk=nblk, C=C), note=pre))
+        ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=dsum, dgamma=dg, dbeta=db, fold=self.fold(pre + ':dfold', nblk, C)), dim=dict(nblk=nblk, C=C), note=pre))
         if self.sync:
             # dgamma/dbeta stay local sums (the gradient all-reduce averages them); dsum must be global
             self.bwd_hooks.append(Hook(len(ops), 'allreduce_f32', slot=dsum))
@@ -474,7 +493,7 @@ class Lowering:
                             nblk = bn_partials(dy.M, K)
                             part = self.f32(pre + ':dbpartial', (nblk, 2, K))
                             ops.append(Op(ir.OP_BN_STATS, buf=dict(x=dy.s, partial=part), dim=dict(M=dy.M, C=K, nblk=nblk), note=pre))
-                        ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=s2, dgamma=sq, dbeta=db), dim=dict(nblk=nblk, C=K), note=pre))
+                        ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=s2, dgamma=sq, dbeta=db, fold=self.fold(pre + ':dbfold', nblk, K)), dim=dict(nblk=nblk, C=K), note=pre))
                         self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
                         return None
                     self._back.append(stem_back)
@@ -521,7 +540,7 @@ class Lowering:
                         ops.append(Op(ir.OP_BN_POOL_BWD_REDUCE, buf=dict(dy=dy.s, argmax=am, x=x.s, coef=coef, partial=part, xsel=xsel), dim=dict(d, nblk=nblk, npix=dy.M),
                                       flags=flt, note=pre))
                         dg, db = self.grad(pre + '.weight', (C,)), self.grad(pre + '.bias', (C,))
-                        ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=dsum, dgamma=dg, dbeta=db), dim=dict(nblk=nblk, C=C), note=pre))
+                        ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=dsum, dgamma=dg, dbeta=db, fold=self.fold(pre + ':dfold', nblk, C)), dim=dict(nblk=nblk, C=C), note=pre))
                         self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
                         dx = self.act(pre + ':dx', x.N, x.H, x.W, C)
                         sums, rows = -1, 0

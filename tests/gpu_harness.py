@@ -32,10 +32,19 @@ class PlanBuilder:
         return Plan(self.slots, self.ops, len(self.ops), [], [], [], so, True, meta=dict(ws_need=self.ws_need, fp32=fp32))
 
 
+_last = [None]
+
+
+def last_engine():
+    """the Engine of the latest run_both (a test that launches the same plan again, e.g. to see a hand-off buffer reused)"""
+    return _last[0]
+
+
 def run_both(plan, inputs, fp32, step_seed=0):
     """inputs: {slot name: array}.  returns (hip: {name: float64 array}, ref: {name: float64 array})."""
     T = torch.float32 if fp32 else torch.bfloat16
     eng = Engine(plan, DEV, T)
+    _last[0] = eng
     ref = NumpyPlan(plan)
     for name, arr in inputs.items():
         i = plan.slot_of[name]

@@ -64,6 +64,21 @@ def test_cpu_forward_refuses():
         m(torch.zeros(2, 3, 32, 32))
 
 
+def test_bn_fold_bytes_matches_library():
+    """the lowering sizes the hand-off buffer of a split finalize launch with a Python mirror of the library's rule (rn_bn_fold_bytes)"""
+    import ctypes as C
+    from pytorch_ddp_resnet_amd.engine.lowering import bn_fold_bytes
+    L = _lib.lib()
+    L.rn_bn_fold_bytes.argtypes = [C.c_int, C.c_int]
+    L.rn_bn_fold_bytes.restype = C.c_size_t
+    split = 0
+    for nblk in (1, 98, 392, 511, 512, 1024, 1568, 2048, 6272, 8192, 25088, 100000):
+        for ch in (8, 16, 64, 128, 160, 256, 512, 1000, 1024, 2048, 4096):
+            assert L.rn_bn_fold_bytes(nblk, ch) == bn_fold_bytes(nblk, ch), (nblk, ch)
+            split += bn_fold_bytes(nblk, ch) > 0
+    assert split > 10 and bn_fold_bytes(392, 2048) == 0 and bn_fold_bytes(1024, 160) == 0 and bn_fold_bytes(6272, 512) > 0 and bn_fold_bytes(6272, 128) > 0
+
+
 def test_conv_stats_rows_matches_library():
     """the lowering sizes the fused-epilogue partial buffers with the same formula the library uses."""
     if not os.path.exists(_lib.LIB_PATH):

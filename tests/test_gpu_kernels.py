@@ -203,6 +203,50 @@ def test_bn_forward_backward(C, M_shape, fp32):
             assert h.max_rel(hip[name], ref[name]) < max(tol, 1e-4), name
 
 
+@pytest.mark.parametrize('nblk,C', [(6272, 128), (1100, 2048), (4200, 520)])
+def test_bn_finalize_rows_split_over_workgroups(nblk, C):
+    """the finalize kernels of the ImageNet-sized layers (thousands of partial rows: rn_bn_finalize_split / rn_bn_bwd_finalize_split, ticketed hand-off through a
+    per-op `fold` buffer) against the plain kernels and the float64 interpreter on the same partial rows; run twice: the finisher leaves the tickets at zero."""
+    from pytorch_ddp_resnet_amd.engine.lowering import bn_fold_bytes
+    h = H()
+    nbytes = bn_fold_bytes(nblk, C)
+    assert nbytes > 0, 'this size must take the split form'
+    M = nblk * 128
+    b = h.PlanBuilder()
+    part = b.slot('part', (nblk, 2, C), 'f32'); dpart = b.slot('dpart', (nblk, 2, C), 'f32')
+    gamma = b.slot('gamma', (C,), 'f32'); beta = b.slot('beta', (C,), 'f32')
+    outs = {}
+    for tag in ('s', 'p'):                       # split, plain
+        outs[tag] = dict(coef=b.slot('coef' + tag, (4, C), 'f32'), rm=b.slot('rm' + tag, (C,), 'f32'), rv=b.slot('rv' + tag, (C,), 'f32'), nbt=b.slot('nbt' + tag, (), 'i64'),
+                         dsum=b.slot('dsum' + tag, (2, C), 'f32'), dg=b.slot('dg' + tag, (C,), 'f32'), db=b.slot('db' + tag, (C,), 'f32'))
+        f1 = b.slot('fold1', ((nbytes + 3) // 4,), 'f32', role='fold') if tag == 's' else -1
+        f2 = b.slot('fold2', ((nbytes + 3) // 4,), 'f32', role='fold') if tag == 's' else -1
+        o = outs[tag]
+        b.op(ir.OP_BN_FINALIZE, buf=dict(partial=part, gamma=gamma, beta=beta, running_mean=o['rm'], running_var=o['rv'], nbt=o['nbt'], coef=o['coef'], fold=f1),
+             dim=dict(nblk=nblk, count=M, C=C), fp=dict(eps=1e-5, momentum=0.1), flags=ir.F_TRAIN)
+        b.op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=dpart, dsum=o['dsum'], dgamma=o['dg'], dbeta=o['db'], fold=f2), dim=dict(nblk=nblk, C=C))
+    plan = b.plan(True)
+    # partial rows of a 128-pixel slab each: sums ~ 128 * mean, sums of squares ~ 128 * (var + mean^2), so the variance stays positive
+    rng = np.random.default_rng(7)
+    mean, var = rng.normal(0, 0.5, C), rng.uniform(0.5, 2.0, C)
+    pv = np.empty((nblk, 2, C)); pv[:, 0] = 128 * mean + rng.normal(0, 3, (nblk, C)); pv[:, 1] = 128 * (var + mean ** 2) + rng.normal(0, 3, (nblk, C))
+    inputs = dict(part=pv, dpart=rng.normal(0, 1, (nblk, 2, C)), gamma=fill((C,), 12, 0.25, 1.0), beta=fill((C,), 13, 0.2))
+    for tag in ('s', 'p'):
+        inputs['rm' + tag] = fill((C,), 14, 0.1); inputs['rv' + tag] = fill((C,), 15, 0.25, 1.0)
+    hip, ref = h.run_both(plan, inputs, True)
+    for name in ('coef', 'rm', 'rv', 'dsum', 'dg', 'db'):
+        assert h.max_rel(hip[name + 's'], ref[name + 's']) < 2e-5, name           # float64 interpreter
+        assert h.max_rel(hip[name + 's'], hip[name + 'p']) < 1e-6, name           # same doubles in another order, rounded to fp32 once
+    assert int(hip['nbts']) == 1 and int(hip['nbtp']) == 1
+    assert not hip['fold1'][:C // 16].any() and not hip['fold2'][:C // 16].any()    # the tickets are back at zero
+    eng = h.last_engine()
+    first = {k: eng.tensors[plan.slot_of[k]].clone() for k in ('dsums', 'dgs', 'dbs')}
+    eng.run(0, len(plan.ops), 0)
+    torch.cuda.synchronize()
+    for k, v in first.items():                   # second launch through the same fold buffers: bitwise the same sums
+        assert torch.equal(eng.tensors[plan.slot_of[k]], v), k
+
+
 @pytest.mark.parametrize('fp32', DT)
 def test_bn_backward_recomputed_mask(fp32):
     """RN_F_MASK_RECOMPUTE: the ReLU/dropout mask rebuilt from x, the coefficients and the dropout hash gives exactly
