@@ -101,7 +101,7 @@ typedef struct rn_plan rn_plan;
 const char* rn_last_error(void);
 /* ABI version: bumped with EVERY change of an entry point's signature or meaning; a binding refuses a library of another version (a stale
  * librn_hip.so would otherwise take shifted pointer / integer arguments).  3: round 3 (operand-set flags of rn_conv_kernel_names, workspaces). */
-#define RN_ABI_VERSION 5
+#define RN_ABI_VERSION 6
 int rn_version(void);
 /* kernel-variant switch for A/B measurements (tools/conv_bench.py; bits documented in csrc/conv_igemm.hip); 0 = shipped */
 void rn_set_variant(int v);
@@ -170,6 +170,8 @@ typedef struct rn_conv_epilogue {
   const float* bn_coef;    /* [4][C] of that BatchNorm */
   float gscale;            /* 1/(1-p) of the dropout behind that BatchNorm, else 1 */
   const float* bias;       /* forward only: per-output-channel bias (the stem Conv2d, resnet.py:69-75), or NULL */
+  int mask_from_x;         /* the caller's promise that bn_mask > 0 exactly where bn_x * scale + shift > 0 (a plain BatchNorm + ReLU: no residual added before the
+                              ReLU, no dropout): a kernel may then test bn_x, which it reads for the sums anyway, and leave the mask tensor unread */
 } rn_conv_epilogue;
 int rn_conv_stats_rows(const rn_conv_geom* g, int is_dgrad);
 

@@ -759,6 +759,7 @@ static void fill_ep(IgemmArgs& a, const rn_conv_epilogue* ep, int tile_base) {
   a.stats = ep ? ep->partial : nullptr;
   a.bn_x = ep ? ep->bn_x : nullptr;
   a.bn_mask = ep ? ep->bn_mask : nullptr;
+  a.mask_from_x = (ep && ep->bn_mask && ep->mask_from_x) ? 1 : 0;
   a.bn_coef = ep ? ep->bn_coef : nullptr;
   a.gscale = ep ? ep->gscale : 1.f;
   a.tile_base = tile_base;

@@ -117,13 +117,13 @@ __device__ inline float row_sum16(float x) {
 //                    accumulating into the destination (the three forms the block backward of residual_block.py:67-99, :173-215 lowers to)
 //   EP8_GEN          everything else, flags at run time: strided destination (parity classes of a stride-2 data gradient), pad / subsample
 //                    residuals, bias, sums without a mask (slow path: it spills)
-enum { EP8_PLAIN = 0, EP8_RES = 1, EP8_ACC = 2, EP8_BNB = 4, EP8_GEN = 8, EP8_BIAS = 16, EP8_STRIDED = 32 };   // EP8_STRIDED: destination pixel (2p + oh, 2q + ow): a parity class of a stride-2 data gradient     // EP8_BIAS: plain + per-channel bias (the stem convolution, resnet.py:69-75)
+enum { EP8_PLAIN = 0, EP8_RES = 1, EP8_ACC = 2, EP8_BNB = 4, EP8_GEN = 8, EP8_BIAS = 16, EP8_STRIDED = 32, EP8_MASKX = 64 };   // EP8_MASKX (with EP8_BNB): the ReLU mask is [x * scale + shift > 0] of the x the sums read anyway, not a second tensor   // EP8_STRIDED: destination pixel (2p + oh, 2q + ow): a parity class of a stride-2 data gradient     // EP8_BIAS: plain + per-channel bias (the stem convolution, resnet.py:69-75)
 
 template <typename T, int RT, int MODE>
 __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw, int kw, int lane, float* lds_mean, bool upper, int pair_floats) {
   constexpr int CE = 8;
   constexpr bool GEN = MODE == EP8_GEN, C_BIAS = MODE == EP8_BIAS, C_STRIDED = (MODE & EP8_STRIDED) != 0;
-  constexpr bool C_RES = (MODE & EP8_RES) != 0, C_ACC = (MODE & EP8_ACC) != 0, C_BNB = (MODE & EP8_BNB) != 0;
+  constexpr bool C_RES = (MODE & EP8_RES) != 0, C_ACC = (MODE & EP8_ACC) != 0, C_BNB = (MODE & EP8_BNB) != 0, C_MASKX = (MODE & EP8_MASKX) != 0;
   constexpr int D = MODE == EP8_RES ? 2 : 1;     // pixel tiles of operand loads in flight ahead of the one being processed (registers decide)
   const int l16 = lane & 15, lq = lane >> 4;
   const int kc = kw + 16 * lq;                   // after the transpose this lane owns channels kc .. kc + 15 of its pixel
@@ -131,7 +131,7 @@ __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw
   const bool dense = !C_STRIDED && (!GEN || ((a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME)));
   const bool want_stats = a.stats != nullptr;
   const bool bn_bwd = C_BNB || (GEN && want_stats && a.bn_x != nullptr);
-  const bool has_mask = C_BNB || (GEN && a.bn_mask != nullptr);
+  const bool has_mask = (C_BNB && !C_MASKX) || (GEN && a.bn_mask != nullptr);
   const bool res_same = C_RES || (GEN && a.res.mode == RN_RES_SAME);
   const bool accum = C_ACC || (GEN && a.accum);
   const int pq = a.Pc * a.Qc;
@@ -197,6 +197,8 @@ __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw
     if (bn_bwd) {
       if (l16 < 4) *reinterpret_cast<float4*>(lm + 4 * l16) = *reinterpret_cast<const float4*>(a.bn_coef + 2 * a.Kd + kc + 4 * l16);
       else if (l16 < 8) *reinterpret_cast<float4*>(lm + 64 + 4 * (l16 - 4)) = *reinterpret_cast<const float4*>(a.bn_coef + 3 * a.Kd + kc + 4 * (l16 - 4));
+      else if (C_MASKX && l16 < 12) *reinterpret_cast<float4*>(lm + 128 + 4 * (l16 - 8)) = *reinterpret_cast<const float4*>(a.bn_coef + kc + 4 * (l16 - 8));            // scale
+      else if (C_MASKX) *reinterpret_cast<float4*>(lm + 192 + 4 * (l16 - 12)) = *reinterpret_cast<const float4*>(a.bn_coef + a.Kd + kc + 4 * (l16 - 12));      // shift
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // same wave writes and reads: program order + the wait
     }
     struct Ops { bool ok; size_t off; int n, hd, wd; Chunk<T> cr[2], co[2], cx[2], cm[2]; };
@@ -265,12 +267,19 @@ __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw
             for (int e4 = 0; e4 < 16; e4 += 4) {
               const float4 mu = *reinterpret_cast<const float4*>(lm + e4);
               const float mean[4] = {mu.x, mu.y, mu.z, mu.w};
+              float sc4[4] = {0.f, 0.f, 0.f, 0.f}, sh4[4] = {0.f, 0.f, 0.f, 0.f};
+              if (C_MASKX) {
+                const float4 a4 = *reinterpret_cast<const float4*>(lm + 128 + e4), b4 = *reinterpret_cast<const float4*>(lm + 192 + e4);
+                sc4[0] = a4.x; sc4[1] = a4.y; sc4[2] = a4.z; sc4[3] = a4.w; sh4[0] = b4.x; sh4[1] = b4.y; sh4[2] = b4.z; sh4[3] = b4.w;
+              }
 #pragma unroll
               for (int u = 0; u < 4; ++u) {
                 const int e = e4 + u;
                 float g = Elem<T>::to_f(st[e / CE].e[e % CE]) * a.gscale;
+                const float xv = Elem<T>::to_f(o.cx[e / CE].e[e % CE]);
                 if (has_mask && !(Elem<T>::to_f(o.cm[e / CE].e[e % CE]) > 0.f)) g = 0.f;
-                s0[e] += g; s1[e] += g * (Elem<T>::to_f(o.cx[e / CE].e[e % CE]) - mean[u]);
+                if (C_MASKX && !(fmaf(xv, sc4[u], sh4[u]) > 0.f)) g = 0.f;      // the test of bn_bwd's recomputed mask (bn.hip use_mask == 2)
+                s0[e] += g; s1[e] += g * (xv - mean[u]);
               }
             }
           }
@@ -328,13 +337,13 @@ __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw
 __host__ __device__ inline int ep8_mode(const IgemmArgs& a) {
   const bool bnb = a.stats != nullptr && a.bn_x != nullptr && a.bn_mask != nullptr;
   if (a.ds == 2 && a.res.mode == RN_RES_NONE && !a.bias && bnb)        // a parity class of a stride-2 data gradient with the BatchNorm-backward sums
-    return EP8_BNB | EP8_STRIDED | (a.accum ? EP8_ACC : 0);
+    return EP8_BNB | EP8_STRIDED | (a.accum ? EP8_ACC : (a.mask_from_x ? EP8_MASKX : 0));
   const bool dense = (a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME) && !a.bias;
   if (!dense) return EP8_GEN;
   const bool res = a.res.mode == RN_RES_SAME, acc = a.accum != 0;
   if (a.stats != nullptr && a.bn_x != nullptr) {
     if (!a.bn_mask || (res && acc)) return EP8_GEN;
-    return EP8_BNB | (res ? EP8_RES : 0) | (acc ? EP8_ACC : 0);
+    return EP8_BNB | (res ? EP8_RES : 0) | (acc ? EP8_ACC : 0) | (!res && !acc && a.mask_from_x ? EP8_MASKX : 0);
   }
   if (acc) return EP8_GEN;
   return res ? EP8_RES : EP8_PLAIN;
@@ -354,7 +363,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
   constexpr int STG = 4096;                                 // uint4 per stage: 64 KiB (A0 | A1 | B0 | B1), power of two: the stage toggles by XOR
   constexpr int A_H = 1024, B_0 = 2048, B_H = BN * 4;       // uint4 offsets: second A half, B, second B half
   static_assert(sizeof(T) == ES && (BN == 256 || BN == 128) && CT == 4 && B_0 + 2 * B_H <= STG, "tile");
-  __shared__ uint4 smem[2 * STG + TAP_INTS / 4 + 8 * 32 + 1];     // stages | tap tables | 128 floats per wave (epilogue8) | one ticket word
+  __shared__ uint4 smem[2 * STG + TAP_INTS / 4 + 8 * 64 + 1];     // stages | tap tables | 256 floats per wave (epilogue8) | one ticket word
   int* taps = reinterpret_cast<int*>(&smem[2 * STG]);
 
   // (no blanket preload of the kernel arguments: this kernel is persistent and its epilogues read many of them -- held in SGPRs across the whole
@@ -372,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
   const v4i32 rb_desc = make_desc(a.wt, (size_t)a.Kd * a.wrs * a.Cs * ES);
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);
   const int nk = a.nk;
-  float* lds_mean = reinterpret_cast<float*>(&smem[2 * STG + TAP_INTS / 4 + wave * 32]);     // 128 floats per wave (epilogue8)
+  float* lds_mean = reinterpret_cast<float*>(&smem[2 * STG + TAP_INTS / 4 + wave * 64]);     // 256 floats per wave (epilogue8: mean, 1 / std, scale, shift of the lane rows' channels)
   // the launch's epilogue specialisation (wave-uniform, from the kernel arguments)
 
   fill_tap_tables<ES>(a, taps);
@@ -652,7 +661,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains, then the workgroup meets, then ONE lane releases and signals
         __syncthreads();
         int* cnt = reinterpret_cast<int*>(a.w8_ws) + pt_sk;
-        volatile int* flagw = reinterpret_cast<volatile int*>(&smem[2 * STG + TAP_INTS / 4 + 8 * 32]);
+        volatile int* flagw = reinterpret_cast<volatile int*>(&smem[2 * STG + TAP_INTS / 4 + 8 * 64]);
         if (tid == 0) {
           *flagw = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -688,7 +697,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
         stores_behind = pm0 + BM <= a.M;                     // a whole tile: every lane stores its 2 x RT chunks of the tile, whatever else the epilogue does
         const int mw = pm0 + wm * WTM, kw = pn0 + wn * WTN;
         // (the epilogue specialisation is a kernel template parameter: one copy per kernel; 64-row waves pair up for the statistics row)
-        epilogue8<T, RT, EPM>(a, acc, mw, kw, lane, lds_mean, RT == 4 && (wm & 1), WN * 128);
+        epilogue8<T, RT, EPM>(a, acc, mw, kw, lane, lds_mean, RT == 4 && (wm & 1), WN * 256);
       }
     }
     stamp(stp, 3);
@@ -757,7 +766,7 @@ template <typename T, int BN> int launch8(IgemmArgs& a, hipStream_t s) {
   { const unsigned nnt = (unsigned)(a.Kd / BN); a.w8_magic_nnt = nnt <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / nnt); }
   static const char* const EPN[] = {"plain", "res", "?", "?", "bnb", "bnb+res", "bnb+acc", "?", "gen"};
   const int epm = ep8_mode(a);
-  rn_note_kernel("igemm8<256x%d:%s%s>", BN, EPN[epm & 15], (epm & EP8_STRIDED) ? "/s2" : "");
+  rn_note_kernel("igemm8<256x%d:%s%s%s>", BN, EPN[epm & 15], (epm & EP8_MASKX) ? "/xmask" : "", (epm & EP8_STRIDED) ? "/s2" : "");
   if (rn_dry_run()) return 0;
   const int ntiles = cdiv(a.M, 256) * (a.Kd / BN);
   // stream-K (tiles cut into K-tile unit ranges, cut tiles summed through the workspace) only where whole tiles cannot occupy the chip: grids of at most
@@ -782,6 +791,8 @@ template <typename T, int BN> int launch8(IgemmArgs& a, hipStream_t s) {
     case EP8_PLAIN: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_PLAIN>), dim3(grid), dim3(512), 0, s, a); break;
     case EP8_RES: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_RES>), dim3(grid), dim3(512), 0, s, a); break;
     case EP8_BNB: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_BNB | EP8_MASKX: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB | EP8_MASKX>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_BNB | EP8_MASKX | EP8_STRIDED: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB | EP8_MASKX | EP8_STRIDED>), dim3(grid), dim3(512), 0, s, a); break;
     case EP8_BNB | EP8_RES: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB | EP8_RES>), dim3(grid), dim3(512), 0, s, a); break;
     case EP8_BNB | EP8_ACC: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB | EP8_ACC>), dim3(grid), dim3(512), 0, s, a); break;
     case EP8_BNB | EP8_STRIDED: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB | EP8_STRIDED>), dim3(grid), dim3(512), 0, s, a); break;

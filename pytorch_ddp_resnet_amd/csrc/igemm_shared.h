@@ -31,6 +31,7 @@ struct IgemmArgs {
   float* stats;            // forward: (sum y, sum y^2) of the stored output
   const void* bn_x;        // dgrad: (sum g, sum g*xhat), g = dx * gscale * [mask > 0], xhat = (bn_x - mean) * invstd
   const void* bn_mask;
+  int mask_from_x;         // rn_conv_epilogue.mask_from_x: bn_mask equals [bn_x * scale + shift > 0], a kernel may compute it instead of reading it
   const float* bn_coef;
   const float* bias;       // per-output-channel bias added in the epilogue (stem convolution), or NULL
   float gscale;

@@ -48,9 +48,10 @@ extern "C" int rn_conv_kernel_names(int pass, int dtype, const rn_conv_geom* g, 
   static float dummy[8];
   void* p = dummy;                              // never dereferenced: the launchers return before launching
   // fused_epilogue is a set of flags naming the launch's operand set (the eight-phase kernels are specialised per set): 1 = fused BatchNorm sums
-  // (forward: statistics of the output; data gradient: the backward sums over x and the mask), 2 = identity residual, 4 = accumulate into dx, 8 = per-channel bias (forward: the stem)
+  // (forward: statistics of the output; data gradient: the backward sums over x and the mask), 2 = identity residual, 4 = accumulate into dx, 8 = per-channel bias (forward: the stem), 16 = mask_from_x
   rn_conv_epilogue ep{(float*)p, nullptr, nullptr, nullptr, 1.f, nullptr};
   const bool fused = (fused_epilogue & 1) != 0, res = (fused_epilogue & 2) != 0, acc = (fused_epilogue & 4) != 0, bias = (fused_epilogue & 8) != 0;
+  ep.mask_from_x = (fused_epilogue & 16) ? 1 : 0;       // 16 = the data gradient's mask may be computed from bn_x (rn_conv_epilogue.mask_from_x)
   int e;
   if (pass == 0) {
     if (bias) ep.bias = (const float*)p;
@@ -288,7 +289,7 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
                              o.flags, o.fp[0], (double)d[6], o.fp[1], o.seed, step_seed, s);
     case RN_OP_CONV_DGRAD: {
       rn_conv_geom g = geom_of(o);
-      rn_conv_epilogue ep{(float*)B(7), B(4), B(5), (const float*)B(6), o.fp[0], nullptr};
+      rn_conv_epilogue ep{(float*)B(7), B(4), B(5), (const float*)B(6), o.fp[0], nullptr, (o.flags & RN_F_MASK_RECOMPUTE) ? 1 : 0};
       return rn_conv_dgrad(B(0), B(1), B(2), B(3), d[11], d[12], o.flags & ~RN_F_RELU, dt, &g, o.buf[7] >= 0 ? &ep : nullptr, s);
     }
     case RN_OP_CONV_WGRAD: {

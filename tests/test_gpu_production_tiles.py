@@ -42,10 +42,11 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
-def run_conv_case(g, dtype, variant=0, expect_same_names=True, fwd_res=True, dgrad_merge='none'):
+def run_conv_case(g, dtype, variant=0, expect_same_names=True, fwd_res=True, dgrad_merge='none', xmask=False):
     """one convolution layer: pack -> forward(+residual, +stats) -> dgrad(+BN-backward sums) -> wgrad, HIP vs torch-CPU.
     fwd_res: the forward adds an identity residual; dgrad_merge: 'none' | 'res' (dx = conv^T(dy) + shortcut gradient) | 'acc' (dx += conv^T(dy)) --
-    the operand sets the block backward of the reference lowers to (the eight-phase kernels are specialised per set)."""
+    the operand sets the block backward of the reference lowers to (the eight-phase kernels are specialised per set).  xmask: the mask fed is exactly
+    [bn_x * scale + shift > 0] and the op says so (F_MASK_RECOMPUTE -> rn_conv_epilogue.mask_from_x): a kernel may test bn_x instead of reading it."""
     import gpu_harness as h
     from pytorch_ddp_resnet_amd.engine.executor import Engine
     L = _lib.lib()
@@ -67,7 +68,7 @@ def run_conv_case(g, dtype, variant=0, expect_same_names=True, fwd_res=True, dgr
     dres = b.slot('dres', (N, Hh, W, C))
     b.op(ir.OP_CONV_DGRAD, buf=dict(dy=dy, w_dgrad=wd, dx=dx, res=dres if dgrad_merge == 'res' else -1, bn_x=bx, bn_mask=bm, bn_coef=coef, bn_partial=dp),
          dim=dict(gm, res_mode=ir.RES_SAME if dgrad_merge == 'res' else 0, res_C=C if dgrad_merge == 'res' else 0), fp=dict(gscale=1 / 0.7),
-         flags=ir.F_ACCUM if dgrad_merge == 'acc' else 0)
+         flags=(ir.F_ACCUM if dgrad_merge == 'acc' else 0) | (ir.F_MASK_RECOMPUTE if xmask else 0))
     b.op(ir.OP_CONV_WGRAD, buf=dict(x=x, dy=dy, dw=dw, ws=ws), dim=dict(gm))
     b.ws_need.append(('wgrad', gm))
     plan = b.plan(fp32)
@@ -83,6 +84,12 @@ def run_conv_case(g, dtype, variant=0, expect_same_names=True, fwd_res=True, dgr
     bmv = _round(fill((N, Hh, W, C), 6), dtype)
     dresv = _round(fill((N, Hh, W, C), 7), dtype)
     cf = torch.from_numpy(np.stack([fill((C,), 71, 0.2, 1.0), fill((C,), 72, 0.1), fill((C,), 73, 0.3), fill((C,), 74, 0.2, 1.0)]))
+    if xmask:
+        # the sign of the kernel's fp32 fma(x, scale, shift) is the sign of the exact value (no underflow at these magnitudes), which float64 holds exactly;
+        # scale of mixed sign so both comparison directions occur
+        cf[0] = cf[0] * torch.where(torch.arange(C) % 3 == 0, -1.0, 1.0).to(cf.dtype)
+        cf32 = cf.float()
+        bmv = ((bxv.double() * cf32[0].double() + cf32[1].double()) > 0).to(bxv.dtype)
 
     eng = Engine(plan, h.DEV, TORCH_DT[dtype])
     feed = dict(x=xv, w=wv, dy=dyv, res=resv, bx=bxv, bm=bmv, coef=cf, dres=dresv)
@@ -101,7 +108,7 @@ def run_conv_case(g, dtype, variant=0, expect_same_names=True, fwd_res=True, dgr
         L.rn_kernel_log(0)
         if expect_same_names:
             want = []
-            flags = [1 | (2 if fwd_res else 0), 1 | {'none': 0, 'res': 2, 'acc': 4}[dgrad_merge], 0]
+            flags = [1 | (2 if fwd_res else 0), 1 | {'none': 0, 'res': 2, 'acc': 4}[dgrad_merge] | (16 if xmask else 0), 0]
             for ps in range(3):
                 want += _lib.conv_kernel_names(ps, RN_DT[dtype], gm, fused_epilogue=flags[ps])
             assert ran == want, (ran, want)
@@ -307,17 +314,29 @@ def test_igemm8_epilogue_specialisations(g, merge, dtype):
     assert ran[1] == {'none': 'igemm8<256x256:bnb>', 'res': 'igemm8<256x256:bnb+res>', 'acc': 'igemm8<256x256:bnb+acc>'}[merge], ran
 
 
-@pytest.mark.parametrize('ops,dtype', [((True, 'none'), 'fp16'), ((True, 'none'), 'bf16'), ((False, 'res'), 'fp16'), ((False, 'acc'), 'fp16')])
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('g,name', [((2, 16, 16, 256, 256, 3, 1, 1), '256x256:bnb/xmask'), ((3, 14, 14, 512, 256, 1, 1, 0), '256x256:bnb/xmask'),
+                                    ((3, 16, 16, 128, 128, 3, 1, 1), '256x128:bnb/xmask'), ((2, 28, 28, 256, 256, 3, 2, 1), '256x256:bnb/xmask/s2'),
+                                    ((5, 15, 15, 256, 128, 3, 1, 1), '256x256:bnb/xmask')])
+def test_igemm8_mask_from_x(g, name, dtype):
+    """the BatchNorm-backward sums with the ReLU mask computed from bn_x (a plain BatchNorm + ReLU in front of the convolution: the lowering promises it
+    with F_MASK_RECOMPUTE): the epilogue reads x only; scales of both signs; dense and strided (parity class) destinations, both column tiles, a row tail."""
+    ran = run_conv_case(g, dtype, variant=IGEMM8, fwd_res=False, dgrad_merge='none', xmask=True)
+    assert all(n == f'igemm8<{name}>' for n in ran[1:-1] if n.startswith('igemm8')) and any(n == f'igemm8<{name}>' for n in ran), ran
+
+
+@pytest.mark.parametrize('ops,dtype', [((True, 'none'), 'fp16'), ((True, 'none'), 'bf16'), ((False, 'res'), 'fp16'), ((False, 'acc'), 'fp16'), ((False, 'none', True), 'fp16')])
 @pytest.mark.parametrize('g', IGEMM8_GEOMS)
 def test_igemm8_production_operand_sets(g, ops, dtype):
     """the eight-phase kernels at production grids (>= 160 persistent tiles, the shipped selection rule), with every operand set the full-batch
     WRN-50-2 configuration launches them with: forward +- identity residual; data gradient with the BatchNorm-backward sums alone, with the
     shortcut gradient as residual, accumulating into dx.  The kernel that ran is asserted against the launchers' own choice."""
-    ran = run_conv_case(g, dtype, fwd_res=ops[0], dgrad_merge=ops[1])
+    xm = len(ops) > 2 and ops[2]
+    ran = run_conv_case(g, dtype, fwd_res=ops[0], dgrad_merge=ops[1], xmask=xm)
     bn_f, bn_d = (256 if g[4] % 256 == 0 else 128), (256 if g[3] % 256 == 0 else 128)
     assert ran[0] == f'igemm8<256x{bn_f}:' + ('res>' if ops[0] else 'plain>'), ran
     if g[6] == 1:
-        assert ran[1] == f'igemm8<256x{bn_d}:' + {'none': 'bnb>', 'res': 'bnb+res>', 'acc': 'bnb+acc>'}[ops[1]], ran
+        assert ran[1] == f'igemm8<256x{bn_d}:' + {'none': 'bnb/xmask>' if xm else 'bnb>', 'res': 'bnb+res>', 'acc': 'bnb+acc>'}[ops[1]], ran
 
 
 WGRAD8 = 1 << 30                     # rn_set_variant: the eight-phase weight-gradient kernel at any size (its rule wants >= 8 K tiles per workgroup)

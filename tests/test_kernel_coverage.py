@@ -43,14 +43,14 @@ def _tested_names(dtype):
     for g in IGEMM8_GEOMS:                     # test_igemm8_production_operand_sets: every operand set
         if dtype == ir.RN_F32:
             break
-        for p, fls in ((0, (1, 3)), (1, (1, 3, 5)), (2, (0,))):
+        for p, fls in ((0, (1, 3)), (1, (1, 3, 5, 17)), (2, (0,))):            # 17: sums with the mask computed from x (test_igemm8_mask_from_x)
             for fl in fls:
                 names.update(_lib.conv_kernel_names(p, dtype, geom(*g), fused_epilogue=fl))
     return names
 
 
 def _op_flags(op):
-    """the operand set of a convolution op as rn_conv_kernel_names takes it: 1 fused sums, 2 identity residual, 4 accumulate"""
+    """the operand set of a convolution op as rn_conv_kernel_names takes it: 1 fused sums, 2 identity residual, 4 accumulate, 8 bias, 16 mask from x"""
     b = op.buf
     fl = 1 if (b.get('stats', -1) >= 0 or b.get('bn_x', -1) >= 0) else 0
     if b.get('res', -1) >= 0 and op.dim.get('res_mode', 0) == ir.RES_SAME:
@@ -59,6 +59,8 @@ def _op_flags(op):
         fl |= 4
     if b.get('bias', -1) >= 0:
         fl |= 8
+    if op.kind == ir.OP_CONV_DGRAD and (op.flags & ir.F_MASK_RECOMPUTE):
+        fl |= 16
     return fl
 
 
