@@ -194,6 +194,8 @@ __device__ inline void igemm_epilogue(const IgemmArgs& a, AccT& acc, int m0, int
   const bool res_same = a.res.mode == RN_RES_SAME;
   // the common forward case gets its own row loop: no residual / accumulate / BatchNorm-backward operands, no bias
   const bool simple = dense && a.res.mode == RN_RES_NONE && !a.accum && !bn_bwd && !a.bias;
+  // (rn_conv_epilogue.mask_from_x is not used here: computing the mask from x in this epilogue was built and measured -- ResNet-v2-164 10.03 -> 10.19 ms/step,
+  // three same-box pairs: the mask chunk's load flies beside x's, the fma + compare per element and 16 more live registers do not)
   float s0[NGRP][CE], s1[NGRP][CE], mean[CE], invstd[CE], bias[CE];
 #pragma unroll
   for (int e = 0; e < CE; ++e) {

@@ -242,9 +242,10 @@ class Lowering:
             mask = fuse_bn['mask']
             buf.update(bn_x=fuse_bn['x'].s, bn_mask=mask.s if mask is not None else -1, bn_coef=fuse_bn['coef'], bn_partial=part)
             fp['gscale'] = 1.0 / (1.0 - fuse_bn['p']) if fuse_bn['p'] > 0 else 1.0
-            # a plain BatchNorm + ReLU (nothing added before the ReLU, no dropout): the mask is [x * scale + shift > 0] of the x the sums read anyway --
+            # a plain BatchNorm + ReLU (nothing added before the ReLU, no dropout -- bn_apply's own record, the one bn_bwd recomputes its mask by): the mask is
+            # [x * scale + shift > 0] of the x the sums read anyway --
             # the kernel may leave the mask tensor unread (rn_conv_epilogue.mask_from_x; a third of a data-gradient epilogue's reads)
-            if mask is not None and fuse_bn.get('pure') and fuse_bn['p'] == 0 and os.environ.get('RN_NO_XMASK', '0') != '1':
+            if mask is not None and self._site_of.get(mask.s, (0, 0, False))[2] and fuse_bn['p'] == 0 and os.environ.get('RN_NO_XMASK', '0') != '1':
                 flags |= ir.F_MASK_RECOMPUTE
             self._dpart_of[dx.s] = (part, rows)
         ops.append(Op(ir.OP_CONV_DGRAD, buf=buf, dim=dict(g, res_mode=res_mode, res_C=res.C if res else 0), fp=fp, flags=flags, note=key))
@@ -371,7 +372,7 @@ class Lowering:
                 for r in reversed(recs):
                     j = r['j']
                     da = self.conv_bwd(ops, r['a'], gcur, f'{bp}._conv{j}.weight', r['g'], r['wd'], f'{bp}.da{j}',
-                                       fuse_bn=dict(x=r['x'], mask=r['a'], coef=r['coef'], p=r['p'], pure=True))
+                                       fuse_bn=dict(x=r['x'], mask=r['a'], coef=r['coef'], p=r['p']))
                     add, mode = None, ir.RES_NONE
                     if j == 1 and not proj:
                         add, mode = dh, (ir.RES_SAME if not down else ir.RES_UP2)
@@ -422,7 +423,7 @@ class Lowering:
                     if j > 1:
                         prev = recs[j - 2]          # the BN+ReLU(+dropout) whose output is this conv's input
                         gcur = self.conv_bwd(ops, r['x'], dy, f'{bp}._conv{j}.weight', r['g'], r['wd'], f'{bp}.da{j - 1}',
-                                             fuse_bn=dict(x=prev['y'], mask=prev['out'], coef=prev['coef'], p=prev['p'], pure=True))
+                                             fuse_bn=dict(x=prev['y'], mask=prev['out'], coef=prev['coef'], p=prev['p']))
                     else:
                         plain = p_in == 0.0
                         res, mode = None, ir.RES_NONE
@@ -562,7 +563,7 @@ class Lowering:
                     continue
                 coef = self.bn_coef(cur, pre)
                 out, _ = self.bn_apply(cur, coef, pre + ':out', relu=relu)
-                self._tail_bn[out.s] = dict(x=cur, mask=out if relu else None, coef=coef, p=0.0, pure=True)
+                self._tail_bn[out.s] = dict(x=cur, mask=out if relu else None, coef=coef, p=0.0)
 
                 def norm_back(dout: T, ops, x=cur, out=out, coef=coef, pre=pre, relu=relu):
                     dx, _ = self.bn_bwd(ops, dout, x, out if relu else None, coef, pre, pre + ':dx')

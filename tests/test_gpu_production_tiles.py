@@ -150,6 +150,17 @@ def test_production_tiles(g, dtype):
     run_conv_case(g, dtype)
 
 
+@pytest.mark.parametrize('dtype', DTYPES)
+@pytest.mark.parametrize('g', [(3, 8, 8, 160, 160, 3, 1, 1), (2, 8, 8, 64, 128, 1, 1, 0), (2, 8, 8, 32, 64, 3, 2, 1), (4, 16, 16, 16, 32, 3, 1, 1), (128, 32, 32, 16, 64, 1, 1, 0),
+                               (128, 32, 32, 64, 16, 1, 1, 0), (128, 16, 16, 64, 64, 3, 2, 1)])
+def test_mask_from_x_on_the_128_row_kernels(g, dtype):
+    """the same promise (rn_conv_epilogue.mask_from_x) reaches the kernels of the CIFAR nets too (the lowering sets it whatever kernel will run): they keep
+    reading the mask tensor -- computing it there was built and measured slower -- and the flagged launch must give the same sums:
+    every tile family (thin ResNet-v2-164 / ResNet-20 shapes at full batch, a stride-2 layer's parity classes), scales of both signs."""
+    ran = run_conv_case(g, dtype, xmask=True, expect_same_names=False)
+    assert not any(n.startswith('igemm8') for n in ran), ran
+
+
 SMALL = [(3, 8, 8, 160, 160, 3, 1, 1), (2, 8, 8, 64, 128, 1, 1, 0), (1, 16, 16, 96, 96, 3, 1, 1), (2, 8, 8, 32, 64, 3, 2, 1), (4, 16, 16, 16, 32, 3, 1, 1)]
 
 
