@@ -40,6 +40,8 @@ def conv_flops(op):
     """ALGORITHMIC flops of a convolution launch (2 per MAC of the reference's layer): the stem runs on the MFMA path with its 3 image
     channels zero-padded to one 16-byte chunk (C = 4 / 8 in the op) -- the padding is not work."""
     d = op.dim
+    if d.get('alg_macs'):                                # the space-to-depth stem: the lowering records the reference layer's MACs per output (7 * 7 * 3)
+        return 2.0 * d['N'] * d['P'] * d['Q'] * d['K'] * d['alg_macs']
     c = 3 if d['C'] <= 8 else d['C']
     return 2.0 * d['N'] * d['P'] * d['Q'] * d['K'] * d['R'] * d['S'] * c
 
@@ -52,7 +54,8 @@ def conv_bytes(op, ir, elem):
     if op.kind == ir.OP_CONV_FWD:
         return elem * (x_ + y_ + w_ + (y_ if b.get('res', -1) >= 0 else 0))
     if op.kind == ir.OP_CONV_DGRAD:
-        extra = sum(x_ for k in ('res', 'bn_x', 'bn_mask') if b.get(k, -1) >= 0) + (x_ if op.flags & ir.F_ACCUM else 0)
+        # (a mask the lowering marks as computable from bn_x -- F_MASK_RECOMPUTE -- is no operand: the eight-phase kernels do not read it)
+        extra = sum(x_ for k in ('res', 'bn_x', 'bn_mask') if b.get(k, -1) >= 0 and not (k == 'bn_mask' and op.flags & ir.F_MASK_RECOMPUTE)) + (x_ if op.flags & ir.F_ACCUM else 0)
         return elem * (y_ + x_ + w_ + extra)
     return elem * (x_ + y_) + 4 * w_                     # wgrad: fp32 dw
 
@@ -379,6 +382,9 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
                 geo = (f"N{d['N']} {d['H']}x{d['W']} C{d['C']}->K{d['K']} k{d['R']} s{d['stride']}" if 'R' in d else
                        ' '.join(f'{k}{v}' for k, v in d.items() if k in ('N', 'H', 'W', 'C', 'M')))
                 extra = f" {conv_flops(op) / (t * 1e-3) / 1e12:7.1f} TFLOP/s" if 'R' in d and t > 0 else ''
+                if 'R' in d and t > 0:                  # the launch's own roofline: max(FLOPs / MFMA peak, algorithmic bytes / HBM peak), and the time over it
+                    bound = max(conv_flops(op) / (PEAK_TFLOPS[dtype] * 1e12), conv_bytes(op, ir, elem) / (HBM_PEAK_GBS * 1e9)) * 1e6
+                    extra += f"  bound {bound:6.1f} us (+{t * 1e3 - bound:6.1f})"
                 print(f'    {ir.OP_NAMES[op.kind]:18s} {t * 1e3:9.1f} us  {geo}{extra}  [{op.note}]', file=sys.stderr)
     if world > 1:
         torch.distributed.barrier()

@@ -64,7 +64,10 @@ enum {
   RN_OP_UNPACK_STEM_DW = 24,/* stem weight gradient [K][RS][CP] fp32 -> [K][RS][C] (drops the padding)                          */
   RN_OP_BN_POOL_FWD = 25,        /* y, argmax = maxpool([relu](x * scale + shift)): BN_APPLY + MAXPOOL_FWD of a top-level "n a mp" in one pass */
   RN_OP_BN_POOL_BWD_REDUCE = 26, /* BN_BWD_REDUCE over g = [bn(x) > 0] * maxpool_bwd(dy, argmax), without materialising it */
-  RN_OP_BN_POOL_BWD_APPLY = 27   /* BN_BWD_APPLY over the same g */
+  RN_OP_BN_POOL_BWD_APPLY = 27,  /* BN_BWD_APPLY over the same g */
+  RN_OP_IMG_TO_S2D = 28,         /* NCHW fp32 image -> space-to-depth NHWC [N][H/2+3][W/2+3][16] (the 7x7 / stride-2 stem as a 4x4 VALID convolution)  */
+  RN_OP_PACK_STEM_W_S2D = 29,    /* stem weights [K][7][7][C] fp32 -> [K][4][4][16] compute dtype                                                       */
+  RN_OP_UNPACK_STEM_DW_S2D = 30  /* stem weight gradient [K][4][4][16] fp32 -> [K][7][7][C]                                                             */
 };
 
 /* flags */
@@ -101,7 +104,7 @@ typedef struct rn_plan rn_plan;
 const char* rn_last_error(void);
 /* ABI version: bumped with EVERY change of an entry point's signature or meaning; a binding refuses a library of another version (a stale
  * librn_hip.so would otherwise take shifted pointer / integer arguments).  3: round 3 (operand-set flags of rn_conv_kernel_names, workspaces). */
-#define RN_ABI_VERSION 6
+#define RN_ABI_VERSION 7
 int rn_version(void);
 /* kernel-variant switch for A/B measurements (tools/conv_bench.py; bits documented in csrc/conv_igemm.hip); 0 = shipped */
 void rn_set_variant(int v);
@@ -191,6 +194,14 @@ size_t rn_stem_wgrad_ws_bytes(const rn_conv_geom* g);
 int rn_img_to_nhwc(const float* x_nchw, void* out, int dtype, int N, int C, int H, int W, int CP, rn_stream s);
 int rn_pack_stem_w(const float* w_krsc, void* w_padded, int dtype, int K, int RS, int C, int CP, rn_stream s);
 int rn_unpack_stem_dw(const float* dw_padded, float* dw_krsc, int K, int RS, int C, int CP, int accumulate, rn_stream s);
+/* The ImageNet stem Conv2d(C <= 4 -> K, 7 x 7, stride 2, padding 3) (resnet.py:69-75 under "c3,K,7,2,3") as a 4 x 4 / stride-1 / VALID convolution over a
+ * space-to-depth image: s2d pixel (i, j) = image pixels (2i + dy, 2j + dx) as 16 channels ((dy, dx, c of 4), zero-filled), stored with 2 zero s2d pixels before
+ * and 1 after in both directions: out [N][H/2 + 3][W/2 + 3][16] (H, W even).  Filter tap (r', s'), channel (dy, dx, c) = the 7 x 7 weight at
+ * (2r' + dy - 1, 2s' + dx - 1), zero outside: w_s2d [K][4][4][16].  rn_conv_fwd / rn_conv_wgrad on that geometry (C = 16, R = S = 4, stride 1, pad 0) give the
+ * stem's output and a [K][4][4][16] weight gradient, which rn_unpack_stem_dw_s2d maps back.  4 K tiles of 64 instead of 7, and contiguous 128-byte rows. */
+int rn_img_to_s2d(const float* x_nchw, void* out, int dtype, int N, int C, int H, int W, rn_stream s);
+int rn_pack_stem_w_s2d(const float* w_k77c, void* w_s2d, int dtype, int K, int C, rn_stream s);
+int rn_unpack_stem_dw_s2d(const float* dw_s2d, float* dw_k77c, int K, int C, int accumulate, rn_stream s);
 
 /* fp32 KRSC master -> w_fwd [K][R*S][C] and w_dgrad [C][R*S][K] in dtype (either may be NULL) */
 int rn_pack_weights(const float* w_krsc, void* w_fwd, void* w_dgrad, int dtype, int K, int RS, int C, rn_stream s);

@@ -336,6 +336,7 @@ __device__ inline void epilogue8(const IgemmArgs& a, f32x4 (&acc)[RT][4], int mw
 // the launch's epilogue specialisation (host and device agree: the launcher's rule reads it too)
 __host__ __device__ inline int ep8_mode(const IgemmArgs& a) {
   const bool bnb = a.stats != nullptr && a.bn_x != nullptr && a.bn_mask != nullptr;
+  if (a.bias && a.ds == 1 && a.res.mode == RN_RES_NONE && !a.accum && !a.bn_x) return EP8_BIAS;      // a biased forward convolution (+ statistics): the stems
   if (a.ds == 2 && a.res.mode == RN_RES_NONE && !a.bias && bnb)        // a parity class of a stride-2 data gradient with the BatchNorm-backward sums
     return EP8_BNB | EP8_STRIDED | (a.accum ? EP8_ACC : (a.mask_from_x ? EP8_MASKX : 0));
   const bool dense = (a.ds == 1) && (a.res.mode == RN_RES_NONE || a.res.mode == RN_RES_SAME) && !a.bias;
@@ -377,7 +378,8 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nmt = (a.M + BM - 1) / BM, nnt = a.Kd / BN, ntiles = nmt * nnt;
   const int pq = a.Pc * a.Qc;
-  const size_t img_bytes = (size_t)a.Hs * a.Ws * a.Cs * ES;
+  const unsigned pixb = a.w8_pixb ? (unsigned)a.w8_pixb : (unsigned)(a.Cs * ES);         // bytes of one source pixel (row-segment form: Cs is the K tile's 64, a pixel is less)
+  const size_t img_bytes = (size_t)a.Hs * a.Ws * pixb;
   const v4i32 rb_desc = make_desc(a.wt, (size_t)a.Kd * a.wrs * a.Cs * ES);
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);
   const int nk = a.nk;
@@ -412,7 +414,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
   unsigned bbase[BI];
   int ra_w0 = 0, ra_w1 = 0, ra_w2 = 0;   // the source descriptor of the current tile (based at its first image), as three wave-uniform words
   const unsigned bhalf = (unsigned)((size_t)HC * a.wrs * a.Cs * ES);                      // B half 1 = the columns HC further
-  const unsigned rowb = (unsigned)(a.Cs * ES);                       // bytes of one source pixel
+  const unsigned rowb = (unsigned)(a.Cs * ES);                       // bytes of one tap's channels in the weights
   auto tile_roles = [&](int m0, int n0) {
     int n_first = (int)__umulhi((unsigned)m0, a.magic_pq);           // m0 / pq (magic multiply + one correction, as decode_row)
     if (m0 - n_first * pq >= pq) ++n_first;
@@ -436,7 +438,7 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
             int n, pp, q;
             decode_row(a, m, pq, n, pp, q);
             const int hb = pp * a.ss, wb = q * a.ss;
-            base = (unsigned)(((n - n_first) * a.Hs + hb) * a.Ws + wb) * rowb;
+            base = (unsigned)(((n - n_first) * a.Hs + hb) * a.Ws + wb) * pixb;
             mk = ((unsigned)hb << 16) | (unsigned)wb;
           }
           abase[h * AI + jj] = base;
@@ -445,13 +447,13 @@ __global__ __launch_bounds__(512, 2) void igemm8_kernel(const IgemmArgs a) {
         }
         if (m < a.M) {                                               // offsets fit 32 bits (launcher)
           if (a.dense_src) {                                         // 1x1, stride 1: row m reads pixel m, no padding
-            base = (unsigned)(m - n_first * pq) * rowb + (unsigned)(c * 16);
+            base = (unsigned)(m - n_first * pq) * pixb + (unsigned)(c * 16);
             mk = 1u;
           } else {
             int n, pp, q;
             decode_row(a, m, pq, n, pp, q);
             const int hb = pp * a.ss, wb = q * a.ss;
-            base = (unsigned)(((n - n_first) * a.Hs + hb) * a.Ws + wb) * rowb + (unsigned)(c * 16);
+            base = (unsigned)(((n - n_first) * a.Hs + hb) * a.Ws + wb) * pixb + (unsigned)(c * 16);
             mk = (unsigned)tap_mask(a, grid, hb, wb) & 0xFFFFu;
           }
         }
@@ -749,10 +751,10 @@ bool fill_walk8(IgemmArgs& a) {
       const int t = i * a.ntw + j;
       if (a.dh[t] != a.dh[0] + i * ddh || a.dw[t] != a.dw[0] + j * ddw || a.widx[t] != a.widx[0] + i * dwi + j * dwj) return false;
     }
-  const long row = (long)a.Cs * 2;
-  a.w8_src0 = (int)(((long)a.dh[0] * a.Ws + a.dw[0]) * row);
-  a.w8_si = (int)((long)ddh * a.Ws * row);
-  a.w8_sj = (int)((long)ddw * row);
+  const long row = (long)a.Cs * 2, prow = a.w8_pixb ? (long)a.w8_pixb : row;     // a tap's bytes in the weights / a pixel's in the source
+  a.w8_src0 = (int)(((long)a.dh[0] * a.Ws + a.dw[0]) * prow);
+  a.w8_si = (int)((long)ddh * a.Ws * prow);
+  a.w8_sj = (int)((long)ddw * prow);
   a.w8_wt0 = (int)((long)a.widx[0] * row);
   a.w8_wi = (int)((long)dwi * row);
   a.w8_wj = (int)((long)dwj * row);
@@ -766,7 +768,8 @@ template <typename T, int BN> int launch8(IgemmArgs& a, hipStream_t s) {
   { const unsigned nnt = (unsigned)(a.Kd / BN); a.w8_magic_nnt = nnt <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / nnt); }
   static const char* const EPN[] = {"plain", "res", "?", "?", "bnb", "bnb+res", "bnb+acc", "?", "gen"};
   const int epm = ep8_mode(a);
-  rn_note_kernel("igemm8<256x%d:%s%s%s>", BN, EPN[epm & 15], (epm & EP8_MASKX) ? "/xmask" : "", (epm & EP8_STRIDED) ? "/s2" : "");
+  rn_note_kernel("igemm8<256x%d:%s%s%s%s>", BN, epm == EP8_BIAS ? "bias" : EPN[epm & 15], (epm & EP8_MASKX) ? "/xmask" : "", (epm & EP8_STRIDED) ? "/s2" : "",
+                 a.w8_pixb ? "/rows" : "");
   if (rn_dry_run()) return 0;
   const int ntiles = cdiv(a.M, 256) * (a.Kd / BN);
   // stream-K (tiles cut into K-tile unit ranges, cut tiles summed through the workspace) only where whole tiles cannot occupy the chip: grids of at most
@@ -790,6 +793,7 @@ template <typename T, int BN> int launch8(IgemmArgs& a, hipStream_t s) {
   switch (ep8_mode(a)) {
     case EP8_PLAIN: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_PLAIN>), dim3(grid), dim3(512), 0, s, a); break;
     case EP8_RES: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_RES>), dim3(grid), dim3(512), 0, s, a); break;
+    case EP8_BIAS: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BIAS>), dim3(grid), dim3(512), 0, s, a); break;
     case EP8_BNB: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB>), dim3(grid), dim3(512), 0, s, a); break;
     case EP8_BNB | EP8_MASKX: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB | EP8_MASKX>), dim3(grid), dim3(512), 0, s, a); break;
     case EP8_BNB | EP8_MASKX | EP8_STRIDED: hipLaunchKernelGGL((igemm8_kernel<T, BN, EP8_BNB | EP8_MASKX | EP8_STRIDED>), dim3(grid), dim3(512), 0, s, a); break;
@@ -828,9 +832,30 @@ static bool stem_capable(const IgemmArgs& a) {
   return true;
 }
 
+// row-segment form: fewer than 64 channels per pixel, but the ntw taps of a kernel row are consecutive pixels and ntw * Cs = 64 -- a kernel row IS one K tile
+// of 128 contiguous bytes per output pixel (the space-to-depth ImageNet stem: 16 channels, 4 x 4 taps).  Forward only, every tap in range for every output
+// (a VALID convolution: the copy is not checked per pixel), weights [K][taps][Cs] = [K][nth][64].
+static bool rowseg_capable(const IgemmArgs& a) {
+  if (a.Cs <= 0 || a.Cs % 8 || a.Cs * a.ntw != 64 || a.nth < 1 || a.nth * a.ntw != a.nt || a.nt > 16 || a.Kd % 128) return false;
+  if (a.ds != 1 || a.res.mode != RN_RES_NONE || a.accum || a.bn_x || a.wrs != a.nt) return false;
+  for (int i = 0; i < a.nth; ++i)
+    for (int j = 0; j < a.ntw; ++j) {
+      const int t = i * a.ntw + j;
+      if (a.dh[t] != a.dh[i * a.ntw] || a.dw[t] != a.dw[i * a.ntw] + j || a.widx[t] != t) return false;
+      if (a.dh[t] < 0 || a.dw[t] < 0 || (a.Pc - 1) * a.ss + a.dh[t] >= a.Hs || (a.Qc - 1) * a.ss + a.dw[t] >= a.Ws) return false;
+    }
+  return true;
+}
+static void rowseg_rewrite(IgemmArgs& a) {               // nth taps of 64 'channels'; the source keeps its own pixel size
+  a.w8_pixb = a.Cs * 2;
+  for (int i = 0; i < a.nth; ++i) { a.dh[i] = a.dh[i * a.ntw]; a.dw[i] = a.dw[i * a.ntw]; a.widx[i] = i; }
+  a.nt = a.nth; a.ntw = 1; a.wrs = a.nth; a.Cs = 64;
+}
+
 // 1: the geometry is one the eight-phase kernel covers with a specialised (spill-free) epilogue; 0: not covered, or only by its general epilogue
 int rn_igemm8_fast(const IgemmArgs& a) {
   if (a.Cs == 8) return stem_capable(a) ? 1 : 0;
+  if (a.Cs % 64) return (rowseg_capable(a) && ep8_mode(a) != EP8_GEN) ? 1 : 0;
   return (a.Cs % 64 == 0 && a.Kd % 128 == 0 && ep8_mode(a) != EP8_GEN) ? 1 : 0;
 }
 
@@ -860,10 +885,12 @@ int rn_launch_igemm8(const IgemmArgs& a_in, int dtype, hipStream_t s) {
   if ((256 / pq + 3) * (double)img_bytes >= 4.0e9) return -1;                          // per-tile source offsets are 32-bit (descriptor based at the tile's first image)
   if (((double)a_in.Kd + 256.0) * a_in.wrs * a_in.Cs * 2 >= 4.0e9) return -1;
   IgemmArgs a = a_in;
+  a.w8_pixb = 0;
   if (a.Cs == 8) {
     if (!stem_capable(a)) return -1;
     return dtype == RN_BF16 ? launch8_stem<bf16_t>(a, s) : launch8_stem<f16_t>(a, s);
   }
+  if (a.Cs % 64 && rowseg_capable(a)) rowseg_rewrite(a);
   if (a.Cs % 64 || a.Kd % 128) return -1;
   if (a.Kd % 256 == 0) return dtype == RN_BF16 ? launch8<bf16_t, 256>(a, s) : launch8<f16_t, 256>(a, s);
   return dtype == RN_BF16 ? launch8<bf16_t, 128>(a, s) : launch8<f16_t, 128>(a, s);           // column tiles of 128: K = 128, 384, 640, ...

@@ -190,10 +190,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   for (int j = 0; j < NJB; ++j) {
     const int ch = cl + TPR * j;
     const bool ok = ch < CHB && c0 + ch * CE < ncols;
-    if constexpr (IC) {                       // column chunk (c0/CE + ch) IS tap number (C == CE)
-      const int tap = ok ? c0 / CE + ch : 0;
+    if constexpr (IC) {                       // column chunk (c0/CE + ch) = (tap, chunk of the pixel): C / CE chunks per tap (1 for the padded stem, 2 for the s2d stem)
+      const int cpt = a.C / CE, cc = ok ? c0 / CE + ch : 0;
+      const int tap = cc / cpt;
       chb_dh[j] = tdh[tap]; chb_dw[j] = tdw[tap];
-      chb_off[j] = ok ? 0u : OOB;
+      chb_off[j] = ok ? (unsigned)((cc - tap * cpt) * 16) : OOB;
     } else {
       chb_off[j] = ok ? (unsigned)((c0 + ch * CE) * ES) : OOB;
     }
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
       for (int j = 0; j < NJB; ++j) {
         const int h = h0 + chb_dh[j], w = w0 + chb_dw[j];
         const bool ok = mv && chb_off[j] != OOB && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W;
-        rb[j] = bload(xdesc, ok ? (unsigned)((((size_t)(n - n_first) * a.H + h) * a.W + w) * a.C * ES) : OOB);
+        rb[j] = bload(xdesc, ok ? (unsigned)((((size_t)(n - n_first) * a.H + h) * a.W + w) * a.C * ES) + chb_off[j] : OOB);
       }
     }
   };
@@ -432,8 +433,10 @@ inline int pick_tile(int n) {       // block tile edge from {160,128,64,32}: few
 }
 
 constexpr int IM2COL_BC = 160;
-inline int col_tile(const rn_conv_geom* g, bool ic) { return ic ? IM2COL_BC : pick_tile(g->C); }
-inline bool use_im2col(const rn_conv_geom* g, int dtype_ce) { return g->C == dtype_ce && g->R * g->S >= 4; }   // one-chunk inputs: the stem
+// one-chunk inputs (the stems: image channels padded to a chunk), and the space-to-depth ImageNet stem (16 channels, 4 x 4 taps, no padding: 256 columns)
+inline bool s2d_stem(const rn_conv_geom* g, int dtype_ce) { return dtype_ce == 8 && g->C == 16 && g->R == 4 && g->S == 4 && g->pad == 0 && g->stride == 1; }
+inline bool use_im2col(const rn_conv_geom* g, int dtype_ce) { return (g->C == dtype_ce && g->R * g->S >= 4) || s2d_stem(g, dtype_ce); }
+inline int col_tile(const rn_conv_geom* g, bool ic, int bk) { return ic ? (((g->R * g->S * g->C) % 128 == 0 && bk == 128) ? 128 : IM2COL_BC) : pick_tile(g->C); }
 
 // workgroups of a (bk x bc) tile that are resident at once: 256 CUs x what LDS (two 64- / 16-pixel stages of both operands) and the
 // accumulator registers allow -- 2 per CU at 160 x 160, 8 at 32 x 32.  Thin layers (ResNet-20 / v2-164: 16..64 channels) are a chain of
@@ -472,7 +475,8 @@ int launch_w(const WgradArgs& a, hipStream_t s) {
 }
 
 template <typename T> int dispatch_w(const WgradArgs& a, int bk, int bc, hipStream_t s) {
-  if (a.im2col) {                                        // column tile fixed at IM2COL_BC
+  if (a.im2col) {                                        // column tile fixed at IM2COL_BC, or 128 when the columns are a multiple of it (the s2d stem's 256)
+    if (bc == 128) return launch_w<T, 4, 4, true>(a, s);      // (col_tile picks 128 columns only beside 128 rows)
     if (bk == 160) return launch_w<T, 5, IM2COL_BC / 32, true>(a, s);
     if (bk == 128) return launch_w<T, 4, IM2COL_BC / 32, true>(a, s);
     if (bk == 64) return launch_w<T, 2, IM2COL_BC / 32, true>(a, s);
@@ -495,7 +499,7 @@ extern "C" size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g) {
   size_t best = 0;
   for (int ce : {4, 8}) {                     // the workspace is sized before the dtype is known: take the larger need
     const bool ic = use_im2col(g, ce);
-    const int bk = pick_tile(g->K), bc = col_tile(g, ic);
+    const int bk = pick_tile(g->K), bc = col_tile(g, ic, bk);
     const size_t need = (size_t)wgrad_splits(g, bk, bc, ic, wgrad_capacity(bk, bc, ce)) * g->K * g->R * g->S * g->C * sizeof(float);
     if (need > best) best = need;
   }
@@ -514,7 +518,7 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   RN_CHECK_ARG((long)g->N * g->P * g->Q < (1L << 31), "rn_conv_wgrad: too many pixels");
   const int w8 = rn_wgrad8_splits(g, dtype);            // > 0: the eight-phase kernel with that many pixel splits (its slabs take the same reduction)
   const bool ic = use_im2col(g, ce);
-  const int bk = pick_tile(g->K), bc = col_tile(g, ic);
+  const int bk = pick_tile(g->K), bc = col_tile(g, ic, bk);
   WgradArgs a{};
   a.im2col = ic ? 1 : 0;
   a.xcd_remap = (g_rn_variant & 4) ? 0 : 1;
@@ -582,7 +586,7 @@ extern "C" int rn_conv_wgrad_splits(const rn_conv_geom* g, int dtype, int flags)
   if (!g || !RN_DTYPE_OK(dtype)) return -1;
   const int ce = dtype == RN_F32 ? 4 : 8;
   const bool ic = use_im2col(g, ce);
-  const int bk = pick_tile(g->K), bc = col_tile(g, ic);
+  const int bk = pick_tile(g->K), bc = col_tile(g, ic, bk);
   const int round = (g_rn_variant & (1 << 23)) ? 512 : wgrad_capacity(bk, bc, ce);
   const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? round / 8 * 7 : round;
   const int w8 = rn_wgrad8_splits(g, dtype);

@@ -48,6 +48,7 @@ struct IgemmArgs {
   void* w8_ws;             // stream-K workspace (rn_set_conv_workspace), or NULL
   unsigned w8_magic_ntw;   // ceil(2^16 / ntw): tap -> (row, column) of the tap grid for taps < 64 (the stem's per-lane tap walk)
   unsigned w8_magic_nnt;   // floor(2^32 / column tiles): tile -> (row tile, column tile) by multiply-high + one correction
+  int w8_pixb;             // bytes of one source pixel when they are not Cs * 2 (row-segment form: a K tile's 64 'channels' are ntw consecutive pixels), else 0
   int w8_drain;            // diagnostic (rn_set_variant 1 << 26): the first K tile of a segment waits for the previous tile's stores too (the pre-counting wait)
   int dh[MAX_TAPS], dw[MAX_TAPS], widx[MAX_TAPS];
 };

@@ -127,6 +127,51 @@ __global__ void unpack_stem_dw_kernel(const float* __restrict__ dwp, float* __re
   }
 }
 
+// ---- the ImageNet stem Conv2d(3 -> K, 7 x 7, stride 2, padding 3) (resnet.py:69-75 under the "c3,K,7,2,3" specs) as a 4 x 4 / stride-1 / VALID convolution
+// over a space-to-depth image.  s2d pixel (i, j) holds the 2 x 2 block of image pixels (2i + dy, 2j + dx) as 16 channels (dy, dx, c of 4: three image
+// channels and a zero); output (p, q) reads s2d rows p - 2 .. p + 1 and columns q - 2 .. q + 1, so the image is stored with 2 zero s2d pixels before and 1
+// after in both directions ([N][H/2 + 3][W/2 + 3][16]) and the convolution needs no padding at all.  Kernel tap (r', s'), channel (dy, dx, c) is the 7 x 7
+// weight at (2r' + dy - 1, 2s' + dx - 1), zero outside.  Against one 16-byte chunk per image pixel (C padded 3 -> 8, K = 49 taps x 8 -> 7 K tiles of 64) the
+// contraction is 16 taps x 16 channels = 4 K tiles, and the 4 taps of a kernel row are 128 contiguous bytes: the eight-phase kernel's ordinary row copy.
+template <typename T>
+__global__ __launch_bounds__(NT) void img_to_s2d_kernel(const float* __restrict__ x, T* __restrict__ out, int N, int C, int H, int W, int HP, int WP) {
+  const long n = (long)N * HP * WP;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const int wp = (int)(i % WP), hp = (int)((i / WP) % HP);
+    const long nn = i / ((long)WP * HP);
+    T* o = out + i * 16;
+#pragma unroll
+    for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+      for (int dx = 0; dx < 2; ++dx) {
+        const int h = 2 * (hp - 2) + dy, w = 2 * (wp - 2) + dx;
+        const bool in = (unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[(dy * 2 + dx) * 4 + c] = Elem<T>::from_f((in && c < C) ? x[((nn * C + c) * H + h) * (long)W + w] : 0.f);
+      }
+  }
+}
+// index of 7 x 7 weight element (r, s, c) inside a [4][4][16] s2d filter, or of filter element j the (r, s, c) it holds (r < 0: a structural zero)
+__device__ inline int s2d_of_rsc(int r, int s, int c) { return ((r + 1) >> 1) * 64 + ((s + 1) >> 1) * 16 + ((((r + 1) & 1) << 1) | ((s + 1) & 1)) * 4 + c; }
+template <typename T>
+__global__ void pack_stem_w_s2d_kernel(const float* __restrict__ w, T* __restrict__ wp, int K, int C) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)K * 256; i += (long)gridDim.x * blockDim.x) {
+    const long k = i >> 8;
+    const int j = (int)(i & 255), rp = j >> 6, sp = (j >> 4) & 3, dy = (j >> 3) & 1, dx = (j >> 2) & 1, c = j & 3;
+    const int r = 2 * rp + dy - 1, t = 2 * sp + dx - 1;
+    wp[i] = Elem<T>::from_f(((unsigned)r < 7u && (unsigned)t < 7u && c < C) ? w[((k * 7 + r) * 7 + t) * C + c] : 0.f);
+  }
+}
+__global__ void unpack_stem_dw_s2d_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int K, int C, int accum) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)K * 49 * C; i += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    const long rs = i / C, k = rs / 49;
+    const int r = (int)((rs % 49) / 7), t = (int)(rs % 7);
+    const float v = dwp[k * 256 + s2d_of_rsc(r, t, c)];
+    dw[i] = accum ? dw[i] + v : v;
+  }
+}
+
 // ---- MaxPool2d(k, s, p), NHWC, -inf padding.  The forward also stores the argmax (window position r*k+s, first maximum
 // in scan order wins -- torch's rule) as one byte per output element; the backward is then a gather: an input element
 // sums dy of the (at most ceil(k/s)^2) windows whose stored argmax points at it.  No atomics, no zero-fill pass.
@@ -954,6 +999,26 @@ extern "C" int rn_pack_stem_w(const float* w_krsc, void* w_padded, int dtype, in
   const long rows = (long)K * RS;
   RN_BY_DTYPE(dtype, hipLaunchKernelGGL((pack_stem_w_kernel<T_>), dim3(ew_grid(rows * CP)), dim3(NT), 0, as_stream(s), w_krsc, (T_*)w_padded, rows, C, CP));
   RN_CHECK_LAUNCH("pack_stem_w");
+  return 0;
+}
+
+extern "C" int rn_img_to_s2d(const float* x_nchw, void* out, int dtype, int N, int C, int H, int W, rn_stream s) {
+  RN_CHECK_ARG(x_nchw && out && N > 0 && C > 0 && C <= 4 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && RN_DTYPE_OK(dtype), "rn_img_to_s2d: bad argument (C=%d H=%d W=%d)", C, H, W);
+  const long n = (long)N * (H / 2 + 3) * (W / 2 + 3);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((img_to_s2d_kernel<T_>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), x_nchw, (T_*)out, N, C, H, W, H / 2 + 3, W / 2 + 3));
+  RN_CHECK_LAUNCH("img_to_s2d");
+  return 0;
+}
+extern "C" int rn_pack_stem_w_s2d(const float* w_k77c, void* w_s2d, int dtype, int K, int C, rn_stream s) {
+  RN_CHECK_ARG(w_k77c && w_s2d && K > 0 && C > 0 && C <= 4 && RN_DTYPE_OK(dtype), "rn_pack_stem_w_s2d: bad argument");
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((pack_stem_w_s2d_kernel<T_>), dim3(ew_grid((long)K * 256)), dim3(NT), 0, as_stream(s), w_k77c, (T_*)w_s2d, K, C));
+  RN_CHECK_LAUNCH("pack_stem_w_s2d");
+  return 0;
+}
+extern "C" int rn_unpack_stem_dw_s2d(const float* dw_s2d, float* dw_k77c, int K, int C, int accumulate, rn_stream s) {
+  RN_CHECK_ARG(dw_s2d && dw_k77c && K > 0 && C > 0 && C <= 4, "rn_unpack_stem_dw_s2d: bad argument");
+  hipLaunchKernelGGL(unpack_stem_dw_s2d_kernel, dim3(ew_grid((long)K * 49 * C)), dim3(NT), 0, as_stream(s), dw_s2d, dw_k77c, K, C, accumulate);
+  RN_CHECK_LAUNCH("unpack_stem_dw_s2d");
   return 0;
 }
 

@@ -102,7 +102,7 @@ extern "C" int rn_plan_create(const rn_op* ops, int n_ops, int n_bufs, int dtype
   RN_CHECK_ARG(ops && out && n_ops > 0 && n_bufs > 0, "rn_plan_create: bad argument");
   RN_CHECK_ARG(RN_DTYPE_OK(dtype), "rn_plan_create: bad dtype %d", dtype);
   for (int i = 0; i < n_ops; ++i) {
-    RN_CHECK_ARG(ops[i].kind >= RN_OP_STEM_FWD && ops[i].kind <= RN_OP_BN_POOL_BWD_APPLY, "rn_plan_create: op %d has unknown kind %d", i, ops[i].kind);
+    RN_CHECK_ARG(ops[i].kind >= RN_OP_STEM_FWD && ops[i].kind <= RN_OP_UNPACK_STEM_DW_S2D, "rn_plan_create: op %d has unknown kind %d", i, ops[i].kind);
     for (int j = 0; j < RN_OP_NBUF; ++j)
       RN_CHECK_ARG(ops[i].buf[j] >= -1 && ops[i].buf[j] < n_bufs, "rn_plan_create: op %d buffer index %d out of range", i, ops[i].buf[j]);
   }
@@ -334,6 +334,12 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
                                          d[4], d[5], d[6], o.flags, (double)d[7], s);
       return rn_bn_pool_bwd_apply(B(0), (const unsigned char*)B(1), B(2), (const float*)B(3), (const float*)B(4), B(5), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6],
                                   o.flags, (double)d[7], s);
+    case RN_OP_IMG_TO_S2D:             /* x out | N C H W */
+      return rn_img_to_s2d((const float*)B(0), B(1), dt, d[0], d[1], d[2], d[3], s);
+    case RN_OP_PACK_STEM_W_S2D:        /* w w_s2d | K C */
+      return rn_pack_stem_w_s2d((const float*)B(0), B(1), dt, d[0], d[1], s);
+    case RN_OP_UNPACK_STEM_DW_S2D:     /* dw_s2d dw | K C */
+      return rn_unpack_stem_dw_s2d((const float*)B(0), (float*)B(1), d[0], d[1], (o.flags & RN_F_ACCUM) ? 1 : 0, s);
     case RN_OP_UNPACK_STEM_DW:
       return rn_unpack_stem_dw((const float*)B(0), (float*)B(1), d[0], d[1], d[2], d[3], (o.flags & RN_F_ACCUM) ? 1 : 0, s);
     default:

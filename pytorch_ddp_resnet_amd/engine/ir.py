@@ -15,7 +15,8 @@ RES_NONE, RES_SAME, RES_DOWN2PAD, RES_UP2 = 0, 1, 2, 3
 (OP_STEM_FWD, OP_PACK_W, OP_CONV_FWD, OP_BN_STATS, OP_BN_FINALIZE, OP_BN_APPLY, OP_DROPOUT_FWD, OP_MAXPOOL_FWD,
  OP_POOL_FC_FWD, OP_POOL_FC_BWD, OP_MAXPOOL_BWD, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE, OP_BN_BWD_APPLY,
  OP_CONV_DGRAD, OP_CONV_WGRAD, OP_STEM_WGRAD, OP_DROPOUT_BWD, OP_SOFTMAX_CE, OP_ZERO, OP_ADD_RES, OP_IMG_TO_NHWC,
- OP_PACK_STEM_W, OP_UNPACK_STEM_DW, OP_BN_POOL_FWD, OP_BN_POOL_BWD_REDUCE, OP_BN_POOL_BWD_APPLY) = range(1, 28)
+ OP_PACK_STEM_W, OP_UNPACK_STEM_DW, OP_BN_POOL_FWD, OP_BN_POOL_BWD_REDUCE, OP_BN_POOL_BWD_APPLY, OP_IMG_TO_S2D, OP_PACK_STEM_W_S2D,
+ OP_UNPACK_STEM_DW_S2D) = range(1, 31)
 
 OP_NAMES = {v: k for k, v in list(globals().items()) if k.startswith('OP_') and isinstance(v, int)}
 
@@ -28,7 +29,7 @@ CONV_STATS_ROWS = 128      # RN_CONV_STATS_ROWS: output pixels per partial-sum r
 OP_FIELDS = {
     OP_STEM_FWD:        ('x w bias y', 'geom', ''),
     OP_PACK_W:          ('w w_fwd w_dgrad', 'K RS C', ''),
-    OP_CONV_FWD:        ('x w_fwd y res stats bias', 'geom res_mode res_C', ''),
+    OP_CONV_FWD:        ('x w_fwd y res stats bias', 'geom res_mode res_C alg_macs', ''),      # alg_macs: MACs per output of the reference's layer when the geometry is a regrouping of it (s2d stem; bench.py), else 0
     OP_BN_STATS:        ('x partial', 'M C nblk', ''),
     OP_BN_FINALIZE:     ('partial gamma beta running_mean running_var nbt coef fold', 'nblk count C', 'eps momentum'),
     OP_BN_APPLY:        ('x coef res out', 'N H W C res_mode res_C', 'p'),
@@ -41,7 +42,7 @@ OP_FIELDS = {
     OP_BN_BWD_FINALIZE: ('partial dsum dgamma dbeta fold', 'nblk C', ''),
     OP_BN_BWD_APPLY:    ('dout x mask coef dsum add dx g_out', 'N H W C add_mode add_C count', 'gscale p'),
     OP_CONV_DGRAD:      ('dy w_dgrad dx res bn_x bn_mask bn_coef bn_partial', 'geom res_mode res_C', 'gscale'),
-    OP_CONV_WGRAD:      ('x dy dw ws', 'geom', ''),
+    OP_CONV_WGRAD:      ('x dy dw ws', 'geom alg_macs', ''),
     OP_STEM_WGRAD:      ('x dy dw db ws', 'geom', ''),
     OP_DROPOUT_BWD:     ('dout out din', 'n_lo n_hi', 'p'),
     OP_SOFTMAX_CE:      ('logits labels out3 dlogits gscale', 'N O', 'scale'),
@@ -53,6 +54,9 @@ OP_FIELDS = {
     OP_BN_POOL_FWD:     ('x coef y argmax xsel', 'N H W C k stride pad', ''),
     OP_BN_POOL_BWD_REDUCE: ('dy argmax x coef partial xsel', 'N H W C k stride pad nblk npix', ''),
     OP_BN_POOL_BWD_APPLY:  ('dy argmax x coef dsum dx sums', 'N H W C k stride pad count rows', ''),
+    OP_IMG_TO_S2D:         ('x out', 'N C H W', ''),
+    OP_PACK_STEM_W_S2D:    ('w w_s2d', 'K C', ''),
+    OP_UNPACK_STEM_DW_S2D: ('dw_s2d dw', 'K C', ''),
 }
 
 GEOM = 'N H W C P Q K R S stride pad'.split()

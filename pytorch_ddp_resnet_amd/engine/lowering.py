@@ -467,6 +467,49 @@ class Lowering:
                 xt = T(xin, self.N, self.H, self.W, c.cin)
                 w, b = self.param(pre + '.weight', (c.cout, k, k, c.cin)), self.param(pre + '.bias', (c.cout,))
                 CP = 4 if self.fp32 else 8
+                s2d = (not self.fp32 and (k, s, pd) == (7, 2, 3) and c.cin <= 4 and self.H % 2 == 0 and self.W % 2 == 0 and c.cout % 16 == 0
+                       and os.environ.get('RN_VALU_STEM', '0') != '1' and os.environ.get('RN_NO_S2D_STEM', '0') != '1')
+                if s2d:
+                    # the ImageNet stem (7 x 7, stride 2, padding 3) as a 4 x 4 / stride-1 / VALID convolution over a space-to-depth image (16 channels per
+                    # s2d pixel, stored pre-padded: csrc/misc.hip img_to_s2d): 4 K tiles of 64 instead of the 7 of the padded-channel route below, and a
+                    # kernel row is 128 contiguous bytes per output pixel.  Same output tensor, same weight / bias gradients (the [K][4][4][16] weight
+                    # gradient is mapped back to [K][7][7][C]).
+                    xp = self.act(pre + ':xs2d', self.N, self.H // 2 + 3, self.W // 2 + 3, 16)
+                    self.fwd.append(Op(ir.OP_IMG_TO_S2D, buf=dict(x=xin, out=xp.s), dim=dict(N=self.N, C=c.cin, H=self.H, W=self.W), note=pre))
+                    wp = self.slot(pre + ':ws2d', 'act', (c.cout, 16, 16), 'T')
+                    self.fwd.append(Op(ir.OP_PACK_STEM_W_S2D, buf=dict(w=w, w_s2d=wp), dim=dict(K=c.cout, C=c.cin), note=pre))
+                    g = self.geom(xp, c.cout, 4, 1, 0)
+                    alg = k * k * c.cin                           # MACs per output of the reference's layer (bench.py's algorithmic FLOPs)
+                    y = self.act(pre + ':y', self.N, g['P'], g['Q'], c.cout)
+                    part = -1
+                    if self.train and self.fuse:
+                        rows = conv_stats_rows(g)
+                        part = self.f32(pre + ':stats', (rows, 2, c.cout))
+                        self._stats_of[y.s] = (part, rows)
+                    self.fwd.append(Op(ir.OP_CONV_FWD, buf=dict(x=xp.s, w_fwd=wp, y=y.s, res=-1, stats=part, bias=b), dim=dict(g, res_mode=0, res_C=0, alg_macs=alg), note=pre))
+                    self._wants_colsum.add(y.s)
+
+                    def stem_back(dy: T, ops, g=g, xp=xp, pre=pre, cin=c.cin, alg=alg):
+                        K = g['K']
+                        dwp = self.f32(pre + ':dws2d', (K, 16, 16))
+                        ops.append(Op(ir.OP_CONV_WGRAD, buf=dict(x=xp.s, dy=dy.s, dw=dwp, ws=self.ws()), dim=dict(g, alg_macs=alg), note=pre))
+                        self._ws_need.append(('wgrad', dict(g)))
+                        dw, db = self.grad(pre + '.weight', (K, 7, 7, cin)), self.grad(pre + '.bias', (K,))
+                        ops.append(Op(ir.OP_UNPACK_STEM_DW_S2D, buf=dict(dw_s2d=dwp, dw=dw), dim=dict(K=K, C=cin), note=pre))
+                        s2, sq = self.f32(pre + ':dbsum', (2, K)), self.f32(pre + ':dbsq', (K,))       # by-products, unused
+                        if dy.s in self._colsum_of:
+                            part, nblk = self._colsum_of[dy.s]
+                        else:
+                            nblk = bn_partials(dy.M, K)
+                            part = self.f32(pre + ':dbpartial', (nblk, 2, K))
+                            ops.append(Op(ir.OP_BN_STATS, buf=dict(x=dy.s, partial=part), dim=dict(M=dy.M, C=K, nblk=nblk), note=pre))
+                        ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=s2, dgamma=sq, dbeta=db, fold=self.fold(pre + ':dbfold', nblk, K)), dim=dict(nblk=nblk, C=K), note=pre))
+                        self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
+                        return None
+                    self._back.append(stem_back)
+                    cur = y
+                    idx += 1
+                    continue
                 if c.cin <= CP and c.cout % 16 == 0 and os.environ.get('RN_VALU_STEM', '0') != '1':
                     # MFMA route: NHWC image with the channels zero-padded to one 16-byte chunk, then the implicit-GEMM
                     # kernels with bias (+ BN statistics) in the epilogue and the im2col wgrad (dy read once)

@@ -335,6 +335,28 @@ class NumpyPlan:
         elif k == ir.OP_UNPACK_STEM_DW:
             v = B('dw_padded').reshape(d['K'], d['RS'], d['CP'])[..., :d['C']]
             put('dw', v + B('dw').reshape(v.shape) if op.flags & ir.F_ACCUM else v)
+        elif k == ir.OP_IMG_TO_S2D:                    # [N,C,H,W] -> [N,H/2+3,W/2+3,16]: s2d pixel (i, j) channel (dy, dx, c of 4) = x[c, 2i+dy, 2j+dx]; 2 zero pixels before, 1 after
+            x = B('x')
+            N, C, H, W = x.shape
+            out = np.zeros((N, H // 2 + 3, W // 2 + 3, 16), dtype=self.dtype)
+            for dy in range(2):
+                for dx in range(2):
+                    out[:, 2:2 + H // 2, 2:2 + W // 2, (dy * 2 + dx) * 4:(dy * 2 + dx) * 4 + C] = np.transpose(x[:, :, dy::2, dx::2], (0, 2, 3, 1))
+            put('out', out)
+        elif k in (ir.OP_PACK_STEM_W_S2D, ir.OP_UNPACK_STEM_DW_S2D):
+            K, C = d['K'], d['C']                      # filter tap (r', s') channel (dy, dx, c) <-> 7x7 weight (2r'+dy-1, 2s'+dx-1, c)
+            idx = np.full((7, 7, C), -1, dtype=np.int64)
+            for r in range(7):
+                for t in range(7):
+                    for c in range(C):
+                        idx[r, t, c] = ((r + 1) // 2) * 64 + ((t + 1) // 2) * 16 + (((r + 1) % 2) * 2 + (t + 1) % 2) * 4 + c
+            if k == ir.OP_PACK_STEM_W_S2D:
+                wp = np.zeros((K, 256), dtype=self.dtype)
+                wp[:, idx.reshape(-1)] = B('w').reshape(K, -1)
+                put('w_s2d', wp.reshape(K, 16, 16))
+            else:
+                v = B('dw_s2d').reshape(K, 256)[:, idx.reshape(-1)].reshape(K, 7, 7, C)
+                put('dw', v + B('dw').reshape(v.shape) if op.flags & ir.F_ACCUM else v)
         elif k == ir.OP_ZERO:
             self.bufs[op.buf['dst']][...] = 0
         else:

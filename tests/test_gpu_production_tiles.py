@@ -486,6 +486,78 @@ def test_igemm8_stem(g, variant, dtype):
     assert float((s1 - (ys * ys).sum(0)).abs().max()) < 2e-5 * float((ys * ys).sum(0).max())
 
 
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('shape,variant,fwd_name', [((8, 224, 224, 512), 0, 'igemm8<256x256:bias/rows>'), ((8, 224, 224, 256), 0, 'igemm8<256x256:bias/rows>'),
+                                                    ((3, 40, 56, 256), IGEMM8, 'igemm8<256x256:bias/rows>'), ((2, 36, 20, 128), IGEMM8, 'igemm8<256x128:bias/rows>'),
+                                                    ((2, 32, 32, 64), 0, None), ((5, 20, 28, 16), 0, None)])
+def test_s2d_stem(shape, variant, fwd_name, dtype):
+    """the ImageNet stem Conv2d(3 -> K, 7 x 7, stride 2, padding 3, bias) (resnet.py:69-75) as the 16-bit engines lower it: image -> space-to-depth layout
+    (rn_img_to_s2d), weights -> [K][4][4][16] (rn_pack_stem_w_s2d), a 4 x 4 / stride-1 / VALID convolution (the eight-phase kernel's row-segment form at the
+    shipped rule and forced on small shapes -- a kernel row = one K tile of 128 contiguous bytes; the 128-row kernels otherwise), its weight gradient (im2col
+    columns = (tap, chunk)) mapped back to [K][7][7][3] (rn_unpack_stem_dw_s2d).  Against torch's 7 x 7 convolution and its weight gradient on the same
+    rounded operands; bias and BatchNorm statistics from the epilogue."""
+    import gpu_harness as h
+    from pytorch_ddp_resnet_amd.engine.executor import Engine
+    N, Hh, W, K = shape
+    b = h.PlanBuilder()
+    x = b.slot('x', (N, 3, Hh, W), 'f32'); w = b.slot('w', (K, 7, 7, 3), 'f32'); bias = b.slot('bias', (K,), 'f32')
+    xs = b.slot('xs', (N, Hh // 2 + 3, W // 2 + 3, 16)); wsd = b.slot('wsd', (K, 16, 16))
+    gm = geom(N, Hh // 2 + 3, W // 2 + 3, 16, K, 4, 1, 0)
+    P, Q = gm['P'], gm['Q']
+    assert (P, Q) == (Hh // 2, W // 2)
+    y = b.slot('y', (N, P, Q, K)); st = b.slot('st', (conv_stats_rows(gm), 2, K), 'f32'); dy = b.slot('dy', (N, P, Q, K))
+    dws = b.slot('dws', (K, 16, 16), 'f32'); dw = b.slot('dw', (K, 7, 7, 3), 'f32'); ws = b.slot('workspace', (0,), 'u8')
+    b.op(ir.OP_IMG_TO_S2D, buf=dict(x=x, out=xs), dim=dict(N=N, C=3, H=Hh, W=W))
+    b.op(ir.OP_PACK_STEM_W_S2D, buf=dict(w=w, w_s2d=wsd), dim=dict(K=K, C=3))
+    b.op(ir.OP_CONV_FWD, buf=dict(x=xs, w_fwd=wsd, y=y, res=-1, stats=st, bias=bias), dim=dict(gm, res_mode=0, res_C=0))
+    b.op(ir.OP_CONV_WGRAD, buf=dict(x=xs, dy=dy, dw=dws, ws=ws), dim=dict(gm))
+    b.op(ir.OP_UNPACK_STEM_DW_S2D, buf=dict(dw_s2d=dws, dw=dw), dim=dict(K=K, C=3))
+    b.ws_need.append(('wgrad', gm))
+    plan = b.plan(False)
+    plan.meta['dtype'] = dtype
+    plan.slot_of['ws'] = ws
+    xv = _round(fill((N, 3, Hh, W), 2), dtype)                    # pre-rounded: both sides multiply the same values
+    wv = _round(fill((K, 7, 7, 3), 1, (3.0 / 147) ** 0.5), dtype)
+    bv = torch.from_numpy(fill((K,), 9, 0.5))
+    dyv = _round(fill((N, P, Q, K), 3), dtype)
+    eng = Engine(plan, h.DEV, TORCH_DT[dtype])
+    for name, v in dict(x=xv, w=wv, bias=bv, dy=dyv).items():
+        t = eng.tensors[plan.slot_of[name]]
+        t.copy_(v.reshape(t.shape).to(t.dtype))
+    eng.bind({})
+    L = _lib.lib()
+    L.rn_set_variant(variant)
+    try:
+        L.rn_kernel_log(1)
+        eng.run(0, len(plan.ops), 0)
+        torch.cuda.synchronize()
+        ran = L.rn_kernel_log_read().decode().split(',')
+        want = _lib.conv_kernel_names(0, RN_DT[dtype], gm, fused_epilogue=9) + _lib.conv_kernel_names(2, RN_DT[dtype], gm)
+    finally:
+        L.rn_kernel_log(0)
+        L.rn_set_variant(0)
+    assert ran == want, (ran, want)
+    if fwd_name:
+        assert ran[0] == fwd_name, ran
+    assert any(n.startswith('wgrad_im2col<') for n in ran), ran
+    wn = wv.permute(0, 3, 1, 2).contiguous()
+    yo = eng.tensors[plan.slot_of['y']].float().cpu()
+    ref = _nhwc(F.conv2d(xv, wn, bv, 2, 3))
+    err = float((yo - ref).abs().max() / ref.abs().max())
+    assert err < TOL[dtype], ('y', err, shape, dtype)
+    ys = yo.double().reshape(-1, K)
+    s0, s1 = eng.tensors[plan.slot_of['st']].double().cpu().sum(0)
+    assert float((s0 - ys.sum(0)).abs().max()) < 2e-5 * float(ys.abs().sum(0).max())
+    assert float((s1 - (ys * ys).sum(0)).abs().max()) < 2e-5 * float((ys * ys).sum(0).max())
+    dw_ref = torch.nn.grad.conv2d_weight(xv, wn.shape, _nchw(dyv), 2, 3).permute(0, 2, 3, 1)
+    dwo = eng.tensors[plan.slot_of['dw']].float().cpu()
+    errw = float((dwo - dw_ref).abs().max() / dw_ref.abs().max())
+    assert errw < 2e-4, ('dw', errw, shape, dtype)
+    # the structural zeros of the regrouped filter (tap row / column -1, channel 3 of every image pixel) carry no weight and receive no gradient back
+    wsd_o = eng.tensors[plan.slot_of['wsd']].float().cpu().reshape(K, 4, 4, 2, 2, 4)
+    assert float(wsd_o[..., 3].abs().max()) == 0 and float(wsd_o[:, 0, :, 0].abs().max()) == 0 and float(wsd_o[:, :, 0, :, 0].abs().max()) == 0
+
+
 @pytest.mark.parametrize('g', [(2, 16, 16, 128, 256, 3, 1, 1), (3, 14, 14, 64, 256, 1, 1, 0)])
 def test_igemm8_exact_integers(g):
     """integer operands: the eight-phase kernel must equal the reference bit for bit (fragment <-> pixel / channel maps, tap walk, stage toggling)."""

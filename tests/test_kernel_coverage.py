@@ -40,6 +40,9 @@ def _tested_names(dtype):
     for g in STEM8_GEOMS:                      # test_igemm8_stem: the stem convolution with its bias and statistics
         if dtype != ir.RN_F32:
             names.update(_lib.conv_kernel_names(0, dtype, geom(*resolve(g, False)), fused_epilogue=9))
+            gs = geom(g[0], g[1] // 2 + 3, g[2] // 2 + 3, 16, g[4], 4, 1, 0)          # test_s2d_stem: the same layers in the space-to-depth form the 16-bit engines lower to
+            names.update(_lib.conv_kernel_names(0, dtype, gs, fused_epilogue=9))
+            names.update(_lib.conv_kernel_names(2, dtype, gs))
     for g in IGEMM8_GEOMS:                     # test_igemm8_production_operand_sets: every operand set
         if dtype == ir.RN_F32:
             break
@@ -84,6 +87,18 @@ def test_every_production_tile_is_parity_tested(name, dtype):
     assert n_conv > 10
     assert not missing, f'{name}: kernels launched by the configuration but by no parity-test geometry: ' + \
         '; '.join(f'{k} e.g. {v[0]}' for k, v in missing.items())
+
+
+@pytest.mark.parametrize('fp32', [False, True])
+@pytest.mark.parametrize('name', list(CONFIGS))
+def test_every_op_of_every_configuration_packs(name, fp32):
+    """Op.packed() (the C-ABI encoding the executor hands to rn_plan_create) accepts every op the lowering emits -- a buffer or dimension name the op table does
+    not declare is an error that would otherwise first show on the GPU box"""
+    cfg = CONFIGS[name]
+    plan = lower(cfg['spec'], cfg['preact'], cfg['use_proj'], 0.0, 4, cfg['hw'], cfg['hw'], train=True, fp32=fp32)
+    for op in plan.ops:
+        buf, dim, fp = op.packed()
+        assert len(buf) == ir.OP_NBUF and len(dim) == ir.OP_NDIM and len(fp) == 4
 
 
 def test_dry_run_launches_nothing_and_restores_the_log():

@@ -56,6 +56,28 @@ def test_plan_matches_golden(golden, name):
     assert len(plan_e.ops) == plan_e.n_fwd
 
 
+@pytest.mark.parametrize('fp32', [True, False])
+def test_imagenet_stem_lowerings_match_golden(golden, fp32):
+    """the 7 x 7 / stride-2 stem has two lowerings: channels padded to one chunk (fp32 engine) and the space-to-depth form (16-bit engines: a 4 x 4 VALID
+    convolution over [N][H/2+3][W/2+3][16], weights regrouped to [K][4][4][16], weight gradient mapped back).  Both, interpreted in float64, must reproduce the
+    reference's golden logits and gradients (the stem weight gradient included)."""
+    cfg = MODELS['inet_small']
+    g = golden('g4_inet_small')
+    shapes, st, x, y, nesterov = model_inputs(g, cfg)
+    plan, npl, logits = run_plan(cfg, st, x, y, train=True, fp32=fp32)
+    kinds = {o.kind for o in plan.ops}
+    assert (ir.OP_IMG_TO_S2D in kinds) == (not fp32) and (ir.OP_IMG_TO_NHWC in kinds) == fp32
+    assert rel_err(logits, g['train.logits']) < 2e-5
+    grads = npl.grads()
+    pkeys = [k for k, _ in shapes if k.endswith('weight') or k.endswith('bias')]
+    norms = np.array([np.sqrt((grads[k] ** 2).sum()) for k in pkeys])
+    assert np.abs(norms - g['grad.norms']).max() < 1e-4 * g['grad.norms'].max()
+    k0 = '_architecture.0.weight'
+    assert grads[k0].shape == (16, 3, 7, 7)                 # reference layout [K][C][R][S]
+    if 'grad.' + k0 in g:
+        assert np.abs(grads[k0] - g['grad.' + k0]).max() < 1e-4 * np.abs(g['grad.' + k0]).max() + 1e-6 * float(g['grad.norms'].max())
+
+
 COMBOS = [(k, p, j) for k in 'rb' for p in (False, True) for j in (False, True)]
 
 
