@@ -15,7 +15,7 @@
 extern int g_rn_variant;   // conv_igemm.hip (rn_set_variant)
 // conv_wgrad8.hip: the eight-phase kernel for channel counts that are multiples of 256 (stream-K, sums in-kernel: no slabs, no reduction launch)
 int rn_wgrad8_splits(const rn_conv_geom* g, int dtype);
-int rn_launch_wgrad8(const void* x, const void* dy, float* out, int splits, int dtype, const rn_conv_geom* g, hipStream_t s);
+int rn_launch_wgrad8(const void* x, const void* dy, float* out, int splits, int dtype, const rn_conv_geom* g, int max_grid, hipStream_t s);
 
 namespace {
 
@@ -549,7 +549,9 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   }
   a.out = direct ? dw_krsc : reinterpret_cast<float*>(ws);
   int e = 0;
-  if (w8 > 0) e = rn_launch_wgrad8(x, dy, a.out, a.splits, dtype, g, as_stream(s));
+  // rn_set_variant low byte of bits 8..15 is taken elsewhere; RN_W8_FORK_GRID (environment, read once) sizes a forked eight-phase launch for A/B runs
+  static const int w8_fork_grid = getenv("RN_W8_FORK_GRID") ? atoi(getenv("RN_W8_FORK_GRID")) : 256;
+  if (w8 > 0) e = rn_launch_wgrad8(x, dy, a.out, a.splits, dtype, g, (flags & RN_F_FORK) ? w8_fork_grid : 256, as_stream(s));
   else RN_BY_DTYPE(dtype, e = dispatch_w<T_>(a, bk, bc, as_stream(s)));
   if (e) return e;
   if (!direct) {

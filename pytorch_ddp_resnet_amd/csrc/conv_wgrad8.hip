@@ -311,7 +311,7 @@ int rn_wgrad8_splits(const rn_conv_geom* g, int dtype) {
 }
 
 // out: the gradient itself (splits == 1) or the slab region [splits][K][RS][C]
-int rn_launch_wgrad8(const void* x, const void* dy, float* out, int splits, int dtype, const rn_conv_geom* g, hipStream_t s) {
+int rn_launch_wgrad8(const void* x, const void* dy, float* out, int splits, int dtype, const rn_conv_geom* g, int max_grid, hipStream_t s) {
   Wg8Args a{};
   a.x = x; a.dy = dy; a.dw = out;
   a.N = g->N; a.H = g->H; a.W = g->W; a.C = g->C; a.P = g->P; a.Q = g->Q; a.K = g->K;
@@ -327,7 +327,10 @@ int rn_launch_wgrad8(const void* x, const void* dy, float* out, int splits, int 
   rn_note_kernel("wgrad8<256x256>");
   if (rn_dry_run()) return 0;
   const long items = (long)a.ntiles * splits;
-  const int grid = items < 256 ? (int)items : 256;
+  // max_grid < 256: a FORKED launch (side stream, beside the data-gradient / BatchNorm chain) leaves CUs free -- a persistent workgroup of this kernel
+  // holds every vector register of its CU until its last item, so behind a full grid the chain's small kernels wait for whole workgroup lifetimes
+  const int cap = max_grid > 0 && max_grid < 256 ? max_grid : 256;
+  const int grid = items < cap ? (int)items : cap;
   if (dtype == RN_BF16) hipLaunchKernelGGL((wgrad8_kernel<bf16_t>), dim3(grid), dim3(512), 0, s, a);
   else hipLaunchKernelGGL((wgrad8_kernel<f16_t>), dim3(grid), dim3(512), 0, s, a);
   RN_CHECK_LAUNCH("wgrad8");
