@@ -117,7 +117,7 @@ int rn_set_conv_workspace(void* p, size_t bytes);
  * rn_conv_kernel_names: the names a geometry WOULD select (pass 0 forward, 1 dgrad, 2 wgrad), without launching anything
  * (host-only: works without a GPU) -- the tests use it to prove that every tile a BASELINE config selects is parity-tested.
  * fused_epilogue names the launch's operand set (kernels may be specialised per set): 1 = fused BatchNorm sums (forward: statistics of the
- * output; data gradient: the backward sums over x and the mask), 2 = identity residual, 4 = accumulate into dx, 8 = per-channel bias (the stem convolution) */
+ * output; data gradient: the backward sums over x and the mask), 2 = identity residual, 4 = accumulate into dx, 8 = per-channel bias (the stem convolution), 16 = rn_conv_epilogue.mask_from_x (data gradient) */
 void rn_kernel_log(int enable);
 const char* rn_kernel_log_read(void);
 struct rn_conv_geom;
