@@ -101,6 +101,11 @@ def fused_loss_and_metrics(logits, labels):
         return None
     if labels.dtype != torch.int64 or labels.device != logits.device or not labels.is_contiguous() or logits.shape[1] < 5:
         return None
+    # the kernel reads labels[n] for every logits row, and the logits from the engine's own buffer (``logits`` is a copy of it): anything else goes
+    # to the torch ops (which raise on a shape mismatch); a label outside [0, O) gives a NaN loss in the kernel (torch device-asserts), never an
+    # out-of-range read
+    if labels.dim() != 1 or logits.dim() != 2 or labels.shape[0] != logits.shape[0] or logits._version != getattr(logits, '_rn_version', -1):
+        return None                                # (an in-place edit of the returned logits bumps the version: the engine's copy is then stale)
     return _LossFn.apply(logits, labels, eng, gen)
 
 
@@ -193,4 +198,5 @@ class ResNet(nn.Module):
         out = _EngineFn.apply(self, x, seed, need_grad, *params)
         eng = self._engine(x.shape, self.training, need_grad)
         out._rn_src = (eng, eng.generation)        # lets algos.metrics.compute_losses_and_metrics take the fused loss path
+        out._rn_version = out._version
         return out

@@ -779,8 +779,11 @@ __global__ __launch_bounds__(SM_NT) void softmax_ce_kernel(const float* __restri
     for (int n0 = wave * per_wave; n0 < N; n0 += SM_NW * per_wave) {
       const int n = n0 + lane / G;
       const bool live = n < N, mine = live && sub < O;
-      const int lab = live ? (int)labels[n] : 0;
-      const float zl = live ? logits[(size_t)n * O + lab] : 0.f;
+      // a label outside [0, O) (torch's cross_entropy device-asserts there) must not become an out-of-range read: the row's loss turns into NaN instead
+      const long long lab_ll = live ? labels[n] : 0;
+      const bool bad = (unsigned long long)lab_ll >= (unsigned long long)O;
+      const int lab = bad ? 0 : (int)lab_ll;
+      const float zl = !live ? 0.f : bad ? __builtin_nanf("") : logits[(size_t)n * O + lab];
       const float z = mine ? logits[(size_t)n * O + sub] : -FLT_MAX;
       float mx = z;
       for (int off = G >> 1; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
@@ -802,8 +805,10 @@ __global__ __launch_bounds__(SM_NT) void softmax_ce_kernel(const float* __restri
   }
   for (int n = wave; n < N; n += SM_NW) {
     const float* row = logits + (size_t)n * O;
-    const int lab = (int)labels[n];
-    const float zl = row[lab];
+    const long long lab_ll = labels[n];
+    const bool bad = (unsigned long long)lab_ll >= (unsigned long long)O;          // see above: NaN loss, never an out-of-range read
+    const int lab = bad ? 0 : (int)lab_ll;
+    const float zl = bad ? __builtin_nanf("") : row[lab];
     float z[SM_R];
     float mx = -FLT_MAX, se = 0.f;
     int ahead = 0;

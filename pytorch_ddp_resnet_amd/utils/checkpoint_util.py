@@ -72,7 +72,11 @@ def maybe_load_checkpoint(checkpoint_dir: str, kind_name: str, checkpointable, m
 
 def save_checkpoint(checkpoint_dir: str, kind_name: str, checkpointable, steps: int, keep: int = 5) -> None:
     os.makedirs(checkpoint_dir, exist_ok=True)
-    torch.save(checkpointable.state_dict(), os.path.join(checkpoint_dir, _format_name(kind_name, steps)))
+    # written under a name the resume scan does not parse, then renamed: a reader never sees a half-written file (torch.save is not atomic)
+    final = os.path.join(checkpoint_dir, _format_name(kind_name, steps))
+    tmp = final + '.tmp%d' % os.getpid()
+    torch.save(checkpointable.state_dict(), tmp)
+    os.replace(tmp, final)
     for old in _steps_of(checkpoint_dir, kind_name)[:-keep]:
         os.remove(os.path.join(checkpoint_dir, _format_name(kind_name, old)))
 

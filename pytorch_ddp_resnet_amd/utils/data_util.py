@@ -87,10 +87,20 @@ def get_datasets(dataset_cls_name: str, data_dir: str, data_aug_train: Dict[str,
     t_train = BatchTransform(shape, data_aug_train, device=device)
     ds_train = DeviceDataset(xtr, ytr, t_train, device)
     if t_train.whitening is not None:
+        # the reference lets every rank load-or-fit-and-save the same file at once (data_util.py:76-92; its slow host-side fit hides the race).  The
+        # fit here takes milliseconds, so rank 0 goes first -- load, else fit and save (atomically) -- and the other ranks load behind a barrier.
+        import torch.distributed as dist
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        first = not multi or dist.get_rank() == 0
+        if multi and not first:
+            dist.barrier()
         step = maybe_load_checkpoint(checkpoint_dir, t_train.kind_name, _Fitted(t_train), 'cpu', None)
         if step == 0:
             t_train.fit(ds_train.images)
-            save_checkpoint(checkpoint_dir, t_train.kind_name, _Fitted(t_train), 1)
+            if first:
+                save_checkpoint(checkpoint_dir, t_train.kind_name, _Fitted(t_train), 1)
+        if multi and first:
+            dist.barrier()
     t_test = BatchTransform(shape, data_aug_test, device=device)
     if t_test.whitening is not None:
         if t_test.whitening != t_train.whitening:
