@@ -67,7 +67,13 @@ enum {
   RN_OP_BN_POOL_BWD_APPLY = 27,  /* BN_BWD_APPLY over the same g */
   RN_OP_IMG_TO_S2D = 28,         /* NCHW fp32 image -> space-to-depth NHWC [N][H/2+3][W/2+3][16] (the 7x7 / stride-2 stem as a 4x4 VALID convolution)  */
   RN_OP_PACK_STEM_W_S2D = 29,    /* stem weights [K][7][7][C] fp32 -> [K][4][4][16] compute dtype                                                       */
-  RN_OP_UNPACK_STEM_DW_S2D = 30  /* stem weight gradient [K][4][4][16] fp32 -> [K][7][7][C]                                                             */
+  RN_OP_UNPACK_STEM_DW_S2D = 30, /* stem weight gradient [K][4][4][16] fp32 -> [K][7][7][C]                                                             */
+  /* grammar corners of resnet.py:122-158 (any token sequence is a network; no shipped config uses these): */
+  RN_OP_RELU_FWD = 31,           /* resnet.py:143-145 a top-level 'a' that follows no 'n': x y | n_lo n_hi                                               */
+  RN_OP_RELU_BWD = 32,           /* dy y dx | n_lo n_hi                                                                                                  */
+  RN_OP_AVGPOOL_FWD = 33,        /* resnet.py:77-81 AvgPool2d(k, s, p) other than the global pool in front of 'f': x y | N H W C k stride pad            */
+  RN_OP_AVGPOOL_BWD = 34,        /* dy dx | N H W C k stride pad                                                                                         */
+  RN_OP_PERMUTE_F32 = 35         /* out[a][c][b] = in[a][b][c]: Linear weights / gradients between NCHW-flattened and NHWC feature order: in out | A B C */
 };
 
 /* flags */
@@ -104,7 +110,7 @@ typedef struct rn_plan rn_plan;
 const char* rn_last_error(void);
 /* ABI version: bumped with EVERY change of an entry point's signature or meaning; a binding refuses a library of another version (a stale
  * librn_hip.so would otherwise take shifted pointer / integer arguments).  3: round 3 (operand-set flags of rn_conv_kernel_names, workspaces). */
-#define RN_ABI_VERSION 7
+#define RN_ABI_VERSION 8
 int rn_version(void);
 /* kernel-variant switch for A/B measurements (tools/conv_bench.py; bits documented in csrc/conv_igemm.hip); 0 = shipped */
 void rn_set_variant(int v);
@@ -282,6 +288,17 @@ int rn_dropout_fwd(const void* x, void* out, int dtype, int64_t n, float p, uint
 int rn_dropout_bwd(const void* dout, void* din, int dtype, int64_t n, float p, uint32_t site, uint64_t step_seed, rn_stream s);
 /* dst[n,h,w,c] += res (RN_RES_* mapping) */
 int rn_add_res(void* dst, const void* res, int dtype, int N, int H, int W, int C, int res_mode, int res_C, rn_stream s);
+
+/* grammar corners (resnet.py:122-158 builds any token sequence; none of the shipped configs uses these).
+ * rn_relu_*: nn.ReLU as a layer of its own (:143-145), backward by the sign of the stored output; n elements, a multiple of the 16-byte chunk.
+ * rn_avgpool_*: nn.AvgPool2d(k, s, p) (:77-81; zero padding counts in the divisor, floor output size), NHWC; the backward is a gather.
+ * rn_permute_f32: out[a][c][b] = in[a][b][c] -- Flatten() of an NCHW map with more than one pixel orders the features (c, h, w) (:117-120), the
+ * engine's maps are (h, w, c): the Linear weight goes [O][C][HW] -> [O][HW][C] in front of rn_pool_fc_fwd (HW = 1), its gradient comes back. */
+int rn_relu_fwd(const void* x, void* y, int dtype, int64_t n, rn_stream s);
+int rn_relu_bwd(const void* dy, const void* y, void* dx, int dtype, int64_t n, rn_stream s);
+int rn_avgpool_fwd(const void* x, void* y, int dtype, int N, int H, int W, int C, int k, int stride, int pad, rn_stream s);
+int rn_avgpool_bwd(const void* dy, void* dx, int dtype, int N, int H, int W, int C, int k, int stride, int pad, rn_stream s);
+int rn_permute_f32(const float* in, float* out, int A, int B, int C, rn_stream s);
 
 /* argmax: one byte per output element (window position r*k+s of the first maximum), consumed by the backward */
 int rn_maxpool_fwd(const void* x, void* y, unsigned char* argmax, int dtype, int N, int H, int W, int C, int k, int stride,

@@ -943,6 +943,108 @@ __global__ __launch_bounds__(NT) void amp_check_unscale_kernel(float* __restrict
   if (bad) *found_inf = 1.f;                   // every writer stores the same value
 }
 
+// ---- grammar corners of the architecture spec (resnet.py:122-158 accepts any token sequence; none of the shipped configs uses these) ----
+// a top-level 'a' that follows no 'n' (resnet.py:143-145, nn.ReLU): y = max(x, 0); backward by the sign of the stored output
+template <typename T>
+__global__ __launch_bounds__(NT) void relu_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, long nchunks) {
+  constexpr int CE = Elem<T>::CE;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < nchunks; i += (long)gridDim.x * NT) {
+    Chunk<T> c = load_chunk<T>(x + i * CE);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) c.e[e] = Elem<T>::from_f(fmaxf(Elem<T>::to_f(c.e[e]), 0.f));
+    store_chunk<T>(y + i * CE, c);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void relu_bwd_kernel(const T* __restrict__ dy, const T* __restrict__ y, T* __restrict__ dx, long nchunks) {
+  constexpr int CE = Elem<T>::CE;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < nchunks; i += (long)gridDim.x * NT) {
+    Chunk<T> d = load_chunk<T>(dy + i * CE);
+    const Chunk<T> o = load_chunk<T>(y + i * CE);
+#pragma unroll
+    for (int e = 0; e < CE; ++e) d.e[e] = Elem<T>::to_f(o.e[e]) > 0.f ? d.e[e] : Elem<T>::from_f(0.f);
+    store_chunk<T>(dx + i * CE, d);
+  }
+}
+
+// AvgPool2d(k, s, p) that is not the global pool in front of the classifier (resnet.py:77-81; torch defaults: zero padding counted in the divisor,
+// floor output size), NHWC.  Forward: a thread per (output pixel, channel chunk); backward: gather form, an input pixel sums dy / k^2 of the windows
+// that cover it (no atomics, no zero-fill pass), like maxpool_bwd_kernel.
+template <typename T>
+__global__ __launch_bounds__(NT) void avgpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int P, int Q, int k, int stride, int pad) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE;
+  const long n = (long)N * P * Q * CC;
+  const float div = (float)(k * k);
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const int cg = (int)(i % CC);
+    long pix = i / CC;
+    const int q = (int)(pix % Q); pix /= Q;
+    const int p = (int)(pix % P);
+    const int nn = (int)(pix / P);
+    float acc[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) acc[e] = 0.f;
+    for (int r = 0; r < k; ++r) {
+      const int h = p * stride + r - pad;
+      if ((unsigned)h >= (unsigned)H) continue;
+      for (int t = 0; t < k; ++t) {
+        const int w = q * stride + t - pad;
+        if ((unsigned)w >= (unsigned)W) continue;
+        const Chunk<T> c = load_chunk<T>(x + (((size_t)nn * H + h) * W + w) * C + cg * CE);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) acc[e] += Elem<T>::to_f(c.e[e]);
+      }
+    }
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) o.e[e] = Elem<T>::from_f(acc[e] / div);
+    store_chunk<T>(y + i * CE, o);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(NT) void avgpool_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int P, int Q, int k, int stride, int pad) {
+  constexpr int CE = Elem<T>::CE;
+  const int CC = C / CE;
+  const long n = (long)N * H * W * CC;
+  const float div = (float)(k * k);
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {
+    const int cg = (int)(i % CC);
+    long pix = i / CC;
+    const int w = (int)(pix % W); pix /= W;
+    const int h = (int)(pix % H);
+    const int nn = (int)(pix / H);
+    const int p_lo = max(0, (h + pad - k + stride) / stride), p_hi = min(P - 1, (h + pad) / stride);
+    const int q_lo = max(0, (w + pad - k + stride) / stride), q_hi = min(Q - 1, (w + pad) / stride);
+    float g[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) g[e] = 0.f;
+    for (int p = p_lo; p <= p_hi; ++p)
+      for (int q = q_lo; q <= q_hi; ++q) {
+        const Chunk<T> d = load_chunk<T>(dy + (((size_t)nn * P + p) * Q + q) * C + cg * CE);
+#pragma unroll
+        for (int e = 0; e < CE; ++e) g[e] += Elem<T>::to_f(d.e[e]);
+      }
+    Chunk<T> o;
+#pragma unroll
+    for (int e = 0; e < CE; ++e) o.e[e] = Elem<T>::from_f(g[e] / div);
+    store_chunk<T>(dx + i * CE, o);
+  }
+}
+
+// out[a][c][b] = in[a][b][c]: the Linear weight of an 'f' that flattens an NCHW map of more than one pixel ([O][C][H*W] in the reference's feature
+// order, resnet.py:117-120) against this engine's NHWC features ([O][H*W][C]), and its gradient back
+__global__ __launch_bounds__(NT) void permute_f32_kernel(const float* __restrict__ in, float* __restrict__ out, int A, int B, int Cc) {
+  const long n = (long)A * B * Cc;
+  for (long i = (long)blockIdx.x * NT + threadIdx.x; i < n; i += (long)gridDim.x * NT) {       // i walks the OUTPUT: coalesced stores
+    const int b = (int)(i % B);
+    const long r = i / B;
+    const int c = (int)(r % Cc);
+    const long a = r / Cc;
+    out[i] = in[(a * B + b) * Cc + c];
+  }
+}
+
 inline int ew_grid(long n) {
   long b = (n + NT - 1) / NT;
   if (b > 4096) b = 4096;
@@ -1039,6 +1141,49 @@ static int check_pool(int dtype, int N, int H, int W, int C, int k, int stride, 
   RN_CHECK_ARG(RN_DTYPE_OK(dtype), "%s: bad dtype", who);
   RN_CHECK_ARG(N > 0 && H > 0 && W > 0 && C > 0 && C % (dtype == RN_F32 ? 4 : 8) == 0 && k > 0 && stride > 0 && pad >= 0 && 2 * pad <= k,
                "%s: bad shape", who);
+  return 0;
+}
+
+extern "C" int rn_relu_fwd(const void* x, void* y, int dtype, int64_t n, rn_stream s) {
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype) && x && y && n > 0 && n % (dtype == RN_F32 ? 4 : 8) == 0, "rn_relu_fwd: bad argument");
+  const long nc = n / (dtype == RN_F32 ? 4 : 8);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((relu_fwd_kernel<T_>), dim3(ew_grid(nc)), dim3(NT), 0, as_stream(s), (const T_*)x, (T_*)y, nc));
+  RN_CHECK_LAUNCH("relu_fwd");
+  return 0;
+}
+
+extern "C" int rn_relu_bwd(const void* dy, const void* y, void* dx, int dtype, int64_t n, rn_stream s) {
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype) && dy && y && dx && n > 0 && n % (dtype == RN_F32 ? 4 : 8) == 0, "rn_relu_bwd: bad argument");
+  const long nc = n / (dtype == RN_F32 ? 4 : 8);
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((relu_bwd_kernel<T_>), dim3(ew_grid(nc)), dim3(NT), 0, as_stream(s), (const T_*)dy, (const T_*)y, (T_*)dx, nc));
+  RN_CHECK_LAUNCH("relu_bwd");
+  return 0;
+}
+
+extern "C" int rn_avgpool_fwd(const void* x, void* y, int dtype, int N, int H, int W, int C, int k, int stride, int pad, rn_stream s) {
+  if (int e = check_pool(dtype, N, H, W, C, k, stride, pad, "rn_avgpool_fwd")) return e;
+  RN_CHECK_ARG(x && y && H + 2 * pad >= k && W + 2 * pad >= k, "rn_avgpool_fwd: bad argument");
+  const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
+  const long n = (long)N * P * Q * (C / (dtype == RN_F32 ? 4 : 8));
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((avgpool_fwd_kernel<T_>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const T_*)x, (T_*)y, N, H, W, C, P, Q, k, stride, pad));
+  RN_CHECK_LAUNCH("avgpool_fwd");
+  return 0;
+}
+
+extern "C" int rn_avgpool_bwd(const void* dy, void* dx, int dtype, int N, int H, int W, int C, int k, int stride, int pad, rn_stream s) {
+  if (int e = check_pool(dtype, N, H, W, C, k, stride, pad, "rn_avgpool_bwd")) return e;
+  RN_CHECK_ARG(dy && dx && H + 2 * pad >= k && W + 2 * pad >= k, "rn_avgpool_bwd: bad argument");
+  const int P = (H + 2 * pad - k) / stride + 1, Q = (W + 2 * pad - k) / stride + 1;
+  const long n = (long)N * H * W * (C / (dtype == RN_F32 ? 4 : 8));
+  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((avgpool_bwd_kernel<T_>), dim3(ew_grid(n)), dim3(NT), 0, as_stream(s), (const T_*)dy, (T_*)dx, N, H, W, C, P, Q, k, stride, pad));
+  RN_CHECK_LAUNCH("avgpool_bwd");
+  return 0;
+}
+
+extern "C" int rn_permute_f32(const float* in, float* out, int A, int B, int C, rn_stream s) {
+  RN_CHECK_ARG(in && out && in != out && A > 0 && B > 0 && C > 0, "rn_permute_f32: bad argument");
+  hipLaunchKernelGGL(permute_f32_kernel, dim3(ew_grid((long)A * B * C)), dim3(NT), 0, as_stream(s), in, out, A, B, C);
+  RN_CHECK_LAUNCH("permute_f32");
   return 0;
 }
 

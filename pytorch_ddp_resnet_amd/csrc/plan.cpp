@@ -102,7 +102,7 @@ extern "C" int rn_plan_create(const rn_op* ops, int n_ops, int n_bufs, int dtype
   RN_CHECK_ARG(ops && out && n_ops > 0 && n_bufs > 0, "rn_plan_create: bad argument");
   RN_CHECK_ARG(RN_DTYPE_OK(dtype), "rn_plan_create: bad dtype %d", dtype);
   for (int i = 0; i < n_ops; ++i) {
-    RN_CHECK_ARG(ops[i].kind >= RN_OP_STEM_FWD && ops[i].kind <= RN_OP_UNPACK_STEM_DW_S2D, "rn_plan_create: op %d has unknown kind %d", i, ops[i].kind);
+    RN_CHECK_ARG(ops[i].kind >= RN_OP_STEM_FWD && ops[i].kind <= RN_OP_PERMUTE_F32, "rn_plan_create: op %d has unknown kind %d", i, ops[i].kind);
     for (int j = 0; j < RN_OP_NBUF; ++j)
       RN_CHECK_ARG(ops[i].buf[j] >= -1 && ops[i].buf[j] < n_bufs, "rn_plan_create: op %d buffer index %d out of range", i, ops[i].buf[j]);
   }
@@ -342,6 +342,16 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
       return rn_unpack_stem_dw_s2d((const float*)B(0), (float*)B(1), d[0], d[1], (o.flags & RN_F_ACCUM) ? 1 : 0, s);
     case RN_OP_UNPACK_STEM_DW:
       return rn_unpack_stem_dw((const float*)B(0), (float*)B(1), d[0], d[1], d[2], d[3], (o.flags & RN_F_ACCUM) ? 1 : 0, s);
+    case RN_OP_RELU_FWD:               /* x y | n_lo n_hi */
+      return rn_relu_fwd(B(0), B(1), dt, ((int64_t)d[1] << 31) | (int64_t)d[0], s);
+    case RN_OP_RELU_BWD:               /* dy y dx | n_lo n_hi */
+      return rn_relu_bwd(B(0), B(1), B(2), dt, ((int64_t)d[1] << 31) | (int64_t)d[0], s);
+    case RN_OP_AVGPOOL_FWD:            /* x y | N H W C k stride pad */
+      return rn_avgpool_fwd(B(0), B(1), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], s);
+    case RN_OP_AVGPOOL_BWD:            /* dy dx | N H W C k stride pad */
+      return rn_avgpool_bwd(B(0), B(1), dt, d[0], d[1], d[2], d[3], d[4], d[5], d[6], s);
+    case RN_OP_PERMUTE_F32:            /* in out | A B C */
+      return rn_permute_f32((const float*)B(0), (float*)B(1), d[0], d[1], d[2], s);
     default:
       rn_set_error("rn_plan_run: unknown op kind %d", o.kind);
       return 1;

@@ -16,7 +16,7 @@ RES_NONE, RES_SAME, RES_DOWN2PAD, RES_UP2 = 0, 1, 2, 3
  OP_POOL_FC_FWD, OP_POOL_FC_BWD, OP_MAXPOOL_BWD, OP_BN_BWD_REDUCE, OP_BN_BWD_FINALIZE, OP_BN_BWD_APPLY,
  OP_CONV_DGRAD, OP_CONV_WGRAD, OP_STEM_WGRAD, OP_DROPOUT_BWD, OP_SOFTMAX_CE, OP_ZERO, OP_ADD_RES, OP_IMG_TO_NHWC,
  OP_PACK_STEM_W, OP_UNPACK_STEM_DW, OP_BN_POOL_FWD, OP_BN_POOL_BWD_REDUCE, OP_BN_POOL_BWD_APPLY, OP_IMG_TO_S2D, OP_PACK_STEM_W_S2D,
- OP_UNPACK_STEM_DW_S2D) = range(1, 31)
+ OP_UNPACK_STEM_DW_S2D, OP_RELU_FWD, OP_RELU_BWD, OP_AVGPOOL_FWD, OP_AVGPOOL_BWD, OP_PERMUTE_F32) = range(1, 36)
 
 OP_NAMES = {v: k for k, v in list(globals().items()) if k.startswith('OP_') and isinstance(v, int)}
 
@@ -57,6 +57,11 @@ OP_FIELDS = {
     OP_IMG_TO_S2D:         ('x out', 'N C H W', ''),
     OP_PACK_STEM_W_S2D:    ('w w_s2d', 'K C', ''),
     OP_UNPACK_STEM_DW_S2D: ('dw_s2d dw', 'K C', ''),
+    OP_RELU_FWD:           ('x y', 'n_lo n_hi', ''),
+    OP_RELU_BWD:           ('dy y dx', 'n_lo n_hi', ''),
+    OP_AVGPOOL_FWD:        ('x y', 'N H W C k stride pad', ''),
+    OP_AVGPOOL_BWD:        ('dy dx', 'N H W C k stride pad', ''),
+    OP_PERMUTE_F32:        ('in out', 'A B C', ''),
 }
 
 GEOM = 'N H W C P Q K R S stride pad'.split()

@@ -206,7 +206,7 @@ class Lowering:
         self._packed[key] = (wf, wd)
         return wf, wd
 
-    def conv_fwd(self, x: T, key, K, k, stride, pad, name, res: Optional[T] = None, res_mode=ir.RES_NONE, need_dgrad=True, stats=True):
+    def conv_fwd(self, x: T, key, K, k, stride, pad, name, res: Optional[T] = None, res_mode=ir.RES_NONE, need_dgrad=True, stats=True, bias=-1):
         """stats: the epilogue also reduces the per-channel (sum, sum^2) of the stored output -- the batch statistics of
         the BatchNorm that reads it next (train mode) -- so that layer needs no statistics pass."""
         g = self.geom(x, K, k, stride, pad)
@@ -217,7 +217,7 @@ class Lowering:
             rows = conv_stats_rows(g)
             part = self.f32(name + ':stats', (rows, 2, K))
             self._stats_of[y.s] = (part, rows)
-        self.fwd.append(Op(ir.OP_CONV_FWD, buf=dict(x=x.s, w_fwd=wf, y=y.s, res=res.s if res else -1, stats=part),
+        self.fwd.append(Op(ir.OP_CONV_FWD, buf=dict(x=x.s, w_fwd=wf, y=y.s, res=res.s if res else -1, stats=part, bias=bias),
                            dim=dict(g, res_mode=res_mode, res_C=res.C if res else 0), note=key))
         return y, g, wd
 
@@ -458,9 +458,35 @@ class Lowering:
         while idx < len(comps):
             c = comps[idx]
             pre = f'_architecture.{idx}'
-            if c.kind == 'conv':
-                if cur is not None:
-                    raise NotImplementedError("a top-level convolution after the first component is not on the accelerated path")
+            if c.kind == 'conv' and cur is not None:
+                # a top-level convolution deeper in the network (resnet.py:126-131 builds Conv2d(i, o, k, s, p) with bias wherever a 'c' token stands):
+                # the block convolutions' kernels with the bias in the epilogue; the bias gradient is the per-channel sum of dy
+                k, s, pd = c.args
+                ce = 4 if self.fp32 else 8
+                if c.cin != cur.C:
+                    raise ValueError(f"{pre}: convolution expects {c.cin} input channels, the map has {cur.C}")
+                if c.cin % ce or c.cout % ce:
+                    raise NotImplementedError(f"{pre}: channel counts must be multiples of {ce} on the accelerated path")
+                w_key = pre + '.weight'
+                self.param(w_key, (c.cout, k, k, c.cin))
+                b_ = self.param(pre + '.bias', (c.cout,))
+                y, g, wd = self.conv_fwd(cur, w_key, c.cout, k, s, pd, pre + ':y', bias=b_)
+
+                def conv_back(dy: T, ops, x=cur, g=g, wd=wd, pre=pre, w_key=w_key):
+                    dx = self.conv_bwd(ops, x, dy, w_key, g, wd, pre + ':dx')
+                    K = g['K']
+                    db = self.grad(pre + '.bias', (K,))
+                    s2, sq = self.f32(pre + ':dbsum', (2, K)), self.f32(pre + ':dbsq', (K,))          # by-products, unused
+                    nblk = bn_partials(dy.M, K)
+                    part = self.f32(pre + ':dbpartial', (nblk, 2, K))
+                    ops.append(Op(ir.OP_BN_STATS, buf=dict(x=dy.s, partial=part), dim=dict(M=dy.M, C=K, nblk=nblk), note=pre))
+                    ops.append(Op(ir.OP_BN_BWD_FINALIZE, buf=dict(partial=part, dsum=s2, dgamma=sq, dbeta=db, fold=self.fold(pre + ':dbfold', nblk, K)),
+                                  dim=dict(nblk=nblk, C=K), note=pre))
+                    self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
+                    return dx
+                self._back.append(conv_back)
+                cur = y
+            elif c.kind == 'conv':
                 k, s, pd = c.args
                 xin = self.slot('x', 'input', (self.N, c.cin, self.H, self.W), 'f32')
                 named['x'] = xin
@@ -616,7 +642,18 @@ class Lowering:
                 if relu:
                     idx += 1
             elif c.kind == 'act':
-                raise NotImplementedError("a standalone 'a' that does not follow 'n' is not on the accelerated path")
+                # an 'a' that follows no 'n' (resnet.py:143-145): ReLU as a pass of its own; the backward goes by the sign of the stored output
+                y = self.act(pre + ':y', cur.N, cur.H, cur.W, cur.C)
+                n_el = cur.M * cur.C
+                nd = dict(n_lo=n_el & 0x7fffffff, n_hi=n_el >> 31)
+                self.fwd.append(Op(ir.OP_RELU_FWD, buf=dict(x=cur.s, y=y.s), dim=nd, note=pre))
+
+                def act_back(dy: T, ops, y=y, pre=pre, nd=nd):
+                    dx = self.act(pre + ':dx', y.N, y.H, y.W, y.C)
+                    ops.append(Op(ir.OP_RELU_BWD, buf=dict(dy=dy.s, y=y.s, dx=dx.s), dim=nd, note=pre))
+                    return dx
+                self._back.append(act_back)
+                cur = y
             elif c.kind == 'maxpool':
                 k, s, pd = c.args
                 P, Q = (cur.H + 2 * pd - k) // s + 1, (cur.W + 2 * pd - k) // s + 1
@@ -635,7 +672,22 @@ class Lowering:
                 k, s, pd = c.args
                 nxt = comps[idx + 1] if idx + 1 < len(comps) else None
                 if not (nxt is not None and nxt.kind == 'fc' and pd == 0 and k == cur.H == cur.W):
-                    raise NotImplementedError("only a global average pool directly followed by 'f' is on the accelerated path")
+                    # any other AvgPool2d(k, s, p) (resnet.py:77-81): a pooling pass of its own (the global pool in front of 'f' is fused with the classifier below)
+                    if 2 * pd > k or cur.H + 2 * pd < k or cur.W + 2 * pd < k:
+                        raise ValueError(f"{pre}: AvgPool2d({k}, {s}, {pd}) does not fit a {cur.H} x {cur.W} map")       # torch raises on both
+                    P, Q = (cur.H + 2 * pd - k) // s + 1, (cur.W + 2 * pd - k) // s + 1
+                    y = self.act(pre + ':y', cur.N, P, Q, cur.C)
+                    d = dict(N=cur.N, H=cur.H, W=cur.W, C=cur.C, k=k, stride=s, pad=pd)
+                    self.fwd.append(Op(ir.OP_AVGPOOL_FWD, buf=dict(x=cur.s, y=y.s), dim=d, note=pre))
+
+                    def ap_back(dy: T, ops, x=cur, d=d, pre=pre):
+                        dx = self.act(pre + ':dx', x.N, x.H, x.W, x.C)
+                        ops.append(Op(ir.OP_AVGPOOL_BWD, buf=dict(dy=dy.s, dx=dx.s), dim=d, note=pre))
+                        return dx
+                    self._back.append(ap_back)
+                    cur = y
+                    idx += 1
+                    continue
                 fpre = f'_architecture.{idx + 1}'
                 O = nxt.cout
                 if nxt.cin != cur.C:
@@ -658,14 +710,44 @@ class Lowering:
                 cur = None
                 idx += 1
             elif c.kind == 'fc':
-                raise NotImplementedError("'f' without a preceding global 'ap' is not on the accelerated path")
+                # 'f' on a map that no global 'ap' has pooled (resnet.py:117-120: Flatten() of the NCHW map, then Linear): the classifier kernels with
+                # one "pixel" of H*W*C features.  The reference orders the features (c, h, w), the engine's map is (h, w, c): the weight is read through
+                # a permuted copy and its gradient is permuted back (nothing to do for a 1 x 1 map).
+                if cur is None or idx + 1 != len(comps):
+                    raise NotImplementedError("'f' must be the last component, on a feature map")
+                HW, Cf, O = cur.H * cur.W, cur.H * cur.W * cur.C, c.cout
+                if c.cin != Cf:
+                    raise ValueError(f"fc input width {c.cin} does not match the {cur.C} x {cur.H} x {cur.W} map")
+                w, b = self.param(pre + '.1.weight', (O, Cf)), self.param(pre + '.1.bias', (O,))
+                wp = w
+                if HW > 1:
+                    wp = self.f32(pre + ':wperm', (O, Cf))
+                    self.fwd.append(Op(ir.OP_PERMUTE_F32, buf={'in': w, 'out': wp}, dim=dict(A=O, B=cur.C, C=HW), note=pre))
+                feat = self.f32('feat', (cur.N, Cf))
+                logits = self.slot('logits', 'f32', (cur.N, O), 'f32')
+                named['logits'] = logits
+                d = dict(N=cur.N, HW=1, C=Cf, O=O)
+                self.fwd.append(Op(ir.OP_POOL_FC_FWD, buf=dict(x=cur.s, w=wp, b=b, feat=feat, logits=logits), dim=d, note=pre))
+
+                def flat_fc_back(_, ops, x=cur, d=d, feat=feat, wp=wp, pre=pre, HW=HW, O=O, Cf=Cf):
+                    dl = named['dlogits']
+                    dw, db = self.grad(pre + '.1.weight', (O, Cf)), self.grad(pre + '.1.bias', (O,))
+                    dwp = self.f32(pre + ':dwperm', (O, Cf)) if HW > 1 else dw
+                    dx = self.act(pre + ':dx', x.N, x.H, x.W, x.C)
+                    ops.append(Op(ir.OP_POOL_FC_BWD, buf=dict(dlogits=dl, feat=feat, w=wp, dx=dx.s, dw=dwp, db=db), dim=d, note=pre))
+                    if HW > 1:
+                        ops.append(Op(ir.OP_PERMUTE_F32, buf={'in': dwp, 'out': dw}, dim=dict(A=O, B=HW, C=x.C), note=pre))
+                    self.bwd_hooks.append(Hook(len(ops), 'grad_ready', arg=len(self.grad_order) - 1))
+                    return dx
+                self._back.append(flat_fc_back)
+                cur = None
             else:
                 for b_ in range(c.depth):
                     cin = c.cin if b_ == 0 else c.cout
                     cur = self.block(f'{pre}.{b_}', c.kind, cin, c.down and b_ == 0, cur)
             idx += 1
         if 'logits' not in named:
-            raise NotImplementedError("the network must end in 'apK,1,0 fI,O'")
+            raise NotImplementedError("the network must end in a classifier ('fI,O')")
         n_logits = self.slots[named['logits']].shape
         if self.with_loss:
             named['labels'] = self.slot('labels', 'labels', (n_logits[0],), 'i64')

@@ -357,6 +357,28 @@ class NumpyPlan:
             else:
                 v = B('dw_s2d').reshape(K, 256)[:, idx.reshape(-1)].reshape(K, 7, 7, C)
                 put('dw', v + B('dw').reshape(v.shape) if op.flags & ir.F_ACCUM else v)
+        elif k == ir.OP_RELU_FWD:
+            put('y', np.maximum(B('x'), 0))
+        elif k == ir.OP_RELU_BWD:
+            put('dx', B('dy') * (B('y') > 0))
+        elif k in (ir.OP_AVGPOOL_FWD, ir.OP_AVGPOOL_BWD):          # AvgPool2d(k, s, p), zero padding counted in the divisor (torch's default)
+            kk, st, pd, H, W = d['k'], d['stride'], d['pad'], d['H'], d['W']
+            P, Q = (H + 2 * pd - kk) // st + 1, (W + 2 * pd - kk) // st + 1
+            if k == ir.OP_AVGPOOL_FWD:
+                xp = np.pad(B('x'), ((0, 0), (pd, pd), (pd, pd), (0, 0)))
+                y = np.zeros((d['N'], P, Q, d['C']), dtype=xp.dtype)
+                for r in range(kk):
+                    for s_ in range(kk):
+                        y += xp[:, r:r + st * (P - 1) + 1:st, s_:s_ + st * (Q - 1) + 1:st, :]
+                put('y', y / (kk * kk))
+            else:
+                dxp = np.zeros((d['N'], H + 2 * pd, W + 2 * pd, d['C']), dtype=B('dy').dtype)
+                for r in range(kk):
+                    for s_ in range(kk):
+                        dxp[:, r:r + st * (P - 1) + 1:st, s_:s_ + st * (Q - 1) + 1:st, :] += B('dy') / (kk * kk)
+                put('dx', dxp[:, pd:pd + H, pd:pd + W, :])
+        elif k == ir.OP_PERMUTE_F32:
+            put('out', np.transpose(B('in').reshape(d['A'], d['B'], d['C']), (0, 2, 1)))
         elif k == ir.OP_ZERO:
             self.bufs[op.buf['dst']][...] = 0
         else:

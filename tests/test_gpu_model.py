@@ -140,6 +140,32 @@ def test_all_block_combinations_fp32(kind, preact, proj, train):
             assert rel(b, tst[k]) < 1e-4, k
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'fp16'])
+@pytest.mark.parametrize('train', [True, False])
+@pytest.mark.parametrize('spec,preact', __import__('test_lowering').GRAMMAR_CORNERS)
+def test_grammar_corners(spec, preact, train, dtype):
+    """token sequences outside the shipped configs (resnet.py:122-158 builds any of them): a standalone 'a', a second top-level convolution, an AvgPool2d
+    that is not the global pool, 'f' on a map of more than one pixel -- engine vs the torch-CPU port of the reference, logits, every gradient, BN buffers"""
+    cfg = dict(spec=spec, preact=preact, use_proj=True)
+    st = fill_state(param_shapes(spec, preact, True), 11)
+    x, y = fill((4, 3, 8, 8), 110), fill_labels(4, 10, 111)
+    m = build(cfg, st, dtype)
+    m.train(train)
+    logits = m(torch.from_numpy(x).cuda())
+    torch.nn.functional.cross_entropy(logits, torch.from_numpy(y).cuda()).backward()
+    tst = tm.make_trainable({k: torch.from_numpy(v.copy()) for k, v in st.items()})
+    lg, _, grads = tm.train_step(tm.TorchResNet(spec, preact, True), tst, torch.from_numpy(x), torch.from_numpy(y), train=train)
+    tol_l, tol_g = (1e-4, 1e-3) if dtype == 'fp32' else (2e-2, 1e-1)      # fp16: 11-bit storage of every activation and gradient on 4 images
+    assert rel(logits, lg) < tol_l
+    scale = max(float(v.abs().max()) for v in grads.values())
+    for k, p in m.named_parameters():
+        assert p.grad is not None and p.grad.shape == grads[k].shape, k
+        assert (p.grad.cpu() - grads[k]).abs().max().item() < tol_g * scale, k
+    if train:
+        for k, b_ in m.named_buffers():
+            assert rel(b_, tst[k]) < (1e-4 if dtype == 'fp32' else 2e-2), k
+
+
 @pytest.mark.parametrize('preact', [False, True])
 def test_dropout_matches_plan_interpreter(preact):
     """p = 0.3: the engine's counter-based masks == the executable spec (np_interp) fed with the same step seed."""

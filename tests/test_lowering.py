@@ -165,9 +165,47 @@ def test_plan_structure_wrn():
         op.packed()
 
 
+# token sequences the reference's grammar accepts (resnet.py:122-158) that none of the shipped configs uses: an 'a' that follows no 'n', a second
+# top-level convolution, an AvgPool2d that is not the global pool in front of 'f' (with and without padding), 'f' on an unpooled / partly pooled map
+# (Flatten() orders the features (c, h, w); the engine's maps are (h, w, c))
+GRAMMAR_CORNERS = [
+    ('c3,16,3,1,1 a r1 ap8,1,0 fc16,10', False),
+    ('c3,16,3,1,1 n a c16,32,3,2,1 n a r1 ap4,1,0 fc32,10', False),
+    ('c3,16,3,1,1 r1 n a c16,16,1,1,0 a ap8,1,0 fc16,10', True),
+    ('c3,16,3,1,1 n a r1 ap2,2,0 fc256,10', False),
+    ('c3,16,3,1,1 r1 n a fc1024,10', True),
+    ('c3,16,3,1,1 n a ap3,2,1 r1 ap4,1,0 fc16,10', False),
+    ('c3,16,3,1,1 n a mp3,2,1 a ap2,1,0 fc144,10', False),
+]
+
+
+@pytest.mark.parametrize('spec,preact', GRAMMAR_CORNERS)
+@pytest.mark.parametrize('train', [True, False])
+def test_plan_grammar_corners(spec, preact, train):
+    cfg = dict(spec=spec, preact=preact, use_proj=True)
+    st = fill_state(param_shapes(spec, preact, True), 11)
+    x, y = fill((4, 3, 8, 8), 110), fill_labels(4, 10, 111)
+    plan, npl, logits = run_plan(cfg, st, x, y, train=train)
+    for op in plan.ops:
+        op.packed()
+    tst = tm.make_trainable({k: torch.from_numpy(v.astype(np.float64) if v.dtype.kind == 'f' else v.copy()) for k, v in st.items()})
+    lg, m, grads = tm.train_step(tm.TorchResNet(spec, preact, True), tst, torch.from_numpy(x).double(), torch.from_numpy(y), train=train)
+    assert rel_err(logits, lg.numpy()) < 1e-9
+    mine = npl.grads()
+    assert set(mine) == set(grads)
+    scale = max(float(v.abs().max()) for v in grads.values())
+    for k, v in grads.items():
+        assert np.abs(mine[k].reshape(v.shape) - v.numpy()).max() < 1e-9 * scale + 1e-12, k
+    if train:
+        for k, v in npl.state().items():
+            assert rel_err(v, tst[k].detach().numpy()) < 1e-9, k
+
+
 def test_unsupported_patterns_fail_loudly():
     with pytest.raises(NotImplementedError):
-        lower('c3,16,3,1,1 a r1 ap8,1,0 fc16,10', False, False, 0.0, 2, 8, 8)
+        lower('c3,16,3,1,1 n a ap8,1,0 fc16,32 fc32,10', False, False, 0.0, 2, 8, 8)        # a classifier that is not the last component
+    with pytest.raises(ValueError):
+        lower('c3,16,3,1,1 n a r1 fc16,10', False, False, 0.0, 2, 8, 8)                     # 'f' narrower than the flattened map
     with pytest.raises(ValueError):
         lower('c3,16,3,1,1 x1 ap8,1,0 fc16,10', False, False, 0.0, 2, 8, 8)
     with pytest.raises(AttributeError):
