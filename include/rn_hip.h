@@ -247,6 +247,20 @@ typedef struct rn_reduce_desc {
 } rn_reduce_desc;
 int rn_conv_wgrad_splits(const rn_conv_geom* g, int dtype, int flags);
 int rn_wgrad_reduce_batch(const rn_reduce_desc* descs, int n, rn_stream s);
+/* Thin networks (ResNet-20 / ResNet-v2-164: ~165 weight gradients of ~10 us per step): the slab-writing launches of up to RN_WGRAD_BATCH_MAX layers
+ * that share a tile shape as ONE grid.  rn_conv_wgrad_batch_key: > 0 when this geometry's weight gradient may ride in such a launch, with others of
+ * the same key (3 x 3 / 1 x 1 block convolutions whose slab sums are deferrable, not forked); 0: it launches alone.  Every record writes
+ * [rn_conv_wgrad_splits][K*R*S*C] slabs at `slabs`, exactly as rn_conv_wgrad(..., RN_F_DEFER_REDUCE) does (bit-identical); rn_wgrad_reduce_batch sums them. */
+#define RN_WGRAD_BATCH_MAX 16
+typedef struct rn_wgrad_desc {
+  const void* x;        /* the layer's input,  NHWC compute dtype */
+  const void* dy;       /* the gradient of its output             */
+  float* slabs;
+  rn_conv_geom g;
+  int32_t flags;
+} rn_wgrad_desc;
+int rn_conv_wgrad_batch_key(const rn_conv_geom* g, int dtype, int flags);
+int rn_conv_wgrad_batch(const rn_wgrad_desc* descs, int n, int dtype, rn_stream s);
 
 /* BatchNorm over a [M, C] view.  partial: [nblk][2][C] fp32 (sum, sum of squares) of nblk row slabs; the caller picks
  * nblk (one workgroup per slab) */

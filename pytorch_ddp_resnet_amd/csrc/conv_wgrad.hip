@@ -122,8 +122,9 @@ constexpr int padded_row(int bytes) { return bytes % 128 == 64 ? bytes : bytes +
 
 // block tile (2*TI*16) x (2*TJ*16): 4 waves as 2x2, each TI x TJ MFMA tiles of 16x16
 // IC: im2col mode (the taps are folded into the column dimension; see WgradArgs::im2col)
-template <typename T, int TI, int TJ, bool IC>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+// (the body is a device function over the argument record and the workgroup's index: the batched launch below runs it over one record of several)
+template <typename T, int TI, int TJ, bool IC, typename ARGS>
+__device__ __forceinline__ void wgrad_tile(const ARGS& a, const int wg, const int nwg) {
   constexpr int CE = Elem<T>::CE;
   constexpr int BK_ = 2 * TI * 16, BC_ = 2 * TJ * 16;
   constexpr int ROWA = padded_row(BK_ * (int)sizeof(T)), ROWB = padded_row(BC_ * (int)sizeof(T));
@@ -144,9 +145,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
   // work order: tap fastest, then C tile, K tile, pixel split slowest -- the workgroups that read the same dy / x rows are
   // neighbours.  With the XCD remap (consecutive work items on ONE XCD instead of round-robin over the 8) their re-reads
   // hit that XCD's L2 instead of going to the memory side 9 times (one per tap).
-  int b = blockIdx.x;
+  int b = wg;
   if (a.xcd_remap) {
-    const int nwg = gridDim.x, xcd = b & 7, q = nwg >> 3, r = nwg & 7;
+    const int xcd = b & 7, q = nwg >> 3, r = nwg & 7;
     b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
   const int t = b % a.nt; b /= a.nt;
@@ -285,6 +286,44 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         else if (c < a.C) out[((size_t)k * a.RS + t) * a.C + c] = acc[i][j][r];
       }
     }
+}
+
+template <typename T, int TI, int TJ, bool IC>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) { wgrad_tile<T, TI, TJ, IC>(a, (int)blockIdx.x, (int)gridDim.x); }
+
+// Batched launch for thin networks (ResNet-20, ResNet-v2-164: ~165 weight gradients per step, each a ~10 us launch whose ramp, tail round and launch gap
+// are half of it): the weight gradients of up to WB_MAX layers that share a tile shape run as ONE grid.  Record i owns the block range
+// [first_block[i], first_block[i] + nwg[i]) -- starts are multiples of 8, so blockIdx & 7 is still the workgroup's XCD inside a record and the XCD remap
+// of the body holds; the padding blocks exit.  Same body, same splits, same slabs as the single launches: bit-identical gradients.  The records are the
+// 3 x 3 / 1 x 1 block convolutions: nine taps, so sixteen records fit the 4 KiB kernel-argument segment.
+constexpr int WB_MAX = 16, WB_TAPS = 9;
+struct WgradArgsS {
+  const void* x;
+  const void* dy;
+  float* out;
+  int N, H, W, C, P, Q, K;
+  int stride, RS, nt;
+  int M;
+  int splits, rows_per_split;
+  int kt, ct;
+  unsigned magic_pq, magic_q;
+  int xcd_remap, im2col;
+  int dh[WB_TAPS], dw[WB_TAPS];
+};
+struct WgradBatch {
+  int n;
+  int first_block[WB_MAX], nwg[WB_MAX];
+  WgradArgsS a[WB_MAX];
+};
+static_assert(sizeof(WgradBatch) <= 4096, "kernel-argument segment");
+
+template <typename T, int TI, int TJ>
+__global__ __launch_bounds__(256) void wgrad_batch_kernel(const WgradBatch wb) {
+  int i = 0;
+  while (i + 1 < wb.n && (int)blockIdx.x >= wb.first_block[i + 1]) ++i;         // wave-uniform
+  const int wg = (int)blockIdx.x - wb.first_block[i];
+  if (wg >= wb.nwg[i]) return;
+  wgrad_tile<T, TI, TJ, false>(wb.a[i], wg, wb.nwg[i]);
 }
 
 // (A three-taps-per-workgroup form -- dy loaded once for a row of taps, x as one run of 66 pixels read shifted, padding by redirecting
@@ -492,7 +531,49 @@ template <typename T> int dispatch_w(const WgradArgs& a, int bk, int bc, hipStre
   return 1;
 }
 
+template <typename T> int dispatch_wb(const WgradBatch& wb, int grid, int bk, int bc, hipStream_t s) {
+#define WB_CASE(BK, BC) if (bk == BK && bc == BC) { hipLaunchKernelGGL((wgrad_batch_kernel<T, BK / 32, BC / 32>), dim3(grid), dim3(256), 0, s, wb); RN_CHECK_LAUNCH("wgrad_batch"); return 0; }
+  WB_CASE(160, 160) WB_CASE(160, 128) WB_CASE(160, 64) WB_CASE(160, 32)
+  WB_CASE(128, 160) WB_CASE(128, 128) WB_CASE(128, 64) WB_CASE(128, 32)
+  WB_CASE(64, 160) WB_CASE(64, 128) WB_CASE(64, 64) WB_CASE(64, 32)
+  WB_CASE(32, 160) WB_CASE(32, 128) WB_CASE(32, 64) WB_CASE(32, 32)
+#undef WB_CASE
+  rn_set_error("wgrad batch: no tile %dx%d", bk, bc);
+  return 1;
+}
+
 }  // namespace
+
+// the kernel choice and the argument record of one weight gradient (everything but the output pointer): rn_conv_wgrad and the batched launch share it
+struct WgradSel { int w8, bk, bc; bool ic; };
+static void wgrad_fill(WgradArgs& a, WgradSel& sel, const void* x, const void* dy, const rn_conv_geom* g, int dtype, int flags) {
+  const int ce = dtype == RN_F32 ? 4 : 8;
+  sel.w8 = rn_wgrad8_splits(g, dtype);                  // > 0: the eight-phase kernel with that many pixel splits (its slabs take the same reduction)
+  const bool ic = use_im2col(g, ce);
+  const int bk = pick_tile(g->K), bc = col_tile(g, ic, bk);
+  sel.ic = ic; sel.bk = bk; sel.bc = bc;
+  a.im2col = ic ? 1 : 0;
+  a.xcd_remap = (g_rn_variant & 4) ? 0 : 1;
+  {
+    const unsigned long long pq = (unsigned long long)g->P * g->Q;
+    a.magic_pq = pq <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / pq);
+    a.magic_q = g->Q <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned)g->Q);
+  }
+  a.x = x; a.dy = dy;
+  a.N = g->N; a.H = g->H; a.W = g->W; a.C = g->C; a.P = g->P; a.Q = g->Q; a.K = g->K;
+  a.stride = g->stride; a.RS = g->R * g->S; a.nt = ic ? 1 : a.RS;
+  for (int r = 0; r < g->R; ++r)
+    for (int t = 0; t < g->S; ++t) { a.dh[r * g->S + t] = r - g->pad; a.dw[r * g->S + t] = t - g->pad; }
+  a.M = g->N * g->P * g->Q;
+  // A FORKED weight gradient (side stream, beside the data-gradient / BatchNorm chain) is sized to 7/8 of a resident round: a
+  // one-round grid retires no workgroup until it ends, so the chain's tiny finalize kernels waited ~19 us each for a slot
+  // (26 per WRN-28-10 step); with an eighth of the slots left free they dispatch at once.  rn_set_variant 1 << 24: full round.
+  const int round = (g_rn_variant & (1 << 23)) ? 512 : wgrad_capacity(bk, bc, ce);       // 1 << 23: the fixed 512-workgroup round (A/B)
+  const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? round / 8 * 7 : round;
+  a.splits = sel.w8 > 0 ? sel.w8 : wgrad_splits(g, bk, bc, ic, capacity);
+  a.rows_per_split = ((a.M + a.splits - 1) / a.splits + 31) / 32 * 32;
+  a.kt = cdiv(g->K, bk); a.ct = cdiv(ic ? g->R * g->S * g->C : g->C, bc);
+}
 
 extern "C" size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g) {
   if (!g) return 0;
@@ -516,31 +597,10 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   RN_CHECK_ARG(g->C % ce == 0 && g->K % ce == 0, "rn_conv_wgrad: C=%d, K=%d must be multiples of %d", g->C, g->K, ce);
   RN_CHECK_ARG(g->R == g->S && g->R * g->S <= MAX_TAPS, "rn_conv_wgrad: kernel %dx%d unsupported", g->R, g->S);
   RN_CHECK_ARG((long)g->N * g->P * g->Q < (1L << 31), "rn_conv_wgrad: too many pixels");
-  const int w8 = rn_wgrad8_splits(g, dtype);            // > 0: the eight-phase kernel with that many pixel splits (its slabs take the same reduction)
-  const bool ic = use_im2col(g, ce);
-  const int bk = pick_tile(g->K), bc = col_tile(g, ic, bk);
+  WgradSel sel;
   WgradArgs a{};
-  a.im2col = ic ? 1 : 0;
-  a.xcd_remap = (g_rn_variant & 4) ? 0 : 1;
-  {
-    const unsigned long long pq = (unsigned long long)g->P * g->Q;
-    a.magic_pq = pq <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / pq);
-    a.magic_q = g->Q <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / (unsigned)g->Q);
-  }
-  a.x = x; a.dy = dy;
-  a.N = g->N; a.H = g->H; a.W = g->W; a.C = g->C; a.P = g->P; a.Q = g->Q; a.K = g->K;
-  a.stride = g->stride; a.RS = g->R * g->S; a.nt = ic ? 1 : a.RS;
-  for (int r = 0; r < g->R; ++r)
-    for (int t = 0; t < g->S; ++t) { a.dh[r * g->S + t] = r - g->pad; a.dw[r * g->S + t] = t - g->pad; }
-  a.M = g->N * g->P * g->Q;
-  // A FORKED weight gradient (side stream, beside the data-gradient / BatchNorm chain) is sized to 7/8 of a resident round: a
-  // one-round grid retires no workgroup until it ends, so the chain's tiny finalize kernels waited ~19 us each for a slot
-  // (26 per WRN-28-10 step); with an eighth of the slots left free they dispatch at once.  rn_set_variant 1 << 24: full round.
-  const int round = (g_rn_variant & (1 << 23)) ? 512 : wgrad_capacity(bk, bc, ce);       // 1 << 23: the fixed 512-workgroup round (A/B)
-  const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? round / 8 * 7 : round;
-  a.splits = w8 > 0 ? w8 : wgrad_splits(g, bk, bc, ic, capacity);
-  a.rows_per_split = ((a.M + a.splits - 1) / a.splits + 31) / 32 * 32;
-  a.kt = cdiv(g->K, bk); a.ct = cdiv(ic ? g->R * g->S * g->C : g->C, bc);
+  wgrad_fill(a, sel, x, dy, g, dtype, flags);
+  const int w8 = sel.w8, bk = sel.bk, bc = sel.bc;
   const size_t n = (size_t)g->K * a.RS * g->C;
   const bool direct = a.splits == 1 && !(flags & RN_F_ACCUM);
   if (!direct) {
@@ -596,6 +656,56 @@ extern "C" int rn_conv_wgrad_splits(const rn_conv_geom* g, int dtype, int flags)
   if (splits == 1 && !(flags & RN_F_ACCUM)) return 0;
   const long n4 = (long)g->K * g->R * g->S * g->C / 4;
   return reduce_is_wide(splits, n4) ? splits : -1;
+}
+
+// > 0: the weight gradient of this geometry may ride in a batched launch with others of the same key (the tile shape); 0: it launches alone
+extern "C" int rn_conv_wgrad_batch_key(const rn_conv_geom* g, int dtype, int flags) {
+  if (!g || !RN_DTYPE_OK(dtype) || (flags & RN_F_FORK) || (g_rn_variant & (1 << 17))) return 0;        // 1 << 17: never (A/B)
+  const int ce = dtype == RN_F32 ? 4 : 8;
+  if (g->R != g->S || g->R * g->S > WB_TAPS || g->C % ce || g->K % ce) return 0;
+  if (use_im2col(g, ce) || rn_wgrad8_splits(g, dtype) > 0) return 0;
+  if (rn_conv_wgrad_splits(g, dtype, flags) <= 0) return 0;                                           // only slabs whose sums are deferrable
+  const int bk = pick_tile(g->K), bc = col_tile(g, false, bk);
+  return bk * 1024 + bc;
+}
+
+// the slab-writing launches of up to RN_WGRAD_BATCH_MAX weight gradients of ONE key as one grid (thin networks: their ~10 us launches are half ramp, tail
+// and gap); every record writes its [splits][K*R*S*C] slabs exactly as rn_conv_wgrad(..., RN_F_DEFER_REDUCE) would -- the caller sums them
+// (rn_wgrad_reduce_batch)
+extern "C" int rn_conv_wgrad_batch(const rn_wgrad_desc* descs, int n, int dtype, rn_stream s) {
+  static_assert(RN_WGRAD_BATCH_MAX == WB_MAX, "header and kernel disagree");
+  RN_CHECK_ARG(descs && n > 0 && n <= RN_WGRAD_BATCH_MAX, "rn_conv_wgrad_batch: n=%d out of range (1..%d)", n, RN_WGRAD_BATCH_MAX);
+  RN_CHECK_ARG(RN_DTYPE_OK(dtype), "rn_conv_wgrad_batch: bad dtype");
+  const int key = rn_conv_wgrad_batch_key(&descs[0].g, dtype, descs[0].flags);
+  RN_CHECK_ARG(key > 0, "rn_conv_wgrad_batch: record 0 is not batchable (rn_conv_wgrad_batch_key)");
+  WgradBatch wb{};
+  wb.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const rn_wgrad_desc& d = descs[i];
+    RN_CHECK_ARG(d.x && d.dy && d.slabs, "rn_conv_wgrad_batch: record %d: null pointer", i);
+    RN_CHECK_ARG(rn_conv_wgrad_batch_key(&d.g, dtype, d.flags) == key, "rn_conv_wgrad_batch: record %d has another key", i);
+    WgradSel sel;
+    WgradArgs a{};
+    wgrad_fill(a, sel, d.x, d.dy, &d.g, dtype, d.flags);
+    WgradArgsS& o = wb.a[i];
+    o.x = a.x; o.dy = a.dy; o.out = d.slabs;
+    o.N = a.N; o.H = a.H; o.W = a.W; o.C = a.C; o.P = a.P; o.Q = a.Q; o.K = a.K;
+    o.stride = a.stride; o.RS = a.RS; o.nt = a.nt; o.M = a.M;
+    o.splits = a.splits; o.rows_per_split = a.rows_per_split; o.kt = a.kt; o.ct = a.ct;
+    o.magic_pq = a.magic_pq; o.magic_q = a.magic_q; o.xcd_remap = a.xcd_remap; o.im2col = 0;
+    for (int t = 0; t < WB_TAPS; ++t) { o.dh[t] = t < a.RS ? a.dh[t] : 0; o.dw[t] = t < a.RS ? a.dw[t] : 0; }
+    wb.first_block[i] = blocks;
+    wb.nwg[i] = a.kt * a.ct * a.nt * a.splits;
+    blocks += (wb.nwg[i] + 7) / 8 * 8;                   // a record starts on a multiple of 8: blockIdx & 7 stays the XCD inside it
+    rn_note_kernel("wgrad<%dx%d>", sel.bk, sel.bc);
+    rn_note_kernel("wgrad_reduce_wide");
+  }
+  rn_note_kernel("wgrad_batch");
+  if (rn_dry_run()) return 0;
+  int e = 0;
+  RN_BY_DTYPE(dtype, e = dispatch_wb<T_>(wb, blocks, key / 1024, key % 1024, as_stream(s)));
+  return e;
 }
 
 extern "C" int rn_wgrad_reduce_batch(const rn_reduce_desc* descs, int n, rn_stream s) {

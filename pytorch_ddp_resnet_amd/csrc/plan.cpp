@@ -7,6 +7,7 @@
 #include <string.h>
 
 #include <string>
+#include <cstdlib>
 #include <vector>
 
 #include "common.h"
@@ -364,7 +365,21 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
   rn_reduce_desc pending[RN_REDUCE_BATCH_MAX];
   int pending_slot[RN_REDUCE_BATCH_MAX];                  // the dw buffer of each pending sum: an op that touches one forces the flush first
   int n_pending = 0;
+  // the slab-writing launches of those weight gradients wait, too, grouped by tile shape (rn_conv_wgrad_batch_key): every group goes out as ONE grid
+  // when it is full or with the sums.  Their operands -- a layer's input and the gradient of its output -- are slots of their own that nothing
+  // rewrites inside a backward, so running them later in the range reads the same values.  RN_NO_WGRAD_BATCH=1: every launch on its own (A/B).
+  static const bool batch_wgrads = !(getenv("RN_NO_WGRAD_BATCH") && atoi(getenv("RN_NO_WGRAD_BATCH")) == 1);
+  constexpr int WQ_KEYS = 6;
+  struct WQueue { int key = 0, n = 0; rn_wgrad_desc d[RN_WGRAD_BATCH_MAX]; } wq[WQ_KEYS];
+  auto launch_queue = [&](WQueue& q) -> int {
+    if (!q.n) return 0;
+    const int e = rn_conv_wgrad_batch(q.d, q.n, plan->dtype, stream);
+    q.n = 0; q.key = 0;
+    return e;
+  };
   auto flush = [&]() -> int {
+    for (auto& q : wq)
+      if (int e = launch_queue(q)) return e;
     if (!n_pending) return 0;
     const int e = rn_wgrad_reduce_batch(pending, n_pending, stream);
     n_pending = 0;
@@ -377,9 +392,28 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
       rn_conv_geom g = geom_of(o);
       const size_t nel = (size_t)g.K * g.R * g.S * g.C;
       char* slabs = plan->arena + plan->slab_off[i];
-      int e = (P(0) && P(1) && P(2)) ? rn_conv_wgrad(P(0), P(1), (float*)P(2), slabs, (size_t)plan->slab_splits[i] * nel * sizeof(float), o.flags | RN_F_DEFER_REDUCE,
-                                                     plan->dtype, &g, stream)
-                                     : (rn_set_error("rn_plan_run: op %d (kind %d) uses an unbound buffer", i, o.kind), 1);
+      int e = 0;
+      const int key = batch_wgrads ? rn_conv_wgrad_batch_key(&g, plan->dtype, o.flags) : 0;
+      if (!(P(0) && P(1) && P(2))) {
+        rn_set_error("rn_plan_run: op %d (kind %d) uses an unbound buffer", i, o.kind);
+        e = 1;
+      } else if (key > 0) {                                // queued: launched with the others of its tile shape
+        WQueue* q = nullptr;
+        for (auto& c : wq) if (c.n && c.key == key) { q = &c; break; }
+        if (!q) for (auto& c : wq) if (!c.n) { q = &c; break; }
+        if (!q) {                                            // every queue holds another shape: the fullest one goes out
+          q = &wq[0];
+          for (auto& c : wq) if (c.n > q->n) q = &c;
+          e = launch_queue(*q);
+        }
+        if (!e) {
+          q->key = key;
+          q->d[q->n++] = rn_wgrad_desc{P(0), P(1), reinterpret_cast<float*>(slabs), g, o.flags};
+          if (q->n == RN_WGRAD_BATCH_MAX) e = launch_queue(*q);
+        }
+      } else {
+        e = rn_conv_wgrad(P(0), P(1), (float*)P(2), slabs, (size_t)plan->slab_splits[i] * nel * sizeof(float), o.flags | RN_F_DEFER_REDUCE, plan->dtype, &g, stream);
+      }
       if (e) { std::string msg = g_err; rn_set_error("op %d (kind %d): %s", i, o.kind, msg.c_str()); return e; }
       pending_slot[n_pending] = o.buf[2];
       pending[n_pending++] = rn_reduce_desc{reinterpret_cast<const float*>(slabs), (float*)P(2), (int64_t)nel, plan->slab_splits[i], (o.flags & RN_F_ACCUM) ? 1 : 0};

@@ -478,6 +478,62 @@ def test_deferred_slab_sums_equal_the_immediate_reduction_bit_for_bit():
             assert torch.equal(a_, b_) and float(a_.abs().max()) > 1.0
 
 
+@pytest.mark.parametrize('dt', [0, 2])
+def test_batched_weight_gradient_launch_writes_the_same_slabs(dt):
+    """rn_conv_wgrad_batch: the slab-writing launches of several thin layers of ONE tile shape as one grid == rn_conv_wgrad(RN_F_DEFER_REDUCE) per layer, slab for
+    slab and bit for bit (3 x 3 stride 1 and 2, 1 x 1, a ragged pixel count, 17 records = two launches); records of another shape are refused."""
+    import ctypes as C
+    from pytorch_ddp_resnet_amd import _lib
+    L = _lib.lib()
+    vp, i32 = C.c_void_p, C.c_int32
+
+    class WDesc(C.Structure):
+        _fields_ = [('x', vp), ('dy', vp), ('slabs', vp), ('g', _lib.RnConvGeom), ('flags', i32)]
+    L.rn_conv_wgrad.argtypes = [vp, vp, vp, vp, C.c_size_t, i32, i32, C.POINTER(_lib.RnConvGeom), vp]
+    L.rn_conv_wgrad_splits.argtypes = [C.POINTER(_lib.RnConvGeom), i32, i32]
+    L.rn_conv_wgrad_batch_key.argtypes = [C.POINTER(_lib.RnConvGeom), i32, i32]
+    L.rn_conv_wgrad_batch.argtypes = [C.POINTER(WDesc), i32, i32, vp]
+    st = vp(torch.cuda.current_stream().cuda_stream)
+    tdt = torch.float32 if dt == 0 else torch.float16
+    # (N, H, W, C, K, k, stride, pad): all select the 32 x 32 tile
+    geoms = [(32, 32, 32, 16, 16, 3, 1, 1), (32, 32, 32, 32, 32, 3, 2, 1), (32, 16, 16, 32, 16, 1, 1, 0), (33, 19, 17, 16, 32, 3, 1, 1)] * 4 + [(32, 16, 16, 16, 16, 3, 1, 1)]
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    descs, want, got, keep = (WDesc * len(geoms))(), [], [], []
+    key0 = None
+    for j, (N, Hh, W, Cc, K, k, s_, p) in enumerate(geoms):
+        P, Q = (Hh + 2 * p - k) // s_ + 1, (W + 2 * p - k) // s_ + 1
+        g = _lib.RnConvGeom(N, Hh, W, Cc, P, Q, K, k, k, s_, p)
+        key = int(L.rn_conv_wgrad_batch_key(C.byref(g), dt, 0))
+        assert key > 0 and (key0 is None or key == key0)
+        key0 = key
+        x = torch.randn(N, Hh, W, Cc, device='cuda', generator=gen).to(tdt)
+        dy = torch.randn(N, P, Q, K, device='cuda', generator=gen).to(tdt)
+        splits = int(L.rn_conv_wgrad_splits(C.byref(g), dt, 0))
+        n = K * k * k * Cc
+        ws0, ws1 = torch.full((splits * n,), 7.0, device='cuda'), torch.full((splits * n,), -7.0, device='cuda')
+        dw = torch.zeros(n, device='cuda')
+        _lib.check(L.rn_conv_wgrad(vp(x.data_ptr()), vp(dy.data_ptr()), vp(dw.data_ptr()), vp(ws0.data_ptr()), ws0.numel() * 4, ir.F_DEFER_REDUCE, dt, C.byref(g), st))
+        descs[j] = WDesc(x.data_ptr(), dy.data_ptr(), ws1.data_ptr(), g, 0)
+        keep += [x, dy, dw]
+        want.append(ws0); got.append(ws1)
+    nmax = 16
+    for lo in range(0, len(geoms), nmax):
+        part = (WDesc * min(nmax, len(geoms) - lo))(*[descs[i] for i in range(lo, min(lo + nmax, len(geoms)))])
+        _lib.check(L.rn_conv_wgrad_batch(part, len(part), dt, st))
+    torch.cuda.synchronize()
+    for a_, b_ in zip(want, got):
+        assert torch.equal(a_, b_) and float(a_.abs().max()) > 1.0 and not bool((a_ == 7.0).any())
+    # a record of another tile shape in the same launch is an argument error, not a wrong gradient
+    g_big = _lib.RnConvGeom(32, 16, 16, 64, 16, 16, 64, 3, 3, 1, 1)
+    assert int(L.rn_conv_wgrad_batch_key(C.byref(g_big), dt, 0)) not in (0, key0)
+    bad = (WDesc * 2)(descs[0], WDesc(descs[0].x, descs[0].dy, descs[0].slabs, g_big, 0))
+    assert L.rn_conv_wgrad_batch(bad, 2, dt, st) != 0
+    # forked launches and the stem's im2col form stay single launches
+    assert int(L.rn_conv_wgrad_batch_key(C.byref(descs[0].g), dt, ir.F_FORK)) == 0
+    g_stem = _lib.RnConvGeom(32, 32, 32, 4 if dt == 0 else 8, 32, 32, 16, 3, 3, 1, 1)
+    assert int(L.rn_conv_wgrad_batch_key(C.byref(g_stem), dt, 0)) == 0
+
+
 @pytest.mark.parametrize('fp32', DT)
 @pytest.mark.parametrize('shape', [(3, 12, 12, 32, 3, 2, 1), (2, 9, 7, 64, 3, 2, 1), (2, 8, 8, 16, 2, 2, 0), (1, 4, 6, 32, 3, 2, 1), (2, 2, 2, 8, 3, 2, 1)])
 def test_bn_relu_maxpool_fused(shape, fp32):

@@ -166,6 +166,46 @@ def test_grammar_corners(spec, preact, train, dtype):
             assert rel(b_, tst[k]) < (1e-4 if dtype == 'fp32' else 2e-2), k
 
 
+@pytest.mark.parametrize('dtype', ['fp32', 'fp16'])
+def test_batched_weight_gradients_are_bit_identical(dtype):
+    """thin networks queue their weight-gradient launches by tile shape and send each queue out as ONE grid (plan.cpp, rn_conv_wgrad_batch): the
+    gradients are those of the single launches, bit for bit (rn_set_variant 1 << 17 turns the queues off), and the batched form really ran."""
+    import ctypes as C
+    from pytorch_ddp_resnet_amd import _lib
+    L = _lib.lib()
+    L.rn_set_variant.argtypes = [C.c_int]
+    cfg = MODELS['rn20']                                       # at batch 64 its layers split their pixels 85-227 ways: the deferrable, batchable kind
+    st = fill_state(param_shapes(cfg['spec'], cfg['preact'], cfg['use_proj']), 21)
+    xs, ys = torch.from_numpy(fill((64, 3, 32, 32), 210)).cuda(), torch.from_numpy(fill_labels(64, 10, 211)).cuda()
+
+    def grads(variant):
+        L.rn_set_variant(variant)
+        try:
+            m = build(cfg, st, dtype).train()
+            out = []
+            for _ in range(3):                                 # eager warm-up, capture, replay: the queues live inside the captured ranges too
+                for p in m.parameters():
+                    p.grad = None
+                torch.nn.functional.cross_entropy(m(xs), ys).backward()
+                out.append({k: p.grad.clone() for k, p in m.named_parameters()})
+            # which launch form ran: the kernel log is per thread and autograd runs the backward on a thread of its own, so the backward ops are
+            # run once more from this thread, eagerly (a replayed graph executes no host code)
+            eng = next(e for k, e in m._engines.items() if k[1] and k[2])
+            eng.use_graphs = False
+            L.rn_kernel_log(1)
+            eng.backward(step_seed=0)
+            torch.cuda.synchronize()
+            return out, L.rn_kernel_log_read().decode().split(',')
+        finally:
+            L.rn_kernel_log(0)
+            L.rn_set_variant(0)
+    (single, log1), (batched, log2) = grads(1 << 17), grads(0)
+    assert 'wgrad_batch' not in log1 and 'wgrad_batch' in log2
+    for a_, b_ in zip(single, batched):
+        for k in a_:
+            assert torch.equal(a_[k], b_[k]), k
+
+
 @pytest.mark.parametrize('preact', [False, True])
 def test_dropout_matches_plan_interpreter(preact):
     """p = 0.3: the engine's counter-based masks == the executable spec (np_interp) fed with the same step seed."""
