@@ -658,6 +658,9 @@ extern "C" int rn_conv_wgrad_splits(const rn_conv_geom* g, int dtype, int flags)
   return reduce_is_wide(splits, n4) ? splits : -1;
 }
 
+static long g_wgrad_batch_launches = 0;                  // diagnostic (tests): batched launches issued by this process
+extern "C" long rn_wgrad_batch_launches(void) { return g_wgrad_batch_launches; }
+
 // > 0: the weight gradient of this geometry may ride in a batched launch with others of the same key (the tile shape); 0: it launches alone
 extern "C" int rn_conv_wgrad_batch_key(const rn_conv_geom* g, int dtype, int flags) {
   if (!g || !RN_DTYPE_OK(dtype) || (flags & RN_F_FORK) || (g_rn_variant & (1 << 17))) return 0;        // 1 << 17: never (A/B)
@@ -701,8 +704,8 @@ extern "C" int rn_conv_wgrad_batch(const rn_wgrad_desc* descs, int n, int dtype,
     rn_note_kernel("wgrad<%dx%d>", sel.bk, sel.bc);
     rn_note_kernel("wgrad_reduce_wide");
   }
-  rn_note_kernel("wgrad_batch");
   if (rn_dry_run()) return 0;
+  ++g_wgrad_batch_launches;
   int e = 0;
   RN_BY_DTYPE(dtype, e = dispatch_wb<T_>(wb, blocks, key / 1024, key % 1024, as_stream(s)));
   return e;
