@@ -327,7 +327,6 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
     roof_t, hbm_bound = 0.0, 0                           # per-launch rooflines: max(FLOPs / MFMA peak, bytes / HBM peak)
     elem = 4 if dtype == 'fp32' else 2
     from pytorch_ddp_resnet_amd import _lib
-    _lib.lib().rn_kernel_log(1)
     for _ in range(nprof):
         eng.profile(True)
         step()
@@ -344,6 +343,14 @@ def measure(args, cfg, dtype, dev, world, rank, steps, warmup, main_run):
                 roof_t += max(t_m, t_h) * 1e3
                 hbm_bound += 1 if t_h > t_m else 0
     eng.profile(False)
+    # which convolution kernels the plan launches: the log is per thread and autograd runs the backward on a thread of its own, so the plan's two op
+    # ranges are run once more from THIS thread (eagerly, no reducer hooks: every rank does the same, the gradients of this pass are not used)
+    _lib.lib().rn_kernel_log(1)
+    graphs, eng.use_graphs = eng.use_graphs, False
+    eng.forward(step_seed=0)
+    eng.backward(step_seed=0)
+    torch.cuda.synchronize()
+    eng.use_graphs = graphs
     kernels = sorted(set(n for n in _lib.lib().rn_kernel_log_read().decode().split(',') if n and 'reduce' not in n))
     _lib.lib().rn_kernel_log(0)
     if rank == 0:
