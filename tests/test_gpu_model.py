@@ -166,15 +166,30 @@ def test_grammar_corners(spec, preact, train, dtype):
             assert rel(b_, tst[k]) < (1e-4 if dtype == 'fp32' else 2e-2), k
 
 
+# every block kind at a size where the weight gradients are of the deferred, batchable kind (64 images of 32 x 32): a queued launch runs later in the
+# backward than its op stands, so every way a block hands gradients on (v1 / v2, basic / bottleneck, projection / padded shortcut, the accumulate into
+# the block input's gradient) must leave the queued operands alone
+BATCH_CASES = [('rn20', None)] + [(f'{k}{int(p)}{int(j)}', (k, p, j)) for k, p, j in COMBOS]
+
+
 @pytest.mark.parametrize('dtype', ['fp32', 'fp16'])
-def test_batched_weight_gradients_are_bit_identical(dtype):
+@pytest.mark.parametrize('case', BATCH_CASES, ids=[c[0] for c in BATCH_CASES])
+def test_batched_weight_gradients_are_bit_identical(case, dtype):
     """thin networks queue their weight-gradient launches by tile shape and send each queue out as ONE grid (plan.cpp, rn_conv_wgrad_batch): the
     gradients are those of the single launches, bit for bit (rn_set_variant 1 << 17 turns the queues off), and the batched form really ran."""
     import ctypes as C
     from pytorch_ddp_resnet_amd import _lib
     L = _lib.lib()
     L.rn_set_variant.argtypes = [C.c_int]
-    cfg = MODELS['rn20']                                       # at batch 64 its layers split their pixels 85-227 ways: the deferrable, batchable kind
+    if case[1] is None:
+        cfg = MODELS['rn20']                                   # at batch 64 its layers split their pixels 85-227 ways: the deferrable, batchable kind
+    else:
+        kind, preact, proj = case[1]
+        if dtype == 'fp32':
+            pytest.skip('block kinds: the 16-bit engine only (same plan, same queues)')
+        top, tail = ('n a ' if not preact else ''), ('n a ' if preact else '')
+        w = 16 if kind == 'r' else 32                          # bottleneck width = channels / 4: one 16-byte chunk at least
+        cfg = dict(spec=f'c3,{w},3,1,1 {top}{kind}2 {kind}2 {tail}ap16,1,0 fc{2 * w},10', preact=preact, use_proj=proj)
     st = fill_state(param_shapes(cfg['spec'], cfg['preact'], cfg['use_proj']), 21)
     xs, ys = torch.from_numpy(fill((64, 3, 32, 32), 210)).cuda(), torch.from_numpy(fill_labels(64, 10, 211)).cuda()
 
