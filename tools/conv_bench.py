@@ -34,8 +34,11 @@ def run(which, iters, variants, dtype=torch.bfloat16):
         dy = torch.randn(N, H, W, K, device='cuda').to(dtype)
         dx = torch.empty(N, H, W, Cc, device='cuda', dtype=dtype)
         dw = torch.empty(K, ks * ks, Cc, device='cuda')
-        L.rn_set_variant(0)                                 # the workspace is sized for the shipped selection
-        wsb = int(L.rn_conv_wgrad_ws_bytes(C.byref(g)))
+        wsb = 16                                            # the workspace fits every variant's selection
+        for v in [0] + list(variants):
+            L.rn_set_variant(v)
+            wsb = max(wsb, int(L.rn_conv_wgrad_ws_bytes(C.byref(g))))
+        L.rn_set_variant(0)
         ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device='cuda')
         rn = {torch.bfloat16: 1, torch.float16: 2, torch.float32: 0}[dtype]
         flops = 2.0 * N * H * W * K * ks * ks * Cc
