@@ -35,8 +35,10 @@ namespace {
 // per tile, identical for all waves: the B tile is padded with out-of-range dummies) and the barrier is the raw
 // `s_barrier`: `__syncthreads()` would make hipcc drain every DMA in flight.  All LDS lives in ONE __shared__ array (a
 // second __shared__ object makes hipcc wait vmcnt(0) before every ds_read; cdna_hip_programming.md section 5).
+// (the body is a device function over the argument record, the workgroup's index and the workgroups of the record: igemm_dma_classes_kernel below
+// runs it over one record of several)
 template <typename T, int BM, int BN, int WM, int WN, int CPRT, int NSTG>
-__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmArgs a) {   // 2 waves per SIMD: <= 256 registers (two 4-wave workgroups per CU)
+__device__ __forceinline__ void igemm_dma_body(const IgemmArgs& a, const int wg, const int nwg_all) {
   constexpr int NW = WM * WN;                          // waves per workgroup
   constexpr int ES = (int)sizeof(T);
   constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
@@ -59,12 +61,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
   const int nmt = (a.M + BM - 1) / BM;
   // tile order: the column tiles of one row tile are neighbours (they read the same input rows), then the next row tile
   // (which shares its halo rows); the XCD remap puts consecutive tiles on ONE XCD, so those re-reads hit its L2
-  int bid = blockIdx.x;
+  int bid = wg;
   if (a.xcd_remap) {
-    const int nwg = gridDim.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int nwg = nwg_all, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  const int nnt_ = gridDim.x / nmt;
+  const int nnt_ = nwg_all / nmt;
   const int ntile = a.xcd_remap ? bid % nnt_ : bid / nmt, mt = a.xcd_remap ? bid / nnt_ : bid % nmt;
   const int m0 = mt * BM, n0 = ntile * BN;
   const int pq = a.Pc * a.Qc;
@@ -213,6 +215,32 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmA
   constexpr int SR = CPRT == 4 ? 32 : (BN == 32 ? BM : 64);              // 64-byte K rows: the ring is half as large, so is the staged slab
   static_assert((size_t)SR * (BN + 4) * 4 + (size_t)(NW * 64 / (BN / Elem<T>::CE)) * 2 * BN * 4 <= sizeof(smem), "epilogue staging exceeds the ring");
   igemm_epilogue<T, BM, BN, WM, WN, TM, TN, NW * 64, SR>(a, acc, m0, n0, wave, lane, reinterpret_cast<float*>(&smem[0]));
+}
+
+template <typename T, int BM, int BN, int WM, int WN, int CPRT, int NSTG>
+__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_kernel(const IgemmArgs a) {   // 2 waves per SIMD: <= 256 registers (two 4-wave workgroups per CU)
+  igemm_dma_body<T, BM, BN, WM, WN, CPRT, NSTG>(a, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// The parity classes of a stride-2 data gradient as ONE grid (they were four launches, each a fraction of a chip-filling grid with its own ramp and
+// tail -- 250 TFLOP/s on WRN-28-10's 160 -> 320 and 320 -> 640 layers): the classes write disjoint pixels of dx and disjoint rows of the fused sums, so
+// their tiles are one pool of independent workgroups.  Record i = the argument record rn_conv_dgrad builds for class i (its tap subset, its compute
+// grid, its row offset into the sums) and owns the block range [first[i], first[i] + nwg[i]); ranges start on multiples of 8 so that blockIdx & 7 is
+// still the XCD inside a record (the remap of the body), padding blocks exit.  Four records are 3.5 KiB of the 4 KiB kernel-argument segment.
+struct IgemmClasses {
+  int n;
+  int first[4], nwg[4];
+  IgemmArgs a[4];
+};
+static_assert(sizeof(IgemmClasses) <= 3840, "kernel-argument segment (4 KiB with the implicit arguments)");
+
+template <typename T, int BM, int BN, int WM, int WN, int CPRT, int NSTG>
+__global__ __launch_bounds__(WM * WN * 64, 2) void igemm_dma_classes_kernel(const IgemmClasses p) {
+  int i = 0;
+  while (i + 1 < p.n && (int)blockIdx.x >= p.first[i + 1]) ++i;            // workgroup-uniform
+  const int wg = (int)blockIdx.x - p.first[i];
+  if (wg >= p.nwg[i]) return;
+  igemm_dma_body<T, BM, BN, WM, WN, CPRT, NSTG>(p.a[i], wg, p.nwg[i]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -721,6 +749,49 @@ template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   return launch_cfg<T, 128, 32, 4, 1>(a, s);
 }
 
+// ---- the parity classes of a stride-2 data gradient as one grid (igemm_dma_classes_kernel) ----
+// Taken when every class would run a 128-row igemm_dma / igemm_ws tile on its own (no eight-phase form, no thin 256-row form; the LDS-patch kernels
+// never take a strided destination): the column tile depends on the output channels only, so the classes share it.  rn_set_variant 1 << 18: never.
+template <typename T, int BN, int WM, int WN>
+int launch_classes_cfg(const IgemmClasses& p, int grid, hipStream_t s) {
+  hipLaunchKernelGGL((igemm_dma_classes_kernel<T, 128, BN, WM, WN, 8, 2>), dim3(grid), dim3(256), 0, s, p);
+  RN_CHECK_LAUNCH("igemm_classes");
+  return 0;
+}
+template <typename T> bool classes_ok(const IgemmArgs* as, int n) {
+  if (n < 2 || (g_rn_variant & (1 << 18))) return false;
+  for (int i = 0; i < n; ++i) {
+    const IgemmArgs& a = as[i];
+    if (a.M <= 0) return false;
+    if constexpr (sizeof(T) == 2) {
+      const bool force8 = (g_rn_variant & (1 << 22)) != 0, forbid8 = (g_rn_variant & (1 << 27)) != 0;
+      if (!forbid8 && (force8 || igemm8_rule(a))) return false;
+    }
+    if (a.Kd <= 32 && !(g_rn_variant & 32) && (long)cdiv(a.M, 256) >= 512) return false;      // the thin 256-row form
+  }
+  return true;
+}
+template <typename T> int launch_classes(const IgemmArgs* as, int n, hipStream_t s) {
+  const int K = as[0].Kd;
+  const int bn = K % 160 == 0 ? 160 : (K % 128 == 0 ? 128 : (K % 96 == 0 ? 96 : (K > 32 ? 64 : 32)));
+  IgemmClasses p{};
+  p.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    p.a[i] = as[i];
+    p.first[i] = blocks;
+    p.nwg[i] = cdiv(as[i].M, 128) * cdiv(K, bn);
+    blocks += (p.nwg[i] + 7) / 8 * 8;
+    rn_note_kernel("igemm_dma<128x%d>", bn);
+  }
+  if (rn_dry_run()) return 0;
+  if (bn == 160) return launch_classes_cfg<T, 160, 4, 1>(p, blocks, s);
+  if (bn == 128) return launch_classes_cfg<T, 128, 2, 2>(p, blocks, s);
+  if (bn == 96) return launch_classes_cfg<T, 96, 4, 1>(p, blocks, s);
+  if (bn == 64) return launch_classes_cfg<T, 64, 2, 2>(p, blocks, s);
+  return launch_classes_cfg<T, 32, 4, 1>(p, blocks, s);
+}
+
 int check_geom(const rn_conv_geom* g, int dtype, const char* who) {
   RN_CHECK_ARG(g != nullptr, "%s: null geometry", who);
   RN_CHECK_ARG(RN_DTYPE_OK(dtype), "%s: bad dtype %d", who, dtype);
@@ -820,10 +891,13 @@ extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, cons
   const int ce = dtype == RN_F32 ? 4 : 8;
   RN_CHECK_ARG(!ep || (ep->partial && ep->bn_x && ep->bn_coef && !ep->bias), "rn_conv_dgrad: incomplete epilogue descriptor");
   int tile_base = 0;
-  // one launch per parity class (a, b) of the input grid: h = st*p' + a, w = st*q' + b
+  // one argument record per parity class (a, b) of the input grid: h = st*p' + a, w = st*q' + b; launched as one grid (launch_classes) or one by one
+  IgemmArgs recs[4];
+  int nrec = 0;
   for (int pa = 0; pa < st; ++pa)
     for (int pb = 0; pb < st; ++pb) {
-      IgemmArgs a{};
+      IgemmArgs& a = recs[nrec];
+      a = IgemmArgs{};
       a.src = dy; a.wt = w_dgrad; a.dst = dx;
       fill_res(a.res, res, res_mode, res_C, g->N, g->H, g->W, g->C);
       a.N = g->N; a.Hs = g->P; a.Ws = g->Q; a.Cs = g->K;
@@ -854,9 +928,15 @@ extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, cons
       fill_magic(a);
       tile_base += cdiv(a.M, RN_CONV_STATS_ROWS);
       if (nt == 0 && a.accum && a.res.mode == RN_RES_NONE && !ep) continue;   // nothing to add to this class (a fused reduction still has to see it)
-      int e = 0;
-      RN_BY_DTYPE(dtype, e = launch_igemm<T_>(a, as_stream(s)));
-      if (e) return e;
+      ++nrec;
     }
-  return 0;
+  int e = 0;
+  bool merged = false;
+  RN_BY_DTYPE(dtype, merged = classes_ok<T_>(recs, nrec));
+  if (merged) {
+    RN_BY_DTYPE(dtype, e = launch_classes<T_>(recs, nrec, as_stream(s)));
+    return e;
+  }
+  for (int i = 0; i < nrec && !e; ++i) RN_BY_DTYPE(dtype, e = launch_igemm<T_>(recs[i], as_stream(s)));
+  return e;
 }

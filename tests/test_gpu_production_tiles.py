@@ -173,6 +173,30 @@ def test_both_schedules_on_small_tiles(g, variant, dtype):
     assert all(('igemm_ws' in n) == (variant == 128) for n in ran if n.startswith('igemm_') and '256x32' not in n), ran
 
 
+# stride-2 layers: the data gradient is four parity classes (1 / 2 / 2 / 4 taps of a 3 x 3 kernel, 1 / 0 / 0 / 0 of a 1 x 1), launched as ONE grid over a
+# table of four argument records (igemm_dma_classes_kernel) or -- rn_set_variant 1 << 18 -- one launch per class.  Column tiles 160 / 128 / 96 / 64 / 32,
+# odd map sizes (classes of unequal size, a class with a single row), every operand set of the block backward
+STRIDED = [(3, 8, 8, 320, 160, 3, 2, 1), (2, 16, 16, 128, 128, 3, 2, 1), (2, 9, 7, 96, 64, 3, 2, 1), (4, 16, 16, 128, 64, 1, 2, 0), (5, 15, 17, 32, 32, 3, 2, 1),
+           (2, 8, 8, 64, 16, 3, 2, 1), (128, 32, 32, 160, 320, 3, 2, 1)]
+CLASSES_OFF = 1 << 18
+
+
+@pytest.mark.parametrize('dtype', ['fp32', 'fp16'])
+@pytest.mark.parametrize('merge', ['none', 'res', 'acc'])
+@pytest.mark.parametrize('variant', [0, CLASSES_OFF])
+@pytest.mark.parametrize('g', STRIDED)
+def test_stride2_parity_classes_as_one_grid_and_one_by_one(g, variant, merge, dtype):
+    """both launch forms of a stride-2 data gradient against torch-CPU: dx of all four classes, the fused BatchNorm-backward sums (their rows are
+    per-class), with a shortcut gradient added / accumulated into an existing gradient; the weight gradient and forward ride along."""
+    if g[0] == 128 and (dtype == 'fp32' or merge != 'none'):
+        pytest.skip('the production-size case once per 16-bit type')
+    ran = run_conv_case(g, dtype, variant=variant, fwd_res=False, dgrad_merge=merge)
+    dgrad = [n for n in ran if n.startswith('igemm_')][1:]                     # (the first name is the forward's)
+    assert len(dgrad) >= 1 and all(n.startswith(('igemm_dma<128x', 'igemm_ws<128x')) for n in dgrad), ran
+    if variant == 0:
+        assert all(n.startswith('igemm_dma<128x') for n in dgrad), ran          # one grid: the two-workgroups-per-CU kernel, one name per class
+
+
 PATCH_SMALL = [
     (3, 8, 8, 160, 160, 3, 1, 1),        # several images per tile, the last tile partly empty: image-validity of the patch DMAs, row tail
     (5, 16, 16, 128, 128, 3, 1, 1),      # BN = 128 (forward and dgrad)
