@@ -751,7 +751,7 @@ template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
 
 // ---- the parity classes of a stride-2 data gradient as one grid (igemm_dma_classes_kernel) ----
 // Taken when every class would run a 128-row igemm_dma / igemm_ws tile on its own (no eight-phase form, no thin 256-row form; the LDS-patch kernels
-// never take a strided destination): the column tile depends on the output channels only, so the classes share it.  rn_set_variant 1 << 18: never.
+// never take a strided destination): the column tile depends on the output channels only, so the classes share it.  rn_set_variant 1 << 18 (or 128): never.
 template <typename T, int BN, int WM, int WN>
 int launch_classes_cfg(const IgemmClasses& p, int grid, hipStream_t s) {
   hipLaunchKernelGGL((igemm_dma_classes_kernel<T, 128, BN, WM, WN, 8, 2>), dim3(grid), dim3(256), 0, s, p);
@@ -759,7 +759,7 @@ int launch_classes_cfg(const IgemmClasses& p, int grid, hipStream_t s) {
   return 0;
 }
 template <typename T> bool classes_ok(const IgemmArgs* as, int n) {
-  if (n < 2 || (g_rn_variant & (1 << 18))) return false;
+  if (n < 2 || (g_rn_variant & ((1 << 18) | 128))) return false;        // (128 forces the wave-specialised kernel: one launch per class)
   for (int i = 0; i < n; ++i) {
     const IgemmArgs& a = as[i];
     if (a.M <= 0) return false;
