@@ -261,6 +261,8 @@ typedef struct rn_wgrad_desc {
 } rn_wgrad_desc;
 int rn_conv_wgrad_batch_key(const rn_conv_geom* g, int dtype, int flags);
 int rn_conv_wgrad_batch(const rn_wgrad_desc* descs, int n, int dtype, rn_stream s);
+unsigned rn_op_output_mask(int kind);    /* bit b set: an op of this kind WRITES buf[b] (rn_plan_run sends a queued weight gradient out before an op that
+                                          * would rewrite one of its operands); mirrored by engine/ir.py OP_OUTPUTS, checked by tests/test_abi.py */
 long rn_wgrad_batch_launches(void);      /* diagnostic: batched launches this process has issued (the kernel log keeps the per-record tile names) */
 
 /* BatchNorm over a [M, C] view.  partial: [nblk][2][C] fp32 (sum, sum of squares) of nblk row slabs; the caller picks

@@ -225,6 +225,41 @@ extern "C" int rn_plan_side_wait(rn_plan* plan, rn_stream stream) {
 extern "C" int rn_plan_num_ops(const rn_plan* plan) { return plan ? (int)plan->ops.size() : 0; }
 extern "C" void rn_plan_destroy(rn_plan* plan) { delete plan; }
 
+// which buf[] entries of an op kind are WRITTEN (bit b = buf[b]; the field lists are in rn_hip.h / engine/ir.py OP_FIELDS).  The lowering gives every
+// activation and gradient a slot of its own, so nothing rewrites a queued weight gradient's operands today; this table keeps the deferral correct for
+// any plan a host builds
+extern "C" unsigned rn_op_output_mask(int kind) {
+  switch (kind) {
+    case RN_OP_STEM_FWD: return 1u << 3;
+    case RN_OP_PACK_W: return (1u << 1) | (1u << 2);
+    case RN_OP_CONV_FWD: return (1u << 2) | (1u << 4);
+    case RN_OP_BN_STATS: return 1u << 1;
+    case RN_OP_BN_FINALIZE: return (1u << 3) | (1u << 4) | (1u << 5) | (1u << 6) | (1u << 7);
+    case RN_OP_BN_APPLY: return 1u << 3;
+    case RN_OP_DROPOUT_FWD: return 1u << 1;
+    case RN_OP_MAXPOOL_FWD: return (1u << 1) | (1u << 2);
+    case RN_OP_POOL_FC_FWD: return (1u << 3) | (1u << 4);
+    case RN_OP_POOL_FC_BWD: return (1u << 3) | (1u << 4) | (1u << 5);
+    case RN_OP_MAXPOOL_BWD: return 1u << 2;
+    case RN_OP_BN_BWD_REDUCE: return 1u << 4;
+    case RN_OP_BN_BWD_FINALIZE: return (1u << 1) | (1u << 2) | (1u << 3) | (1u << 4);
+    case RN_OP_BN_BWD_APPLY: return (1u << 6) | (1u << 7);
+    case RN_OP_CONV_DGRAD: return (1u << 2) | (1u << 7);
+    case RN_OP_CONV_WGRAD: return (1u << 2) | (1u << 3);
+    case RN_OP_STEM_WGRAD: return (1u << 2) | (1u << 3) | (1u << 4);
+    case RN_OP_DROPOUT_BWD: return 1u << 2;
+    case RN_OP_SOFTMAX_CE: return (1u << 2) | (1u << 3);
+    case RN_OP_ZERO: case RN_OP_ADD_RES: return 1u << 0;
+    case RN_OP_IMG_TO_NHWC: case RN_OP_PACK_STEM_W: case RN_OP_UNPACK_STEM_DW: case RN_OP_IMG_TO_S2D: case RN_OP_PACK_STEM_W_S2D:
+    case RN_OP_UNPACK_STEM_DW_S2D: case RN_OP_RELU_FWD: case RN_OP_AVGPOOL_FWD: case RN_OP_AVGPOOL_BWD: case RN_OP_PERMUTE_F32: return 1u << 1;
+    case RN_OP_BN_POOL_FWD: return (1u << 2) | (1u << 3) | (1u << 4);
+    case RN_OP_BN_POOL_BWD_REDUCE: return 1u << 4;
+    case RN_OP_BN_POOL_BWD_APPLY: return (1u << 5) | (1u << 6);
+    case RN_OP_RELU_BWD: return 1u << 2;
+    default: return ~0u;                                   // unknown kind: treat every buffer as written
+  }
+}
+
 static inline rn_conv_geom geom_of(const rn_op& o) {
   rn_conv_geom g;
   g.N = o.dim[0]; g.H = o.dim[1]; g.W = o.dim[2]; g.C = o.dim[3]; g.P = o.dim[4]; g.Q = o.dim[5]; g.K = o.dim[6];
@@ -370,7 +405,7 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
   // rewrites inside a backward, so running them later in the range reads the same values.  RN_NO_WGRAD_BATCH=1: every launch on its own (A/B).
   static const bool batch_wgrads = !(getenv("RN_NO_WGRAD_BATCH") && atoi(getenv("RN_NO_WGRAD_BATCH")) == 1);
   constexpr int WQ_KEYS = 6;
-  struct WQueue { int key = 0, n = 0; rn_wgrad_desc d[RN_WGRAD_BATCH_MAX]; } wq[WQ_KEYS];
+  struct WQueue { int key = 0, n = 0; rn_wgrad_desc d[RN_WGRAD_BATCH_MAX]; int xs[RN_WGRAD_BATCH_MAX], dys[RN_WGRAD_BATCH_MAX]; } wq[WQ_KEYS];
   auto launch_queue = [&](WQueue& q) -> int {
     if (!q.n) return 0;
     const int e = rn_conv_wgrad_batch(q.d, q.n, plan->dtype, stream);
@@ -408,6 +443,7 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
         }
         if (!e) {
           q->key = key;
+          q->xs[q->n] = o.buf[0]; q->dys[q->n] = o.buf[1];
           q->d[q->n++] = rn_wgrad_desc{P(0), P(1), reinterpret_cast<float*>(slabs), g, o.flags};
           if (q->n == RN_WGRAD_BATCH_MAX) e = launch_queue(*q);
         }
@@ -420,6 +456,20 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
       if (n_pending == RN_REDUCE_BATCH_MAX)
         if (int e2 = flush()) return e2;
       continue;
+    }
+    {                                                      // an op that WRITES a slot a queued weight gradient still has to read sends that queue out first
+      const unsigned outs = rn_op_output_mask(plan->ops[i].kind);
+      for (auto& q : wq) {
+        bool hit = false;
+        for (int b = 0; b < RN_OP_NBUF && !hit && q.n; ++b) {
+          const int sl = plan->ops[i].buf[b];
+          if (!((outs >> b) & 1) || sl < 0) continue;
+          for (int j = 0; j < q.n; ++j)
+            if (q.xs[j] == sl || q.dys[j] == sl) { hit = true; break; }
+        }
+        if (hit)
+          if (int e2 = launch_queue(q)) return e2;
+      }
     }
     if (n_pending) {                                       // e.g. the stem: UNPACK_STEM_DW reads the padded weight gradient right behind its CONV_WGRAD
       bool touched = false;

@@ -64,6 +64,18 @@ OP_FIELDS = {
     OP_PERMUTE_F32:        ('in out', 'A B C', ''),
 }
 
+# the buf[] fields an op WRITES (everything else it only reads): rn_op_output_mask in csrc/plan.cpp is the same table in bits (tests/test_abi.py)
+OP_OUTPUTS = {
+    OP_STEM_FWD: 'y', OP_PACK_W: 'w_fwd w_dgrad', OP_CONV_FWD: 'y stats', OP_BN_STATS: 'partial',
+    OP_BN_FINALIZE: 'running_mean running_var nbt coef fold', OP_BN_APPLY: 'out', OP_DROPOUT_FWD: 'out', OP_MAXPOOL_FWD: 'y argmax',
+    OP_POOL_FC_FWD: 'feat logits', OP_POOL_FC_BWD: 'dx dw db', OP_MAXPOOL_BWD: 'dx', OP_BN_BWD_REDUCE: 'partial',
+    OP_BN_BWD_FINALIZE: 'dsum dgamma dbeta fold', OP_BN_BWD_APPLY: 'dx g_out', OP_CONV_DGRAD: 'dx bn_partial', OP_CONV_WGRAD: 'dw ws',
+    OP_STEM_WGRAD: 'dw db ws', OP_DROPOUT_BWD: 'din', OP_SOFTMAX_CE: 'out3 dlogits', OP_ZERO: 'dst', OP_ADD_RES: 'dst', OP_IMG_TO_NHWC: 'out',
+    OP_PACK_STEM_W: 'w_padded', OP_UNPACK_STEM_DW: 'dw', OP_BN_POOL_FWD: 'y argmax xsel', OP_BN_POOL_BWD_REDUCE: 'partial',
+    OP_BN_POOL_BWD_APPLY: 'dx sums', OP_IMG_TO_S2D: 'out', OP_PACK_STEM_W_S2D: 'w_s2d', OP_UNPACK_STEM_DW_S2D: 'dw', OP_RELU_FWD: 'y',
+    OP_RELU_BWD: 'dx', OP_AVGPOOL_FWD: 'y', OP_AVGPOOL_BWD: 'dx', OP_PERMUTE_F32: 'out',
+}
+
 GEOM = 'N H W C P Q K R S stride pad'.split()
 
 

@@ -50,6 +50,26 @@ def test_constants_match_header():
     assert int(re.search(r'#define RN_OP_NDIM (\d+)', HEADER).group(1)) == ir.OP_NDIM
 
 
+def test_output_fields_of_every_op_kind_agree_with_the_library():
+    """rn_plan_run defers thin layers' weight-gradient launches and must send a queued one out before any op that WRITES one of its operands: the
+    library's table of written buf[] entries per op kind == the IR's declaration (OP_OUTPUTS), for every kind."""
+    if not os.path.exists(_lib.LIB_PATH):
+        pytest.skip('librn_hip.so not built')
+    import ctypes as C
+    L = _lib.lib()
+    L.rn_op_output_mask.argtypes = [C.c_int]
+    L.rn_op_output_mask.restype = C.c_uint
+    assert set(ir.OP_OUTPUTS) == set(ir.OP_FIELDS)
+    for kind, (bufs, _, _) in ir.OP_FIELDS.items():
+        names = bufs.split()
+        want = 0
+        for n in ir.OP_OUTPUTS[kind].split():
+            assert n in names, (ir.OP_NAMES[kind], n)
+            want |= 1 << names.index(n)
+        assert int(L.rn_op_output_mask(kind)) == want, ir.OP_NAMES[kind]
+    assert int(L.rn_op_output_mask(999)) == 0xFFFFFFFF        # an unknown kind counts as writing everything
+
+
 def test_op_struct_layout():
     import ctypes as C
     assert C.sizeof(_lib.RnOp) == 4 * (2 + ir.OP_NBUF + ir.OP_NDIM + 4 + 2)
