@@ -107,3 +107,37 @@ def test_fitted_transform_checkpoint_protocol(tmp_path, monkeypatch):
     assert torch.equal(d2['dataset_train'].transform._image_stddev, tr._image_stddev)
     with pytest.raises(ValueError, match='Fittable test transform'):
         data_util.get_datasets('CIFAR10', str(tmp_path / 'data'), WRN_AUG, {'ToTensorTransform': {}, 'ZeroMeanWhiteningTransform': {}}, ck, 'cpu')
+
+
+def _two_rank_fit_worker(rank, world, port, data_dir, ck, out_dir):
+    import torch.distributed as dist
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        fits = []
+        orig = BatchTransform.fit
+        BatchTransform.fit = lambda self, *a, **k: (fits.append(1), orig(self, *a, **k))[1]
+        d = data_util.get_datasets('CIFAR10', data_dir, WRN_AUG, TEST_AUG, ck, 'cpu')
+        tr = d['dataset_train'].transform
+        torch.save(dict(mean=tr._image_mean.clone(), std=tr._image_stddev.clone(), fits=len(fits)), os.path.join(out_dir, f'rank{rank}.pt'))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_fit_once_and_agree(tmp_path):
+    """world_size 2 (gloo): rank 0 fits and saves the whitening statistics (atomically), rank 1 loads the finished file behind the barrier --
+    one fit, one file, identical statistics (every rank fitting and saving the same file at once is the reference's race, data_util.py:76-92)."""
+    import socket
+    import torch.multiprocessing as mp
+    fake_cifar10(str(tmp_path / 'data'))
+    ck, out = str(tmp_path / 'ckpt'), str(tmp_path / 'out')
+    os.makedirs(out)
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_two_rank_fit_worker, args=(2, port, str(tmp_path / 'data'), ck, out), nprocs=2, join=True)
+    r0, r1 = torch.load(os.path.join(out, 'rank0.pt')), torch.load(os.path.join(out, 'rank1.pt'))
+    assert r0['fits'] == 1 and r1['fits'] == 0
+    assert torch.equal(r0['mean'], r1['mean']) and torch.equal(r0['std'], r1['std'])
+    assert sorted(os.listdir(ck)) == ['standardizewhiteningtransform_1.pth']            # no temporary file left behind
