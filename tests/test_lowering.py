@@ -207,6 +207,12 @@ def test_unsupported_patterns_fail_loudly():
     with pytest.raises(ValueError):
         lower('c3,16,3,1,1 n a r1 fc16,10', False, False, 0.0, 2, 8, 8)                     # 'f' narrower than the flattened map
     with pytest.raises(ValueError):
+        lower('c3,16,3,1,1 n a c8,16,3,1,1 ap8,1,0 fc16,10', False, False, 0.0, 2, 8, 8)      # a mid-network 'c' whose input width is not the map's
+    with pytest.raises(NotImplementedError):
+        lower('c3,16,3,1,1 n a c16,12,3,1,1 ap8,1,0 fc12,10', False, False, 0.0, 2, 8, 8, fp32=False)     # ... or whose channel counts are no multiple of the 16-byte chunk (8 in 16 bits)
+    with pytest.raises(ValueError):
+        lower('c3,16,3,1,1 n a ap9,1,0 fc16,10', False, False, 0.0, 2, 8, 8)                  # AvgPool2d larger than the (padded) map: torch raises too
+    with pytest.raises(ValueError):
         lower('c3,16,3,1,1 x1 ap8,1,0 fc16,10', False, False, 0.0, 2, 8, 8)
     with pytest.raises(AttributeError):
         lower('c3,16 r1 ap8,1,0 fc16,10', False, False, 0.0, 2, 8, 8)
