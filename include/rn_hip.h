@@ -109,11 +109,15 @@ typedef struct rn_plan rn_plan;
 
 const char* rn_last_error(void);
 /* ABI version: bumped with EVERY change of an entry point's signature or meaning; a binding refuses a library of another version (a stale
- * librn_hip.so would otherwise take shifted pointer / integer arguments).  3: round 3 (operand-set flags of rn_conv_kernel_names, workspaces). */
-#define RN_ABI_VERSION 8
+ * librn_hip.so would otherwise take shifted pointer / integer arguments).  3: round 3 (operand-set flags of rn_conv_kernel_names, workspaces).
+ * 9: round 4 (rn_set_variant2). */
+#define RN_ABI_VERSION 9
 int rn_version(void);
 /* kernel-variant switch for A/B measurements (tools/conv_bench.py; bits documented in csrc/conv_igemm.hip); 0 = shipped */
 void rn_set_variant(int v);
+/* second switch word (round 4; bits documented in csrc/conv_igemm8r.hip): 1 = never take the row-patch 256 x 160 convolution kernel (igemm8r), 2 = take it on any
+ * grid size (tests, tools/conv_bench.py); 0 = shipped */
+void rn_set_variant2(int v);
 /* Stream-K workspace of the 256-row convolution kernels (csrc/conv_igemm8.hip): device memory of rn_conv_workspace_bytes() bytes whose first 4 KiB are
  * zero (tile tickets; the kernels leave them zero), owned by the caller, used by one stream at a time.  NULL (default): whole tiles only. */
 size_t rn_conv_workspace_bytes(void);

@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librn_hip.so')
 
 OP_NBUF, OP_NDIM = 8, 20
-ABI_VERSION = 8          # include/rn_hip.h RN_ABI_VERSION this binding was written for
+ABI_VERSION = 9          # include/rn_hip.h RN_ABI_VERSION this binding was written for
 
 
 class RnOp(C.Structure):
@@ -63,6 +63,7 @@ def lib():
     L.rn_sgd_step.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, f32, vp]
     L.rn_sgd_step_amp.argtypes = [vp, vp, vp, i64, f32, f32, f32, f32, i32, i32, vp, vp, vp]
     L.rn_set_variant.argtypes = [i32]
+    L.rn_set_variant2.argtypes = [i32]
     L.rn_conv_workspace_bytes.restype = sz
     L.rn_set_conv_workspace.argtypes = [vp, sz]
     L.rn_augment_batch.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]
@@ -73,6 +74,8 @@ def lib():
     L.rn_conv_kernel_names.argtypes = [i32, i32, C.POINTER(RnConvGeom), i32, C.c_char_p, sz]
     if os.environ.get('RN_VARIANT'):          # kernel-variant switch for A/B runs (tools/conv_bench.py); unset = shipped configuration
         L.rn_set_variant(int(os.environ['RN_VARIANT']))
+    if os.environ.get('RN_VARIANT2'):
+        L.rn_set_variant2(int(os.environ['RN_VARIANT2']))
     _lib = L
     return L
 

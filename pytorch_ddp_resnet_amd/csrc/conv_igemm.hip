@@ -719,6 +719,14 @@ template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
       if (e >= 0) return e;
     }
   }
+  // row-patch kernel (conv_igemm8r.hip): 3x3 stride 1 with 160 n output channels -- the WRN-28-10 family, which the tiles above do not divide.
+  // rn_set_variant2: 1 = never, 2 = on any grid size.
+  if constexpr (sizeof(T) == 2) {
+    if (!(g_rn_variant2 & 1) && rn_igemm8r_ok(a) && ((g_rn_variant2 & 2) || (long)cdiv(a.M, 256) * (K / 160) >= 192)) {
+      const int e = rn_launch_igemm8r(a, std::is_same<T, bf16_t>::value ? RN_BF16 : RN_F16, s);
+      if (e >= 0) return e;
+    }
+  }
   // LDS-patch kernels (3x3 stride 1, 16-bit types).  The 128-pixel kernel (two workgroups per CU, 23 KiB instead of 36 KiB of DMA per K
   // step) is the default wherever the grid keeps two workgroups on every CU (>= 512 tiles): measured in one process against the im2col
   // kernel on the WRN-28-10 shapes, forward / dgrad: stage 1 (1,024 tiles) 84.5 / 84.1 vs 88.2 / 89.0 us, stage 2 (512 tiles) 65.7 / 67.3

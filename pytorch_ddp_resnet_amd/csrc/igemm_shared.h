@@ -532,3 +532,7 @@ template <int N> __device__ inline void wait_vmcnt() { asm volatile("s_waitcnt v
 // conv_igemm8.hip: 256-row tiles on the eight-phase schedule; returns -1 when the geometry is not one it covers (the caller falls back)
 int rn_launch_igemm8(const IgemmArgs& a, int dtype, hipStream_t s);
 int rn_igemm8_fast(const IgemmArgs& a);
+// conv_igemm8r.hip: 3x3 stride-1 convolutions with 160 n output channels, input staged as row patches (256 x 160 tiles); -1: not covered
+int rn_launch_igemm8r(const IgemmArgs& a, int dtype, hipStream_t s);
+int rn_igemm8r_ok(const IgemmArgs& a);
+extern int g_rn_variant2;         // round-4 switches (rn_set_variant2), defined in conv_igemm8r.hip

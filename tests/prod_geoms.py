@@ -6,7 +6,7 @@ batch that keeps the same kernel choice as b256 but lets the torch-CPU reference
 
 PROD_GEOMS = [
     # ---- WRN-28-10, CIFAR, batch 128 (config 3) ----
-    (128, 32, 32, 160, 160, 3, 1, 1),     # stage 1: igemm_dma<128x160> (1,024 tiles), wgrad<160x160> split 56 ways
+    (128, 32, 32, 160, 160, 3, 1, 1),     # stage 1: igemm8r<256x160> (512 tiles; round 3: igemm_patch<128x160>, 1,024 tiles), wgrad<160x160> split 56 ways
     (128, 32, 32, 160, 320, 3, 2, 1),     # stage 2 entry: stride-2 forward + 4-class dgrad
     (128, 32, 32, 160, 320, 1, 2, 0),     # projection shortcut 160 -> 320
     (128, 16, 16, 320, 320, 3, 1, 1),     # stage 2: 512 tiles
@@ -59,6 +59,13 @@ IGEMM8_GEOMS = [
     (16, 56, 56, 128, 128, 3, 1, 1),      # stage 1 of WRN-50-2: 128 output channels -> column tiles of 128 (igemm8<256x128>), 196 tiles
     (16, 56, 56, 512, 128, 1, 1, 0),      # 1x1 reduce to 128 channels (forward 256x128 tiles; data gradient 256x256)
     (64, 56, 56, 128, 128, 3, 2, 1),      # WRN-50-2 spec A: stride-2 3x3 with 128 channels (parity classes on 256x128 tiles, strided epilogue)
+]
+
+# WRN-28-10's 3x3 stride-1 layers at batch 128 on the row-patch 256 x 160 kernel (conv_igemm8r.hip) by the shipped rule, run with every operand set the
+# block forward / backward launches them with (tests/test_gpu_production_tiles.py::test_igemm8r_production_operand_sets)
+R8_GEOMS = [
+    (128, 32, 32, 160, 160, 3, 1, 1),     # stage 1: 512 tiles, 8 groups of 3 K tiles
+    (128, 16, 16, 320, 320, 3, 1, 1),     # stage 2: 256 tiles, 15 groups
 ]
 
 # the ImageNet stems on the eight-phase kernel's tap-chunk mode (bias + statistics, no residual): tests/test_gpu_production_tiles.py::test_igemm8_stem

@@ -19,7 +19,7 @@ from filler import fill
 from pytorch_ddp_resnet_amd import _lib
 from pytorch_ddp_resnet_amd.engine import ir
 from pytorch_ddp_resnet_amd.engine.lowering import conv_stats_rows
-from prod_geoms import PROD_GEOMS, IGEMM8_GEOMS, STEM8_GEOMS, geom, resolve
+from prod_geoms import PROD_GEOMS, IGEMM8_GEOMS, R8_GEOMS, STEM8_GEOMS, geom, resolve
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,7 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
-def run_conv_case(g, dtype, variant=0, expect_same_names=True, fwd_res=True, dgrad_merge='none', xmask=False):
+def run_conv_case(g, dtype, variant=0, expect_same_names=True, fwd_res=True, dgrad_merge='none', xmask=False, variant2=0):
     """one convolution layer: pack -> forward(+residual, +stats) -> dgrad(+BN-backward sums) -> wgrad, HIP vs torch-CPU.
     fwd_res: the forward adds an identity residual; dgrad_merge: 'none' | 'res' (dx = conv^T(dy) + shortcut gradient) | 'acc' (dx += conv^T(dy)) --
     the operand sets the block backward of the reference lowers to (the eight-phase kernels are specialised per set).  xmask: the mask fed is exactly
@@ -100,6 +100,7 @@ def run_conv_case(g, dtype, variant=0, expect_same_names=True, fwd_res=True, dgr
         t.copy_(v.reshape(t.shape).to(t.dtype))
     eng.bind({})
     L.rn_set_variant(variant)
+    L.rn_set_variant2(variant2)
     try:
         L.rn_kernel_log(1)
         eng.run(0, len(plan.ops), 0)
@@ -114,6 +115,7 @@ def run_conv_case(g, dtype, variant=0, expect_same_names=True, fwd_res=True, dgr
             assert ran == want, (ran, want)
     finally:
         L.rn_set_variant(0)
+        L.rn_set_variant2(0)
         L.rn_kernel_log(0)
     out = {n: eng.tensors[plan.slot_of[n]].detach().float().cpu() for n in ('y', 'dx', 'dw', 'st', 'dp')}
 
@@ -236,8 +238,9 @@ def test_production_set_reaches_every_instantiation():
 
 @pytest.mark.parametrize('g', [PROD_GEOMS[0], PROD_GEOMS[3]])
 def test_patch_kernel_on_production_shapes(g):
-    """WRN-28-10 stage 1 / stage 2 at batch 128 take the patch kernel by the shipped rule (grids of 512-1024 workgroups, XCD remap, two column tiles)."""
-    ran = run_conv_case(g, 'fp16', expect_same_names=False)
+    """WRN-28-10 stage 1 / stage 2 at batch 128 take the patch kernel (grids of 512-1024 workgroups, XCD remap, two column tiles) when the row-patch
+    256 x 160 kernel of round 4 is switched off (rn_set_variant2 1): the fallback stays parity-tested at size."""
+    ran = run_conv_case(g, 'fp16', expect_same_names=False, variant2=1)
     assert sum(n.startswith('igemm_patch<128x') for n in ran) == 2, ran
 
 
@@ -551,6 +554,7 @@ def test_s2d_stem(shape, variant, fwd_name, dtype):
     eng.bind({})
     L = _lib.lib()
     L.rn_set_variant(variant)
+    L.rn_set_variant2(variant2)
     try:
         L.rn_kernel_log(1)
         eng.run(0, len(plan.ops), 0)
@@ -606,3 +610,77 @@ def test_igemm8_exact_integers(g):
     ref = torch.nn.functional.conv2d(_nchw(torch.from_numpy(xv)), torch.from_numpy(wv).permute(0, 3, 1, 2), padding=p).permute(0, 2, 3, 1)
     assert float(ref.abs().max()) < 2048
     assert torch.equal(eng.tensors[sl['y']].float().cpu(), ref.contiguous())
+
+
+# ---- the row-patch 256 x 160 kernel (conv_igemm8r.hip): 3x3 stride-1 layers with 160 n output channels, the WRN-28-10 family ----
+R8_ANY = 2                           # rn_set_variant2: on any grid size
+R8_SMALL = [
+    (3, 8, 8, 160, 160, 3, 1, 1),        # W = 8: ten-row patches of four images per tile, ONE partly empty tile (192 rows); 15 items, the last group half empty
+    (2, 32, 32, 160, 160, 3, 1, 1),      # W = 32: eight image rows per tile, 8 tiles
+    (1, 16, 16, 320, 320, 3, 1, 1),      # W = 16: a tile = one image; two column tiles; 30 items = 15 full groups
+    (5, 16, 16, 64, 160, 3, 1, 1),       # 64 input channels: 6 items = 3 groups (forward only: the data gradient has 64 output channels)
+    (2, 16, 16, 96, 160, 3, 1, 1),       # 96 input channels: 9 items, 5 groups, kernel rows change inside a group
+    (9, 8, 8, 160, 320, 3, 1, 1),        # 576 pixels = two whole tiles + a quarter; forward 2 column tiles
+    (3, 24, 16, 160, 160, 3, 1, 1),      # H = 24: 16-row tiles straddle images (vertical padding inside a patch)
+    (300, 8, 8, 160, 160, 3, 1, 1),      # 75 tiles on 75 workgroups: several per XCD class (the remap with a remainder)
+    (70, 16, 16, 160, 320, 3, 1, 1),     # 140 tiles forward (two column tiles), 70 in the data gradient
+]
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('merge', ['none', 'res', 'acc'])
+@pytest.mark.parametrize('g', R8_SMALL)
+def test_igemm8r_on_small_geometries(g, merge, dtype):
+    """the row-patch kernel forced onto small shapes: every map width it takes (8 / 16 / 32), channel counts whose items end inside a group, tiles that
+    straddle images, a partly empty tile, every operand set (forward +- residual; data gradient with the BatchNorm-backward sums alone / + shortcut
+    gradient / accumulating), fused statistics rows shared by two waves."""
+    if g[0] >= 70 and (dtype == 'bf16' or merge != 'none'):
+        pytest.skip('the larger grids once')
+    ran = run_conv_case(g, dtype, variant2=R8_ANY, fwd_res=(merge == 'none'), dgrad_merge=merge)
+    assert ran[0] == 'igemm8r<256x160:' + ('res>' if merge == 'none' else 'plain>'), ran
+    if g[3] % 160 == 0:
+        assert ran[1] == 'igemm8r<256x160:' + {'none': 'bnb>', 'res': 'bnb+res>', 'acc': 'bnb+acc>'}[merge], ran
+
+
+def test_igemm8r_more_tiles_than_workgroups():
+    """600 tiles on 256 persistent workgroups: two to three tiles per workgroup (the next tile's prologue under the previous tile's epilogue), XCD remap."""
+    ran = run_conv_case((300, 16, 16, 160, 320, 3, 1, 1), 'fp16', variant2=R8_ANY)
+    assert ran[0] == 'igemm8r<256x160:res>' and ran[1] == 'igemm8r<256x160:bnb>', ran
+
+
+@pytest.mark.parametrize('g', [(2, 32, 32, 160, 160, 3, 1, 1), (3, 8, 8, 160, 320, 3, 1, 1), (2, 16, 16, 96, 160, 3, 1, 1)])
+def test_igemm8r_exact_integers(g):
+    """integer-valued operands: the convolution equals the reference BIT FOR BIT (a wrong lane <-> pixel / channel map of the transposed products, of the
+    fifth column tile's transpose over pixel tiles, a mis-paired item half or a mis-shifted tap cannot hide behind a tolerance)."""
+    N, Hh, W, C, K, k, s_, p = g
+    eng, sl = _one_op_engine(ir.OP_CONV_FWD, g, dict(x=((N, Hh, W, C), 'T'), w_fwd=((K, 9, C), 'T'), y=((N, Hh, W, K), 'T')))
+    rng = np.random.RandomState(1)
+    xv = rng.randint(-2, 3, size=(N, Hh, W, C)).astype(np.float32)
+    wv = rng.randint(-1, 2, size=(K, 3, 3, C)).astype(np.float32)
+    eng.tensors[sl['x']].copy_(torch.from_numpy(xv).to(torch.float16))
+    eng.tensors[sl['w_fwd']].copy_(torch.from_numpy(wv).reshape(K, 9, C).to(torch.float16))
+    eng.bind({})
+    L = _lib.lib()
+    L.rn_set_variant2(R8_ANY)
+    try:
+        L.rn_kernel_log(1)
+        eng.run(0, 1, 0)
+        torch.cuda.synchronize()
+        assert 'igemm8r<256x160:plain>' in L.rn_kernel_log_read().decode()
+    finally:
+        L.rn_kernel_log(0)
+        L.rn_set_variant2(0)
+    ref = torch.nn.functional.conv2d(_nchw(torch.from_numpy(xv)), torch.from_numpy(wv).permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    assert float(ref.abs().max()) < 2048                     # representable in fp16: the stored output is exact too
+    assert torch.equal(eng.tensors[sl['y']].float().cpu(), ref.contiguous())
+
+
+@pytest.mark.parametrize('ops,dtype', [((True, 'none'), 'fp16'), ((True, 'none'), 'bf16'), ((False, 'res'), 'fp16'), ((False, 'acc'), 'fp16')])
+@pytest.mark.parametrize('g', R8_GEOMS)
+def test_igemm8r_production_operand_sets(g, ops, dtype):
+    """WRN-28-10's stage-1 / stage-2 layers at batch 128 by the SHIPPED rule (512 / 256 tiles on 256 persistent workgroups), with every operand set the
+    block forward / backward launches them with (residual_block.py:67-99, pre-activation + dropout: conv1 plain + statistics, conv2 + identity residual;
+    data gradients with the BatchNorm-backward sums alone, + the shortcut gradient, accumulating into dx)."""
+    ran = run_conv_case(g, dtype, fwd_res=ops[0], dgrad_merge=ops[1])
+    assert ran[0] == 'igemm8r<256x160:' + ('res>' if ops[0] else 'plain>'), ran
+    assert ran[1] == 'igemm8r<256x160:' + {'none': 'bnb>', 'res': 'bnb+res>', 'acc': 'bnb+acc>'}[ops[1]], ran

@@ -11,7 +11,7 @@ import pytest
 from pytorch_ddp_resnet_amd import _lib
 from pytorch_ddp_resnet_amd.engine import ir
 from pytorch_ddp_resnet_amd.engine.lowering import lower
-from prod_geoms import PROD_GEOMS, IGEMM8_GEOMS, STEM8_GEOMS, CONFIGS, geom, resolve
+from prod_geoms import PROD_GEOMS, IGEMM8_GEOMS, R8_GEOMS, STEM8_GEOMS, CONFIGS, geom, resolve
 
 pytestmark = pytest.mark.skipif(not os.path.exists(_lib.LIB_PATH), reason='librn_hip.so not built')
 
@@ -47,6 +47,12 @@ def _tested_names(dtype):
         if dtype == ir.RN_F32:
             break
         for p, fls in ((0, (1, 3)), (1, (1, 3, 5, 17)), (2, (0,))):            # 17: sums with the mask computed from x (test_igemm8_mask_from_x)
+            for fl in fls:
+                names.update(_lib.conv_kernel_names(p, dtype, geom(*g), fused_epilogue=fl))
+    for g in R8_GEOMS:                         # test_igemm8r_production_operand_sets: every operand set of the row-patch kernel
+        if dtype == ir.RN_F32:
+            break
+        for p, fls in ((0, (1, 3)), (1, (1, 3, 5, 17)), (2, (0,))):
             for fl in fls:
                 names.update(_lib.conv_kernel_names(p, dtype, geom(*g), fused_epilogue=fl))
     return names
