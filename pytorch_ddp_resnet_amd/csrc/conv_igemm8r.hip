@@ -250,7 +250,8 @@ __host__ __device__ inline int r8_mode(const IgemmArgs& a) {     // -1: an opera
 
 struct Items { int i0, h0, i1, h1; };          // the two (kernel row, half chunk) items of a group; i >= 3: past the end
 
-template <typename T, int EPM>
+// PROBE (diagnostic instantiations, rn_set_variant2 bits 4-6; wrong results, timing only): 1 = no LDS-DMA in the K loop, 2 = no MFMA, 3 = no fragment reads
+template <typename T, int EPM, int PROBE = 0>
 __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
   constexpr int BM = 256, BN = 160, ES = 2;
   constexpr int WN = 2;                                     // 4 x 2 waves of 64 x 80
@@ -381,19 +382,26 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
 
   f32x4 acc[RT][CT];
   uint4 bf[CT][2], af[2][2];
+  if constexpr (PROBE == 3) {
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) bf[ct][0] = bf[ct][1] = make_uint4(lane, 1, 2, 3);
+    af[0][0] = af[0][1] = af[1][0] = af[1][1] = make_uint4(3, 2, 1, lane);
+  }
   // one K tile (g, J) = two phases.  F bit 0: the patch of group g+1 is issued during this group; bit 1: K tile kt+2 exists (its weights are issued);
   // bit 2: K tile kt+1 exists (its weights, and a next group's patch, are waited for)
   auto ktile = [&](auto jtag, auto ftag, int a_cur, unsigned a_nxt, int my_i_n, unsigned sel_a_n, unsigned sel_b, bool ok_b) {
     constexpr int J = decltype(jtag)::value, F = decltype(ftag)::value;
-    constexpr bool IA = (F & 1) != 0, IB = (F & 2) != 0, NEXT = (F & 4) != 0;
+    constexpr bool IA = (F & 1) != 0 && PROBE != 1, IB = (F & 2) != 0 && PROBE != 1, NEXT = (F & 4) != 0;
     const uint4* SB = &smem[B_0 + J * B_SZ];               // K tile 3g + J lives in weight stage J
     const uint4* SA = &smem[a_cur];
     const unsigned b_nxt = lds0 + (unsigned)((B_0 + ((J + 2) % 3) * B_SZ) * 16);
     // ---- phase 1: all B fragments, A rows 0-31 of the wave ----
+    if constexpr (PROBE != 3) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) { bf[ct][0] = SB[fb0 + ct * 128]; bf[ct][1] = SB[(fb0 ^ 4) + ct * 128]; }
+      for (int ct = 0; ct < CT; ++ct) { bf[ct][0] = SB[fb0 + ct * 128]; bf[ct][1] = SB[(fb0 ^ 4) + ct * 128]; }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { af[i][0] = SA[fa[J][i]]; af[i][1] = SA[fa[J][i] ^ 4]; }
+      for (int i = 0; i < 2; ++i) { af[i][0] = SA[fa[J][i]]; af[i][1] = SA[fa[J][i] ^ 4]; }
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (IA || IB) {
       const unsigned keep = m0_save();
@@ -410,12 +418,17 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) Mfma16<T>::run(bf[ct][ks], af[i][ks], acc[i][ct]);
+        for (int ct = 0; ct < CT; ++ct) {
+          if constexpr (PROBE != 2) Mfma16<T>::run(bf[ct][ks], af[i][ks], acc[i][ct]);
+          else asm volatile("" : "+v"(acc[i][ct]) : "v"(bf[ct][ks].x), "v"(bf[ct][ks].w), "v"(af[i][ks].x), "v"(af[i][ks].w));
+        }
     __builtin_amdgcn_s_setprio(0);
     raw_barrier();
     // ---- phase 2: A rows 32-63 of the wave, B from registers ----
+    if constexpr (PROBE != 3) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) { af[i][0] = SA[fa[J][2 + i]]; af[i][1] = SA[fa[J][2 + i] ^ 4]; }
+      for (int i = 0; i < 2; ++i) { af[i][0] = SA[fa[J][2 + i]]; af[i][1] = SA[fa[J][2 + i] ^ 4]; }
+    }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (IA || IB) {
       const unsigned keep = m0_save();
@@ -437,7 +450,10 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int ct = 0; ct < CT; ++ct) Mfma16<T>::run(bf[ct][ks], af[i][ks], acc[2 + i][ct]);
+        for (int ct = 0; ct < CT; ++ct) {
+          if constexpr (PROBE != 2) Mfma16<T>::run(bf[ct][ks], af[i][ks], acc[2 + i][ct]);
+          else asm volatile("" : "+v"(acc[2 + i][ct]) : "v"(bf[ct][ks].x), "v"(bf[ct][ks].w), "v"(af[i][ks].x), "v"(af[i][ks].w));
+        }
     __builtin_amdgcn_s_setprio(0);
     raw_barrier();
   };
@@ -450,6 +466,9 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
   for (int itn = 0;; ++itn) {
     const int vb = itn * Gw + blockIdx.x;
     const bool more = vb < ntiles;                          // wave-uniform
+    const unsigned long long* stp = itn < 2 ? a.stamps : nullptr;      // diagnostic (rn_set_stamp_buffer): the workgroup's first two tiles, slots 6 itn + 0..5
+    const int sb = 6 * itn;
+    stamp(stp, sb);
     int m0 = 0, n0 = 0;
     Items cur{0, 0, 0, 1}, nxt{0, 0, 0, 0};
     if (more) {
@@ -462,6 +481,7 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
       if (tile - mt * nnt >= nnt) ++mt;
       m0 = mt * BM; n0 = (tile - mt * nnt) * BN;
       tile_roles(m0, n0);
+      stamp(stp, sb + 1);
       // prologue: the patch of group 0 into A buffer 0, the weights of K tiles 0 and 1 into stages 0 and 1 (every wave has left the previous K loop)
       const int mi = lane_i(cur);
       const unsigned sa = lane_src(cur);
@@ -479,12 +499,14 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
       m0_restore(keep);
       nxt = cur; items_next(nxt);
     }
+    stamp(stp, sb + 2);
     // the previous tile leaves the registers while this one's first pieces are in flight
     bool stores_behind = false;
     if (pm0 >= 0) {
       stores_behind = pm0 + BM <= a.M;
       epilogue8r<T, EPM>(a, acc, pm0 + wm * WTM, pn0 + wn * WTN, lane, corner, (wm & 1) != 0, WN * CORNER);
     }
+    stamp(stp, sb + 3);
     if (!more) break;
 #pragma unroll
     for (int i = 0; i < RT; ++i)
@@ -497,6 +519,7 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
     else wait_vm(nBw);
     raw_barrier();
     if (wave >= 4) raw_barrier();                           // the second wave group runs one barrier behind
+    stamp(stp, sb + 4);
 
     int a_cur = 0;
     for (int g = 0; g + 1 < G; ++g) {
@@ -513,6 +536,7 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
     ktile(I1{}, F4{}, a_cur, 0u, 0, 0u, 0u, false);
     ktile(I2{}, std::integral_constant<int, 0>{}, a_cur, 0u, 0, 0u, 0u, false);
     if (wave < 4) raw_barrier();                            // the first group waits for the second: every wave has executed the same barriers
+    stamp(stp, sb + 5);
     pm0 = m0; pn0 = n0;
   }
 }
@@ -547,6 +571,16 @@ template <typename T> int launch8r(IgemmArgs& a, hipStream_t s) {
   { const unsigned nnt = (unsigned)(a.Kd / 160); a.w8_magic_nnt = nnt <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / nnt); }
   const int ntiles = cdiv(a.M, 256) * (a.Kd / 160);
   const int grid = ntiles < 256 ? ntiles : 256;
+  if constexpr (std::is_same<T, f16_t>::value) {
+    const int probe = (g_rn_variant2 >> 4) & 7;
+    if (probe && epm == R8_PLAIN) {
+      if (probe == 1) hipLaunchKernelGGL((igemm8r_kernel<T, R8_PLAIN, 1>), dim3(grid), dim3(512), 0, s, a);
+      else if (probe == 2) hipLaunchKernelGGL((igemm8r_kernel<T, R8_PLAIN, 2>), dim3(grid), dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((igemm8r_kernel<T, R8_PLAIN, 3>), dim3(grid), dim3(512), 0, s, a);
+      RN_CHECK_LAUNCH("igemm8r probe");
+      return 0;
+    }
+  }
   switch (epm) {
     case R8_PLAIN: hipLaunchKernelGGL((igemm8r_kernel<T, R8_PLAIN>), dim3(grid), dim3(512), 0, s, a); break;
     case R8_RES: hipLaunchKernelGGL((igemm8r_kernel<T, R8_RES>), dim3(grid), dim3(512), 0, s, a); break;

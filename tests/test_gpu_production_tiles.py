@@ -91,7 +91,12 @@ def run_conv_case(g, dtype, variant=0, expect_same_names=True, fwd_res=True, dgr
         cf32 = cf.float()
         bmv = ((bxv.double() * cf32[0].double() + cf32[1].double()) > 0).to(bxv.dtype)
 
-    eng = Engine(plan, h.DEV, TORCH_DT[dtype])
+    L.rn_set_variant2(variant2)                             # (before the engine: workspace sizes and deferral marks follow the kernel choice)
+    try:
+        eng = Engine(plan, h.DEV, TORCH_DT[dtype])
+    except Exception:
+        L.rn_set_variant2(0)
+        raise
     feed = dict(x=xv, w=wv, dy=dyv, res=resv, bx=bxv, bm=bmv, coef=cf, dres=dresv)
     if dgrad_merge == 'acc':
         feed['dx'] = dresv                                   # the destination already holds the other branch's gradient
@@ -684,3 +689,49 @@ def test_igemm8r_production_operand_sets(g, ops, dtype):
     ran = run_conv_case(g, dtype, fwd_res=ops[0], dgrad_merge=ops[1])
     assert ran[0] == 'igemm8r<256x160:' + ('res>' if ops[0] else 'plain>'), ran
     assert ran[1] == 'igemm8r<256x160:' + {'none': 'bnb>', 'res': 'bnb+res>', 'acc': 'bnb+acc>'}[ops[1]], ran
+
+
+# ---- the 320 x 160 weight-gradient kernel of the 160-channel family (conv_wgrad8r.hip) ----
+W8R_ANY = 8                          # rn_set_variant2: at any size (its rule wants >= 2,048 tile x K-tile units)
+W8R_SMALL = [
+    (2, 16, 16, 160, 160, 3, 1, 1),      # five units (four tap pairs + a single tap: half of the last tile's rows empty), 8 K tiles, padding taps
+    (3, 8, 8, 320, 160, 3, 1, 1),        # 320 input channels: a unit = the two 160-channel slices of one tap; 3 K tiles
+    (2, 16, 16, 160, 320, 3, 2, 1),      # stride 2, two output-channel tiles
+    (4, 8, 8, 320, 640, 1, 2, 0),        # stride-2 1x1 (projection shortcut): ONE unit, four output-channel tiles; one K tile
+    (1, 7, 9, 160, 160, 3, 1, 1),        # 63 pixels: a single, partly empty K tile
+    (5, 12, 12, 320, 320, 3, 1, 1),      # pixel tail (720 = 11 x 64 + 16), splits that cut the K-tile range unevenly
+    (37, 16, 16, 160, 160, 3, 1, 1),     # 148 K tiles x 5 tiles: ~51 splits, more than one item per workgroup for some
+]
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('g', W8R_SMALL)
+def test_wgrad8r_on_small_geometries(g, dtype):
+    """the 320 x 160 weight-gradient kernel forced onto small shapes: per-pixel LDS rows filled by global_load_lds (zero page for padding taps, pixel tails
+    and the pad chunks), whole-row XOR swizzle under the transposed reads, segment pairs across taps / across channel slices, strides, slabs."""
+    ran = run_conv_case(g, dtype, variant2=W8R_ANY | R8_ANY)
+    assert 'wgrad8r<320x160>' in ran, ran
+
+
+def test_wgrad8r_exact_integers():
+    """integer operands: bit for bit against the reference (lane <-> channel maps of the transposed fragments, tap pairing, slab sums in fixed order)."""
+    for g in [(2, 16, 16, 160, 160, 3, 1, 1), (3, 8, 8, 320, 320, 3, 1, 1)]:
+        N, Hh, W, C, K, k, s_, p = g
+        eng, sl = _one_op_engine(ir.OP_CONV_WGRAD, g, dict(x=((N, Hh, W, C), 'T'), dy=((N, Hh, W, K), 'T'), dw=((K, 3, 3, C), 'f32'), ws=((0,), 'u8')))
+        rng = np.random.RandomState(0)
+        xv = rng.randint(-3, 4, size=(N, Hh, W, C)).astype(np.float32)
+        dv = rng.randint(-2, 3, size=(N, Hh, W, K)).astype(np.float32)
+        eng.tensors[sl['x']].copy_(torch.from_numpy(xv).to(torch.float16)); eng.tensors[sl['dy']].copy_(torch.from_numpy(dv).to(torch.float16))
+        eng.bind({})
+        L = _lib.lib()
+        L.rn_set_variant2(W8R_ANY)
+        try:
+            L.rn_kernel_log(1)
+            eng.run(0, 1, 0)
+            torch.cuda.synchronize()
+            assert 'wgrad8r<320x160>' in L.rn_kernel_log_read().decode()
+        finally:
+            L.rn_kernel_log(0)
+            L.rn_set_variant2(0)
+        ref = torch.nn.grad.conv2d_weight(_nchw(torch.from_numpy(xv)), (K, C, 3, 3), _nchw(torch.from_numpy(dv)), 1, 1).permute(0, 2, 3, 1)
+        assert torch.equal(eng.tensors[sl['dw']].cpu(), ref.contiguous()), g
