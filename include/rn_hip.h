@@ -265,6 +265,23 @@ typedef struct rn_wgrad_desc {
 } rn_wgrad_desc;
 int rn_conv_wgrad_batch_key(const rn_conv_geom* g, int dtype, int flags);
 int rn_conv_wgrad_batch(const rn_wgrad_desc* descs, int n, int dtype, rn_stream s);
+/* Wide layers of the 160-channel family (WRN-28-10: 3x3 convolutions with 160 n channels): the weight gradients of up to RN_WGRAD8R_BATCH_MAX layers of ONE
+ * geometry as one launch of the 320 x 160 kernel (csrc/conv_wgrad8r.hip).  A 160-channel layer has five output tiles, so a launch of its own cuts the pixels
+ * ~51 ways (47 MB of fp32 slabs per layer); n layers in one launch take ~1/n of those splits each.  Every record's slabs go to its own workspace (ws_bytes >=
+ * what rn_conv_wgrad_ws_bytes gives the layer is always enough) and are summed into its dw (+= with RN_F_ACCUM) by the fixed-order reductions right behind,
+ * on the same stream: the gradients of a batch are bitwise reproducible for a given n.  rn_conv_wgrad8r_ok: 1 when the geometry is one the kernel takes. */
+#define RN_WGRAD8R_BATCH_MAX 12
+typedef struct rn_wgrad8r_desc {
+  const void* x;
+  const void* dy;
+  float* dw;
+  void* ws;
+  size_t ws_bytes;
+  rn_conv_geom g;
+  int32_t flags;
+} rn_wgrad8r_desc;
+int rn_conv_wgrad8r_ok(const rn_conv_geom* g, int dtype);
+int rn_conv_wgrad8r_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, rn_stream s);
 unsigned rn_op_output_mask(int kind);    /* bit b set: an op of this kind WRITES buf[b] (rn_plan_run sends a queued weight gradient out before an op that
                                           * would rewrite one of its operands); mirrored by engine/ir.py OP_OUTPUTS, checked by tests/test_abi.py */
 long rn_wgrad_batch_launches(void);      /* diagnostic: batched launches this process has issued (the kernel log keeps the per-record tile names) */

@@ -80,7 +80,10 @@ def training_loop(rank, world_size, device, dl_train, dl_test, classifier, optim
             save_checkpoints(checkpoint_dir, {'checkpoint_strategy': checkpoint_strategy, 'classifier': ddp_keys(classifier), 'optimizer': optimizer,
                                               'scheduler': scheduler, 'scaler': scaler}, steps=steps)
 
-    epoch = 0
+    # a resumed run continues the epoch count (training.py:87-88: sampler_train.set_epoch(checkpoint_strategy.epoch_step)); setup() loads the strategy on every
+    # rank, so the start value agrees across ranks, and from here on every rank counts for itself (the reference advances the counter on rank 0 only)
+    epoch = checkpoint_strategy.epoch_step if checkpoint_strategy is not None else 0
+    saving = rank == 0 and checkpoint_strategy is not None and checkpoint_dir is not None
     while global_step < max_steps:
         if sampler_train is not None:
             sampler_train.set_epoch(epoch)
@@ -102,7 +105,7 @@ def training_loop(rank, world_size, device, dl_train, dl_test, classifier, optim
                     last_loss[0] = means.get('loss')
                     if rank == 0:
                         log(f"global step: {gs}... loss: {means.get('loss')}")
-                    maybe_save('batch', means.get('loss'), gs + 1)           # training.py:129-139 (resolved one microbatch late, in step order)
+                    maybe_save('batch', means.get('loss'), gs + 1)           # training.py:129-139 (in step order; see `saving` below for WHEN)
                     running = Counter()
 
         for microbatch_id, (x, y) in enumerate(dl_train, 1):
@@ -110,7 +113,12 @@ def training_loop(rank, world_size, device, dl_train, dl_test, classifier, optim
             pm = train_step(classifier, x, y, optimizer, reducer, world_size, microbatch_id, num_microbatches, acc, lazy=True, scaler=scaler)
             closes = microbatch_id % num_microbatches == 0
             pending.append((pm, closes, global_step))
-            resolve(1)                                     # everything but the microbatch just enqueued
+            # A step whose observation may write a checkpoint is closed on the host NOW, before the next train_step enqueues another optimizer step: the
+            # files of step k hold the weights, BatchNorm statistics, momentum and scaler state after exactly k steps, as the reference's synchronous loop
+            # writes them (training.py:129-139).  Every other step keeps the lagged read (the device never waits for the host).
+            resolve(1)                                     # everything but the microbatch just enqueued (the strategy's counters are current after this)
+            if closes and saving and checkpoint_strategy.may_save('batch'):
+                resolve(0)
             if closes:
                 if scheduler is not None and scheduler_step_unit == 'batch':
                     if requires_loss(scheduler):

@@ -19,6 +19,9 @@ int rn_launch_wgrad8(const void* x, const void* dy, float* out, int splits, int 
 // conv_wgrad8r.hip: 320 x 160 tiles for channel counts that are multiples of 160 (the WRN-28-10 family)
 int rn_wgrad8r_splits(const rn_conv_geom* g, int dtype);
 int rn_launch_wgrad8r(const void* x, const void* dy, float* out, int splits, int accumulate, int dtype, const rn_conv_geom* g, int max_grid, hipStream_t s);
+// conv_wgrad9.hip: 3x3 stride-1 layers with 160 n output channels, all nine taps from one staged input patch (288 x 160 tiles)
+int rn_wgrad9_splits(const rn_conv_geom* g, int dtype);
+int rn_launch_wgrad9(const void* x, const void* dy, float* out, int splits, int dtype, const rn_conv_geom* g, int max_grid, hipStream_t s);
 
 namespace {
 
@@ -548,11 +551,12 @@ template <typename T> int dispatch_wb(const WgradBatch& wb, int grid, int bk, in
 }  // namespace
 
 // the kernel choice and the argument record of one weight gradient (everything but the output pointer): rn_conv_wgrad and the batched launch share it
-struct WgradSel { int w8, w8r, bk, bc; bool ic; };
+struct WgradSel { int w8, w9, w8r, bk, bc; bool ic; };
 static void wgrad_fill(WgradArgs& a, WgradSel& sel, const void* x, const void* dy, const rn_conv_geom* g, int dtype, int flags) {
   const int ce = dtype == RN_F32 ? 4 : 8;
   sel.w8 = rn_wgrad8_splits(g, dtype);                  // > 0: the eight-phase kernel with that many pixel splits (its slabs take the same reduction)
-  sel.w8r = sel.w8 > 0 ? 0 : rn_wgrad8r_splits(g, dtype);     // > 0: the 320 x 160 kernel of the 160-channel family, likewise
+  sel.w9 = sel.w8 > 0 ? 0 : rn_wgrad9_splits(g, dtype);       // > 0: the nine-tap 288 x 160 kernel (3x3 stride 1, 160 n output channels), likewise
+  sel.w8r = (sel.w8 > 0 || sel.w9 > 0) ? 0 : rn_wgrad8r_splits(g, dtype);     // > 0: the 320 x 160 kernel of the 160-channel family, likewise
   const bool ic = use_im2col(g, ce);
   const int bk = pick_tile(g->K), bc = col_tile(g, ic, bk);
   sel.ic = ic; sel.bk = bk; sel.bc = bc;
@@ -574,9 +578,29 @@ static void wgrad_fill(WgradArgs& a, WgradSel& sel, const void* x, const void* d
   // (26 per WRN-28-10 step); with an eighth of the slots left free they dispatch at once.  rn_set_variant 1 << 24: full round.
   const int round = (g_rn_variant & (1 << 23)) ? 512 : wgrad_capacity(bk, bc, ce);       // 1 << 23: the fixed 512-workgroup round (A/B)
   const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? round / 8 * 7 : round;
-  a.splits = sel.w8 > 0 ? sel.w8 : (sel.w8r > 0 ? sel.w8r : wgrad_splits(g, bk, bc, ic, capacity));
+  a.splits = sel.w8 > 0 ? sel.w8 : (sel.w9 > 0 ? sel.w9 : (sel.w8r > 0 ? sel.w8r : wgrad_splits(g, bk, bc, ic, capacity)));
   a.rows_per_split = ((a.M + a.splits - 1) / a.splits + 31) / 32 * 32;
   a.kt = cdiv(g->K, bk); a.ct = cdiv(ic ? g->R * g->S * g->C : g->C, bc);
+}
+
+// dw (+)= sum of `splits` slabs of n floats, in slab order per output (the kernel depends on the shape only: bitwise reproducible)
+int rn_wgrad_reduce_slabs(const float* ws, float* dw_krsc, long n, int splits, int accum, int eight_phase, hipStream_t s) {
+  const long n4 = n / 4;
+  if (reduce_is_wide(splits, n4) && n4 >= 16384) {   // a thread per output chunk fills the chip: same sums, no LDS step
+    hipLaunchKernelGGL(wgrad_reduce_lanes_kernel, dim3((int)((n4 + 255) / 256)), dim3(256), 0, s, ws, dw_krsc, n, splits, accum);
+  } else if (reduce_is_wide(splits, n4)) {
+    const int blocks = reduce_wide_blocks(n4);
+    hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(blocks), dim3(256), 0, s, ws, dw_krsc, n, splits, accum);
+  } else if (eight_phase && n4 >= 65536) {           // the eight-phase kernels' large slabs: a thread per chunk, four slabs in flight (same sums)
+    hipLaunchKernelGGL(wgrad_reduce_mlp_kernel, dim3((int)((n4 + 255) / 256)), dim3(256), 0, s, ws, dw_krsc, n, splits, accum);
+  } else {
+    int blocks = (int)((n4 + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, s, ws, dw_krsc, n, splits, accum);
+  }
+  RN_CHECK_LAUNCH("wgrad_reduce");
+  return 0;
 }
 
 extern "C" size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g) {
@@ -590,7 +614,9 @@ extern "C" size_t rn_conv_wgrad_ws_bytes(const rn_conv_geom* g) {
   }
   const int w8 = rn_wgrad8_splits(g, RN_F16);             // the eight-phase kernel's own split count (16-bit engines)
   size_t need8 = w8 > 0 ? (size_t)w8 * g->K * g->R * g->S * g->C * sizeof(float) : 0;
-  const int w8r = w8 > 0 ? 0 : rn_wgrad8r_splits(g, RN_F16);
+  const int w9 = w8 > 0 ? 0 : rn_wgrad9_splits(g, RN_F16);
+  const int w8r = (w8 > 0 || w9 > 0) ? 0 : rn_wgrad8r_splits(g, RN_F16);
+  if (w9 > 0) need8 = (size_t)w9 * g->K * g->R * g->S * g->C * sizeof(float);
   if (w8r > 0) need8 = (size_t)w8r * g->K * g->R * g->S * g->C * sizeof(float);
   return need8 > best ? need8 : best;
 }
@@ -606,7 +632,7 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   WgradSel sel;
   WgradArgs a{};
   wgrad_fill(a, sel, x, dy, g, dtype, flags);
-  const int w8 = sel.w8, w8r = sel.w8r, bk = sel.bk, bc = sel.bc;
+  const int w8 = sel.w8, w9 = sel.w9, w8r = sel.w8r, bk = sel.bk, bc = sel.bc;
   const size_t n = (size_t)g->K * a.RS * g->C;
   const bool direct = a.splits == 1 && !(flags & RN_F_ACCUM);
   if (!direct) {
@@ -618,6 +644,7 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
   // rn_set_variant low byte of bits 8..15 is taken elsewhere; RN_W8_FORK_GRID (environment, read once) sizes a forked eight-phase launch for A/B runs
   static const int w8_fork_grid = getenv("RN_W8_FORK_GRID") ? atoi(getenv("RN_W8_FORK_GRID")) : 256;
   if (w8 > 0) e = rn_launch_wgrad8(x, dy, a.out, a.splits, dtype, g, (flags & RN_F_FORK) ? w8_fork_grid : 256, as_stream(s));
+  else if (w9 > 0) e = rn_launch_wgrad9(x, dy, a.out, a.splits, dtype, g, (flags & RN_F_FORK) ? w8_fork_grid : 256, as_stream(s));
   else if (w8r > 0) e = rn_launch_wgrad8r(x, dy, a.out, a.splits, 0, dtype, g, (flags & RN_F_FORK) ? w8_fork_grid : 256, as_stream(s));
   else RN_BY_DTYPE(dtype, e = dispatch_w<T_>(a, bk, bc, as_stream(s)));
   if (e) return e;
@@ -629,24 +656,7 @@ extern "C" int rn_conv_wgrad(const void* x, const void* dy, float* dw_krsc, void
       RN_CHECK_ARG(reduce_is_wide(a.splits, n4), "rn_conv_wgrad: RN_F_DEFER_REDUCE on a geometry whose reduction is not deferrable (rn_conv_wgrad_splits < 0)");
       return 0;
     }
-    if (reduce_is_wide(a.splits, n4) && n4 >= 16384) {   // a thread per output chunk fills the chip: same sums, no LDS step
-      hipLaunchKernelGGL(wgrad_reduce_lanes_kernel, dim3((int)((n4 + 255) / 256)), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), dw_krsc, (long)n,
-                         a.splits, (flags & RN_F_ACCUM) ? 1 : 0);
-    } else if (reduce_is_wide(a.splits, n4)) {
-      const int blocks = reduce_wide_blocks(n4);
-      hipLaunchKernelGGL(wgrad_reduce_wide_kernel, dim3(blocks), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), dw_krsc, (long)n,
-                         a.splits, (flags & RN_F_ACCUM) ? 1 : 0);
-    } else if ((w8 > 0 || w8r > 0) && n4 >= 65536) {                  // the eight-phase kernel's large slabs: a thread per chunk, four slabs in flight (same sums)
-      hipLaunchKernelGGL(wgrad_reduce_mlp_kernel, dim3((int)((n4 + 255) / 256)), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), dw_krsc, (long)n,
-                         a.splits, (flags & RN_F_ACCUM) ? 1 : 0);
-    } else {
-      int blocks = (int)((n4 + 255) / 256);
-      if (blocks > 2048) blocks = 2048;
-      if (blocks < 1) blocks = 1;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(s), reinterpret_cast<const float*>(ws), dw_krsc, (long)n,
-                         a.splits, (flags & RN_F_ACCUM) ? 1 : 0);
-    }
-    RN_CHECK_LAUNCH("wgrad_reduce");
+    return rn_wgrad_reduce_slabs(reinterpret_cast<const float*>(ws), dw_krsc, (long)n, a.splits, (flags & RN_F_ACCUM) ? 1 : 0, (w8 > 0 || w9 > 0 || w8r > 0) ? 1 : 0, as_stream(s));
   }
   return 0;
 }
@@ -658,8 +668,8 @@ extern "C" int rn_conv_wgrad_splits(const rn_conv_geom* g, int dtype, int flags)
   const int bk = pick_tile(g->K), bc = col_tile(g, ic, bk);
   const int round = (g_rn_variant & (1 << 23)) ? 512 : wgrad_capacity(bk, bc, ce);
   const int capacity = ((flags & RN_F_FORK) && !(g_rn_variant & (1 << 24))) ? round / 8 * 7 : round;
-  const int w8 = rn_wgrad8_splits(g, dtype), w8r = w8 > 0 ? 0 : rn_wgrad8r_splits(g, dtype);
-  const int splits = w8 > 0 ? w8 : (w8r > 0 ? w8r : wgrad_splits(g, bk, bc, ic, capacity));
+  const int w8 = rn_wgrad8_splits(g, dtype), w9 = w8 > 0 ? 0 : rn_wgrad9_splits(g, dtype), w8r = (w8 > 0 || w9 > 0) ? 0 : rn_wgrad8r_splits(g, dtype);
+  const int splits = w8 > 0 ? w8 : (w9 > 0 ? w9 : (w8r > 0 ? w8r : wgrad_splits(g, bk, bc, ic, capacity)));
   if (splits == 1 && !(flags & RN_F_ACCUM)) return 0;
   const long n4 = (long)g->K * g->R * g->S * g->C / 4;
   return reduce_is_wide(splits, n4) ? splits : -1;
@@ -673,7 +683,7 @@ extern "C" int rn_conv_wgrad_batch_key(const rn_conv_geom* g, int dtype, int fla
   if (!g || !RN_DTYPE_OK(dtype) || (flags & RN_F_FORK) || (g_rn_variant & (1 << 17))) return 0;        // 1 << 17: never (A/B)
   const int ce = dtype == RN_F32 ? 4 : 8;
   if (g->R != g->S || g->R * g->S > WB_TAPS || g->C % ce || g->K % ce) return 0;
-  if (use_im2col(g, ce) || rn_wgrad8_splits(g, dtype) > 0 || rn_wgrad8r_splits(g, dtype) > 0) return 0;
+  if (use_im2col(g, ce) || rn_wgrad8_splits(g, dtype) > 0 || rn_wgrad9_splits(g, dtype) > 0 || rn_wgrad8r_splits(g, dtype) > 0) return 0;
   if (rn_conv_wgrad_splits(g, dtype, flags) <= 0) return 0;                                           // only slabs whose sums are deferrable
   const int bk = pick_tile(g->K), bc = col_tile(g, false, bk);
   return bk * 1024 + bc;

@@ -19,6 +19,7 @@
 // 160-channel layer are five, which would mean ~51 pixel splits -- 47 MB of slabs -- per layer); split-major inside a layer so that XCD-mates read the
 // same pixels; slabs in the gradient's own layout, summed by the fixed-order kernels of conv_wgrad.hip.
 #include "igemm_shared.h"
+#include <string.h>
 
 __device__ uint4 g_w8r_zero[64];       // 1 KiB of zeros: the source of padding / out-of-range pixels and of the pad chunks
 
@@ -71,7 +72,9 @@ __device__ inline void gdma16(unsigned long long addr, unsigned lds_addr) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(addr), "s"(lds_addr) : "memory");
 }
 
-template <typename T>
+// PROBE (diagnostic instantiations, rn_set_variant2 bits 8-10; wrong results, timing only): 1 = no LDS-DMA in the K loop, 2 = no MFMA, 3 = no fragment reads,
+// 4 = no pixel decode in the K loop (the prologue's addresses again), 5 = DMAs issued but every lane reads the zero page
+template <typename T, int PROBE = 0>
 __global__ __launch_bounds__(512, 2) void wgrad8r_kernel(const W8rBatch b) {
   constexpr int ES = 2;
   constexpr int STGB = 65536, ROWB = 1024;
@@ -87,15 +90,17 @@ __global__ __launch_bounds__(512, 2) void wgrad8r_kernel(const W8rBatch b) {
 
   // ---- DMA roles.  Wave w stages pixels 4w + j and 32 + 4w + j (j = 0..3) of a K tile, one instruction per pixel, lane = physical chunk; the lane's
   // logical chunk for pixel j is lane ^ f, f = 2 (j + 4 ((w >> 1) & 1)); logical chunks [0,20) segment 0, [20,40) segment 1, [40,60) dy, [60,64) pad
-  int lseg[4];
-  unsigned loff[4];
+  // (the lane's segment as three all-ones / zero masks per pixel slot: the 64-bit source address is picked with and / or -- written as a conditional
+  // expression hipcc compiled the pick into divergent branches, 19 exec-mask flips and 130 moves per K tile)
+  unsigned mk0[4], mk1[4], mk2[4], loff[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int c = lane ^ (2 * (j + 4 * ((wave >> 1) & 1)));
-    lseg[j] = c / 20;
-    loff[j] = (unsigned)((c - 20 * lseg[j]) * 16);
-    if (lseg[j] == 3) loff[j] = 0;
+    const int sg = c / 20;
+    mk0[j] = sg == 0 ? 0xFFFFFFFFu : 0u; mk1[j] = sg == 1 ? 0xFFFFFFFFu : 0u; mk2[j] = sg == 2 ? 0xFFFFFFFFu : 0u;
+    loff[j] = sg == 3 ? 0u : (unsigned)((c - 20 * sg) * 16);
   }
+  const unsigned zlo = (unsigned)(zero_page & 0xFFFFFFFFull), zhi = (unsigned)(zero_page >> 32);
 
   // ---- fragment addresses (bytes inside a stage).  Transposed read: lane t = 4q + p of a 16-lane group supplies pixel row q, 8 bytes p of the 32 ----
   const int tq = (lane >> 2) & 3, tp = lane & 3;
@@ -118,50 +123,68 @@ __global__ __launch_bounds__(512, 2) void wgrad8r_kernel(const W8rBatch b) {
   int iM = 0, iQ = 0, ipq = 1, iH = 0, iW = 0, istride = 1;
   unsigned imagic_pq = 0, imagic_q = 0, icrow = 0, ikrow = 0;
   unsigned long long ixb = 0, iyb = 0;
-  // one pixel row: pixel m of the output grid (K tile g, pixel px), into LDS row px of the stage
-  auto stage_pixel = [&](int g, int px, int j, unsigned stage_lds) {
-    const int m = 64 * g + px;
-    unsigned long long a0 = zero_page, a1 = zero_page, ay = zero_page;
-    if (g < kend && m < iM) {                                // wave-uniform
-      int n = (int)__umulhi((unsigned)m, imagic_pq);
-      int rem = m - n * ipq;
-      if (rem >= ipq) { ++n; rem -= ipq; }
-      int p = (int)__umulhi((unsigned)rem, imagic_q);
-      int q = rem - p * iQ;
-      if (q >= iQ) { ++p; q -= iQ; }
-      const int h0 = p * istride + dh0, w0 = q * istride + dw0;
-      if ((unsigned)h0 < (unsigned)iH && (unsigned)w0 < (unsigned)iW) a0 = ixb + (unsigned long long)((unsigned)((n * iH + h0) * iW + w0)) * icrow + xo0;
-      const int h1 = p * istride + dh1, w1 = q * istride + dw1;
-      if (seg1_ok && (unsigned)h1 < (unsigned)iH && (unsigned)w1 < (unsigned)iW) a1 = ixb + (unsigned long long)((unsigned)((n * iH + h1) * iW + w1)) * icrow + xo1;
-      ay = iyb + (unsigned long long)(unsigned)m * ikrow + yo;
-    }
-    const int sg = lseg[j];
-    const unsigned long long base = sg == 0 ? a0 : (sg == 1 ? a1 : (sg == 2 ? ay : zero_page));
-    const bool z = base == zero_page;
-    gdma16(base + (z ? 0u : loff[j]), stage_lds + (unsigned)(px * ROWB));
+  // The source addresses of the wave's pixel rows, decoded with the LANES running over pixels (a scalar decode per pixel -- magic divisions, range checks,
+  // 64-bit address arithmetic: ~90 SALU instructions -- made a phase 800 instructions long, 8 waves on one scalar unit: 5 us per K tile).  Lane l & 7 < 4 decodes
+  // pixel 32 + 4 wave + (l & 3) of K tile g1 (its second half), lane l & 7 >= 4 pixel 4 wave + (l & 3) of K tile g2 (its first half); out-of-range pixels,
+  // padding taps and K tiles beyond the item read the zero page.
+  struct Addr3 { unsigned long long a0, a1, ay; };
+  auto decode8 = [&](int g1, int g2) {
+    const int l = lane & 7;
+    const bool first_half = l >= 4;
+    const int g = first_half ? g2 : g1;
+    const int m = 64 * g + (first_half ? 0 : 32) + 4 * wave + (l & 3);
+    Addr3 r{zero_page, zero_page, zero_page};
+    const bool ok = g < kend && m < iM;
+    int n = (int)__umulhi((unsigned)m, imagic_pq);
+    int rem = m - n * ipq;
+    if (rem >= ipq) { ++n; rem -= ipq; }
+    int p = (int)__umulhi((unsigned)rem, imagic_q);
+    int q = rem - p * iQ;
+    if (q >= iQ) { ++p; q -= iQ; }
+    const int h0 = p * istride + dh0, w0 = q * istride + dw0;
+    if (ok && (unsigned)h0 < (unsigned)iH && (unsigned)w0 < (unsigned)iW) r.a0 = ixb + (unsigned long long)((unsigned)((n * iH + h0) * iW + w0)) * icrow + xo0;
+    const int h1 = p * istride + dh1, w1 = q * istride + dw1;
+    if (ok && seg1_ok && (unsigned)h1 < (unsigned)iH && (unsigned)w1 < (unsigned)iW) r.a1 = ixb + (unsigned long long)((unsigned)((n * iH + h1) * iW + w1)) * icrow + xo1;
+    if (ok) r.ay = iyb + (unsigned long long)(unsigned)m * ikrow + yo;
+    return r;
   };
-  // the wave's four pixel rows of half h (pixels 32 h + 4 wave + j) of K tile g
-  auto stage_half = [&](int g, int h, unsigned stage_lds) {
+  auto rl = [](unsigned v, int src) { return (unsigned)__builtin_amdgcn_readlane((int)v, src); };
+  // the wave's four pixel rows of half h of a stage: the addresses sit in lanes lb .. lb + 3 of `ad`
+  auto stage_half = [&](const Addr3& ad, int lb, int h, unsigned stage_lds) {
     const unsigned keep = m0_save();
 #pragma unroll
-    for (int j = 0; j < 4; ++j) stage_pixel(g, 32 * h + 4 * wave + j, j, stage_lds);
+    for (int j = 0; j < 4; ++j) {
+      // the pixel's three addresses minus the zero page's, broadcast from lane lb + j: (x - z) & mask summed over the three segments, + z = the lane's source
+      const unsigned d0l = rl((unsigned)(ad.a0 & 0xFFFFFFFFull), lb + j) ^ zlo, d0h = rl((unsigned)(ad.a0 >> 32), lb + j) ^ zhi;
+      const unsigned d1l = rl((unsigned)(ad.a1 & 0xFFFFFFFFull), lb + j) ^ zlo, d1h = rl((unsigned)(ad.a1 >> 32), lb + j) ^ zhi;
+      const unsigned dyl = rl((unsigned)(ad.ay & 0xFFFFFFFFull), lb + j) ^ zlo, dyh = rl((unsigned)(ad.ay >> 32), lb + j) ^ zhi;
+      unsigned lo = zlo ^ ((d0l & mk0[j]) | (d1l & mk1[j]) | (dyl & mk2[j])), hi = zhi ^ ((d0h & mk0[j]) | (d1h & mk1[j]) | (dyh & mk2[j]));
+      if constexpr (PROBE == 5) { lo = zlo; hi = zhi; asm volatile("" : "+v"(lo), "+v"(hi) : "v"(d0l), "v"(d1h), "v"(dyl)); }
+      gdma16((((unsigned long long)hi << 32) | lo) + loff[j], stage_lds + (unsigned)((32 * h + 4 * wave + j) * ROWB));      // (the zero page is 1 KiB: any chunk offset stays inside it)
+    }
     m0_restore(keep);
   };
 
   f32x4 acc[5][5];
   uint4 af[5], bfr[5];
+  if constexpr (PROBE == 3) {
+#pragma unroll
+    for (int i = 0; i < 5; ++i) { af[i] = make_uint4(lane, 1, 2, 3); bfr[i] = make_uint4(3, 2, 1, lane); }
+  }
   auto rd = [&](int off) {                                   // one MFMA operand: pixels 8 lq .. 8 lq + 7 of a 32-pixel k-step, two transposed reads
     const uint2 lo = Tr16r<T>::rd(lds + off), hi = Tr16r<T>::rd(lds + off + 4 * ROWB);
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
   };
   // one phase: k-step ks of the K tile in stage sx; meanwhile the 32 pixel rows the PREVIOUS phase read are re-staged with K tile gn, half hn
-  auto phase = [&](int sx, int ks, int gn, int hn, unsigned dst_lds) {
+  auto phase = [&](int sx, int ks, const Addr3& ad, int lb, int hn, unsigned dst_lds) {
+    if constexpr (PROBE != 3) {
 #pragma unroll
-    for (int j = 0; j < 5; ++j) bfr[j] = rd(sx + fb[j] + ks * 32 * ROWB);
+      for (int j = 0; j < 5; ++j) bfr[j] = rd(sx + fb[j] + ks * 32 * ROWB);
 #pragma unroll
-    for (int i = 0; i < 5; ++i) af[i] = rd(sx + fa[i] + ks * 32 * ROWB);
+      for (int i = 0; i < 5; ++i) af[i] = rd(sx + fa[i] + ks * 32 * ROWB);
+    }
     __builtin_amdgcn_sched_barrier(0);
-    stage_half(gn, hn, dst_lds);
+    if constexpr (PROBE != 1) stage_half(ad, lb, hn, dst_lds);
     wait_vmcnt<8>();                                         // all but this phase's and the previous phase's pieces: the half-tile the NEXT phase reads has landed
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this phase's reads are retired in front of the barrier: the next phase re-stages these rows
     rbar();
@@ -169,7 +192,10 @@ __global__ __launch_bounds__(512, 2) void wgrad8r_kernel(const W8rBatch b) {
 #pragma unroll
     for (int i = 0; i < 5; ++i)
 #pragma unroll
-      for (int j = 0; j < 5; ++j) Mfma16<T>::run(af[i], bfr[j], acc[i][j]);
+      for (int j = 0; j < 5; ++j) {
+        if constexpr (PROBE != 2) Mfma16<T>::run(af[i], bfr[j], acc[i][j]);
+        else asm volatile("" : "+v"(acc[i][j]) : "v"(af[i].x), "v"(af[i].w), "v"(bfr[j].x), "v"(bfr[j].w));
+      }
     __builtin_amdgcn_s_setprio(0);
     rbar();
   };
@@ -180,6 +206,7 @@ __global__ __launch_bounds__(512, 2) void wgrad8r_kernel(const W8rBatch b) {
     const int vb = it * G + (int)blockIdx.x;
     const bool more = vb < nitems;                           // wave-uniform
     int tile = 0, split = 0, kb = 0;
+    Addr3 pkeep{zero_page, zero_page, zero_page};
     if (more) {
       const int xcd = vb & 7, q = nitems >> 3, r = nitems & 7;
       const int item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
@@ -202,7 +229,9 @@ __global__ __launch_bounds__(512, 2) void wgrad8r_kernel(const W8rBatch b) {
       imagic_pq = R.magic_pq; imagic_q = R.magic_q; icrow = (unsigned)(R.C * ES); ikrow = (unsigned)(R.K * ES);
       ixb = (unsigned long long)(size_t)R.x; iyb = (unsigned long long)(size_t)R.dy;
       // prologue: K tile kb whole into stage 0, the first half of K tile kb + 1 into stage 1 (every wave has left the previous K loop)
-      stage_half(kb, 0, lds0); stage_half(kb, 1, lds0); stage_half(kb + 1, 0, lds0 + STGB);
+      const Addr3 p0 = decode8(kb, kb), p1 = decode8(kb, kb + 1);
+      pkeep = p1;
+      stage_half(p0, 4, 0, lds0); stage_half(p0, 0, 1, lds0); stage_half(p1, 4, 0, lds0 + STGB);
     }
     bool stores_behind = false;
     if (prec >= 0) {        // acc[i][j][r]: row 80 wm + 16 i + 4 lq + r of the 320, output channel 160 bt + 80 wn + 16 j + l16
@@ -241,8 +270,9 @@ __global__ __launch_bounds__(512, 2) void wgrad8r_kernel(const W8rBatch b) {
     const int nseg_k = kend - kb;
     for (int kt = 0; kt < nseg_k; ++kt) {
       const int g = kb + kt;
-      phase(sx, 0, g + 1, 1, lds0 + (unsigned)(sx ^ STGB));          // re-stage the other stage's pixels 32-63 (read by the previous phase) with K tile g + 1
-      phase(sx, 1, g + 2, 0, lds0 + (unsigned)sx);                   // re-stage this stage's pixels 0-31 with K tile g + 2
+      const Addr3 ad = PROBE == 4 ? pkeep : decode8(g + 1, g + 2);
+      phase(sx, 0, ad, 0, 1, lds0 + (unsigned)(sx ^ STGB));          // re-stage the other stage's pixels 32-63 (read by the previous phase) with K tile g + 1
+      phase(sx, 1, ad, 4, 0, lds0 + (unsigned)sx);                   // re-stage this stage's pixels 0-31 with K tile g + 2
       sx ^= STGB;
     }
     if (wave < 4) rbar();
@@ -254,10 +284,11 @@ __global__ __launch_bounds__(512, 2) void wgrad8r_kernel(const W8rBatch b) {
 
 // pixel splits of ONE layer's launch: one resident round of 256 persistent workgroups, or two when that balances better; cost = rounds x K tiles per
 // split (~1.3 us each) + slab traffic (written once, read once)
-static int w8r_pick_splits(long ntiles, long nk, double n_floats) {
+static int w8r_pick_splits(long ntiles, long nk, double n_floats, long cap = 128) {
   int best = 1;
   double best_cost = 1e30;
-  const long smax = nk / 4 < 128 ? (nk / 4 < 1 ? 1 : nk / 4) : 128;
+  long smax = nk / 4 < 128 ? (nk / 4 < 1 ? 1 : nk / 4) : 128;
+  if (smax > cap) smax = cap < 1 ? 1 : cap;
   for (long S = 1; S <= smax; ++S) {
     const long per = (nk + S - 1) / S;
     if (per * (S - 1) >= nk) continue;                                       // an empty last split
@@ -309,8 +340,70 @@ int rn_launch_wgrad8r(const void* x, const void* dy, float* out, int splits, int
   if (rn_dry_run()) return 0;
   const int cap = max_grid > 0 && max_grid < 256 ? max_grid : 256;
   const int grid = b.first[1] < cap ? b.first[1] : cap;
+  const int probe = (g_rn_variant2 >> 8) & 7;
   if (dtype == RN_BF16) hipLaunchKernelGGL((wgrad8r_kernel<bf16_t>), dim3(grid), dim3(512), 0, s, b);
+  else if (probe == 1) hipLaunchKernelGGL((wgrad8r_kernel<f16_t, 1>), dim3(grid), dim3(512), 0, s, b);
+  else if (probe == 2) hipLaunchKernelGGL((wgrad8r_kernel<f16_t, 2>), dim3(grid), dim3(512), 0, s, b);
+  else if (probe == 3) hipLaunchKernelGGL((wgrad8r_kernel<f16_t, 3>), dim3(grid), dim3(512), 0, s, b);
+  else if (probe == 4) hipLaunchKernelGGL((wgrad8r_kernel<f16_t, 4>), dim3(grid), dim3(512), 0, s, b);
+  else if (probe == 5) hipLaunchKernelGGL((wgrad8r_kernel<f16_t, 5>), dim3(grid), dim3(512), 0, s, b);
   else hipLaunchKernelGGL((wgrad8r_kernel<f16_t>), dim3(grid), dim3(512), 0, s, b);
   RN_CHECK_LAUNCH("wgrad8r");
+  return 0;
+}
+
+int rn_wgrad_reduce_slabs(const float* ws, float* dw_krsc, long n, int splits, int accum, int eight_phase, hipStream_t s);      // conv_wgrad.hip
+
+int rn_wgrad9_splits(const rn_conv_geom* g, int dtype);                                                                      // conv_wgrad9.hip
+int rn_wgrad9_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, hipStream_t s);
+
+extern "C" int rn_conv_wgrad8r_ok(const rn_conv_geom* g, int dtype) { return g && (rn_wgrad9_splits(g, dtype) > 0 || rn_wgrad8r_splits(g, dtype) > 0) ? 1 : 0; }
+
+// The weight gradients of n layers of ONE geometry as one launch (the plan executor queues the forked weight gradients of a residual stage: the tiles of
+// n layers share the chip, so a layer is cut into ~1/n of the pixel splits a launch of its own takes -- 1/n of the slab traffic -- and the launch's ramp,
+// tail and tile quantisation are paid once).  Every record's slabs go to its own workspace and are summed into its dw (+= with RN_F_ACCUM) right behind.
+extern "C" int rn_conv_wgrad8r_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, rn_stream s) {
+  static_assert(RN_WGRAD8R_BATCH_MAX == W8R_MAX, "header and kernel disagree");
+  RN_CHECK_ARG(descs && n > 0 && n <= RN_WGRAD8R_BATCH_MAX, "rn_conv_wgrad8r_batch: n=%d out of range (1..%d)", n, RN_WGRAD8R_BATCH_MAX);
+  const rn_conv_geom& g0 = descs[0].g;
+  RN_CHECK_ARG(rn_conv_wgrad8r_ok(&g0, dtype), "rn_conv_wgrad8r_batch: the geometry is not one the 320 x 160 / 288 x 160 kernels take");
+  if (rn_wgrad9_splits(&g0, dtype) > 0) return rn_wgrad9_batch(descs, n, dtype, max_grid, as_stream(s));      // 3x3 stride 1: the nine-tap kernel
+  const long M = (long)g0.N * g0.P * g0.Q, nk = (M + 63) / 64;
+  const long nseg = (long)g0.R * g0.S * (g0.C / 160), ntiles = ((nseg + 1) / 2) * (g0.K / 160);
+  const size_t nel = (size_t)g0.K * g0.R * g0.S * g0.C;
+  long ws_cap = 128;                                     // slabs every record's workspace holds
+  for (int i = 0; i < n; ++i) {
+    const long c = descs[i].ws ? (long)(descs[i].ws_bytes / (nel * sizeof(float))) : 0;
+    if (c < ws_cap) ws_cap = c;
+  }
+  const int splits = w8r_pick_splits(ntiles * n, nk, (double)nel * n, ws_cap);
+  W8rBatch b{};
+  b.n = n;
+  int items = 0;
+  for (int i = 0; i < n; ++i) {
+    const rn_wgrad8r_desc& d = descs[i];
+    RN_CHECK_ARG(d.x && d.dy && d.dw, "rn_conv_wgrad8r_batch: record %d: null pointer", i);
+    RN_CHECK_ARG(memcmp(&d.g, &g0, sizeof(g0)) == 0, "rn_conv_wgrad8r_batch: record %d has another geometry", i);
+    const bool direct = splits == 1 && !(d.flags & RN_F_ACCUM);
+    RN_CHECK_ARG(direct || (d.ws && d.ws_bytes >= (size_t)splits * nel * sizeof(float)), "rn_conv_wgrad8r_batch: record %d: workspace too small (%zu < %zu)", i, d.ws_bytes,
+                 (size_t)splits * nel * sizeof(float));
+    w8r_fill(b.r[i], d.x, d.dy, direct ? d.dw : reinterpret_cast<float*>(d.ws), splits, &g0, 0);
+    b.first[i] = items;
+    items += b.r[i].nau * b.r[i].nbt * splits;
+    rn_note_kernel("wgrad8r<320x160>");
+    if (!direct) rn_note_kernel("wgrad_reduce");
+  }
+  b.first[n] = items;
+  if (rn_dry_run()) return 0;
+  const int cap = max_grid > 0 && max_grid < 256 ? max_grid : 256;
+  const int grid = items < cap ? items : cap;
+  if (dtype == RN_BF16) hipLaunchKernelGGL((wgrad8r_kernel<bf16_t>), dim3(grid), dim3(512), 0, as_stream(s), b);
+  else hipLaunchKernelGGL((wgrad8r_kernel<f16_t>), dim3(grid), dim3(512), 0, as_stream(s), b);
+  RN_CHECK_LAUNCH("wgrad8r batch");
+  for (int i = 0; i < n; ++i) {
+    const rn_wgrad8r_desc& d = descs[i];
+    if (splits == 1 && !(d.flags & RN_F_ACCUM)) continue;             // written in place
+    if (int e = rn_wgrad_reduce_slabs(reinterpret_cast<const float*>(d.ws), d.dw, (long)nel, splits, (d.flags & RN_F_ACCUM) ? 1 : 0, 1, as_stream(s))) return e;
+  }
   return 0;
 }

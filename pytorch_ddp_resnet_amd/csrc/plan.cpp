@@ -7,6 +7,8 @@
 #include <string.h>
 
 #include <string>
+#include <algorithm>
+#include <string.h>
 #include <cstdlib>
 #include <vector>
 
@@ -412,7 +414,25 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
     q.n = 0; q.key = 0;
     return e;
   };
+  // Wide layers of the 160-channel family (WRN-28-10): the FORKED weight gradients the 320 x 160 kernel takes wait as well, per geometry, and go to the
+  // side stream as ONE launch of up to w8r_batch layers (rn_conv_wgrad8r_batch: 1 / n of the pixel splits and slab traffic per layer, one ramp and tail).
+  // RN_W8R_BATCH=<n> (1: every layer on its own, as before round 4).
+  static const int w8r_batch = getenv("RN_W8R_BATCH") ? std::max(1, std::min(RN_WGRAD8R_BATCH_MAX, atoi(getenv("RN_W8R_BATCH")))) : 4;
+  static const int w8r_fork_grid = getenv("RN_W8_FORK_GRID") ? atoi(getenv("RN_W8_FORK_GRID")) : 256;
+  struct W8Queue { int n = 0; rn_wgrad8r_desc d[RN_WGRAD8R_BATCH_MAX]; int xs[RN_WGRAD8R_BATCH_MAX], dys[RN_WGRAD8R_BATCH_MAX], dws[RN_WGRAD8R_BATCH_MAX]; } w8q;
+  auto launch_w8q = [&]() -> int {
+    if (!w8q.n) return 0;
+    if (hipEventRecord(plan->ev_fork, as_stream(stream)) != hipSuccess || hipStreamWaitEvent(plan->side, plan->ev_fork, 0) != hipSuccess) {
+      rn_set_error("rn_plan_run: fork onto the side stream failed (batched weight gradients)");
+      return 2;
+    }
+    plan->side_pending = true;
+    const int e = rn_conv_wgrad8r_batch(w8q.d, w8q.n, plan->dtype, w8r_fork_grid, reinterpret_cast<rn_stream>(plan->side));
+    w8q.n = 0;
+    return e;
+  };
   auto flush = [&]() -> int {
+    if (int e = launch_w8q()) return e;
     for (auto& q : wq)
       if (int e = launch_queue(q)) return e;
     if (!n_pending) return 0;
@@ -457,6 +477,18 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
         if (int e2 = flush()) return e2;
       continue;
     }
+    if (w8q.n) {                                           // an op that writes an operand of a queued wide weight gradient, or touches its dw, sends the queue out first
+      const unsigned outs = rn_op_output_mask(plan->ops[i].kind);
+      bool hit = false;
+      for (int b = 0; b < RN_OP_NBUF && !hit; ++b) {
+        const int sl = plan->ops[i].buf[b];
+        if (sl < 0) continue;
+        for (int j = 0; j < w8q.n && !hit; ++j)
+          hit = sl == w8q.dws[j] || (((outs >> b) & 1) && (sl == w8q.xs[j] || sl == w8q.dys[j]));
+      }
+      if (hit)
+        if (int e2 = launch_w8q()) return e2;
+    }
     {                                                      // an op that WRITES a slot a queued weight gradient still has to read sends that queue out first
       const unsigned outs = rn_op_output_mask(plan->ops[i].kind);
       for (auto& q : wq) {
@@ -499,6 +531,20 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
       }
     }
     const bool forked = plan->overlap && !plan->profile && (plan->ops[i].flags & RN_F_FORK);   // flagged ops own a workspace of their own
+    if (forked && w8r_batch > 1 && plan->ops[i].kind == RN_OP_CONV_WGRAD) {
+      const rn_op& o = plan->ops[i];
+      rn_conv_geom g = geom_of(o);
+      auto P = [&](int b) -> void* { return o.buf[b] >= 0 ? plan->bufs[o.buf[b]] : nullptr; };
+      if (P(0) && P(1) && P(2) && P(3) && rn_conv_wgrad8r_ok(&g, plan->dtype)) {
+        if (w8q.n && memcmp(&w8q.d[0].g, &g, sizeof(g)) != 0)
+          if (int e2 = launch_w8q()) return e2;
+        w8q.xs[w8q.n] = o.buf[0]; w8q.dys[w8q.n] = o.buf[1]; w8q.dws[w8q.n] = o.buf[2];
+        w8q.d[w8q.n++] = rn_wgrad8r_desc{P(0), P(1), (float*)P(2), P(3), plan->ws_bytes[o.buf[3]], g, o.flags};
+        if (w8q.n == w8r_batch)
+          if (int e2 = launch_w8q()) return e2;
+        continue;
+      }
+    }
     rn_stream s = stream;
     if (forked) {
       if (hipEventRecord(plan->ev_fork, as_stream(stream)) != hipSuccess || hipStreamWaitEvent(plan->side, plan->ev_fork, 0) != hipSuccess) {

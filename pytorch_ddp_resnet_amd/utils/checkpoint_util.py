@@ -126,6 +126,12 @@ class CheckpointStrategy(torch.nn.Module):
     def observe(self, **kwargs) -> bool:
         raise NotImplementedError
 
+    def may_save(self, unit: str) -> bool:
+        """can the NEXT observation of `unit` ask for a checkpoint?  (Not in the reference: its loop observes synchronously.  The training loop here reads
+        its logging values one microbatch late, so it asks first and closes the step on the host -- before the next optimizer step is enqueued -- whenever
+        the answer is yes: the file written for step k then holds the state after exactly k steps, training.py:129-139.)"""
+        return self.unit == unit
+
 
 class FrequencyCheckpointStrategy(CheckpointStrategy):
     """eligible every `frequency`-th observation of its own unit (counted from 0, so the first one is)."""
@@ -138,6 +144,9 @@ class FrequencyCheckpointStrategy(CheckpointStrategy):
         cond = getattr(self, f"{unit}_step") % self._frequency == 0
         self.step(unit)
         return bool(cond) if self.unit == unit else False
+
+    def may_save(self, unit: str) -> bool:
+        return self.unit == unit and getattr(self, f"{unit}_step") % self._frequency == 0
 
 
 class PerformanceCheckpointStrategy(CheckpointStrategy):

@@ -693,6 +693,7 @@ def test_igemm8r_production_operand_sets(g, ops, dtype):
 
 # ---- the 320 x 160 weight-gradient kernel of the 160-channel family (conv_wgrad8r.hip) ----
 W8R_ANY = 8                          # rn_set_variant2: at any size (its rule wants >= 2,048 tile x K-tile units)
+NO_W9 = 16384                        # rn_set_variant2: never the nine-tap kernel (which otherwise takes the 3x3 stride-1 geometries first)
 W8R_SMALL = [
     (2, 16, 16, 160, 160, 3, 1, 1),      # five units (four tap pairs + a single tap: half of the last tile's rows empty), 8 K tiles, padding taps
     (3, 8, 8, 320, 160, 3, 1, 1),        # 320 input channels: a unit = the two 160-channel slices of one tap; 3 K tiles
@@ -709,7 +710,7 @@ W8R_SMALL = [
 def test_wgrad8r_on_small_geometries(g, dtype):
     """the 320 x 160 weight-gradient kernel forced onto small shapes: per-pixel LDS rows filled by global_load_lds (zero page for padding taps, pixel tails
     and the pad chunks), whole-row XOR swizzle under the transposed reads, segment pairs across taps / across channel slices, strides, slabs."""
-    ran = run_conv_case(g, dtype, variant2=W8R_ANY | R8_ANY)
+    ran = run_conv_case(g, dtype, variant2=W8R_ANY | R8_ANY | NO_W9)
     assert 'wgrad8r<320x160>' in ran, ran
 
 
@@ -724,12 +725,112 @@ def test_wgrad8r_exact_integers():
         eng.tensors[sl['x']].copy_(torch.from_numpy(xv).to(torch.float16)); eng.tensors[sl['dy']].copy_(torch.from_numpy(dv).to(torch.float16))
         eng.bind({})
         L = _lib.lib()
-        L.rn_set_variant2(W8R_ANY)
+        L.rn_set_variant2(W8R_ANY | NO_W9)
         try:
             L.rn_kernel_log(1)
             eng.run(0, 1, 0)
             torch.cuda.synchronize()
             assert 'wgrad8r<320x160>' in L.rn_kernel_log_read().decode()
+        finally:
+            L.rn_kernel_log(0)
+            L.rn_set_variant2(0)
+        ref = torch.nn.grad.conv2d_weight(_nchw(torch.from_numpy(xv)), (K, C, 3, 3), _nchw(torch.from_numpy(dv)), 1, 1).permute(0, 2, 3, 1)
+        assert torch.equal(eng.tensors[sl['dw']].cpu(), ref.contiguous()), g
+
+
+@pytest.mark.parametrize('g,n', [((2, 16, 16, 160, 160, 3, 1, 1), 3), ((3, 8, 8, 320, 320, 3, 1, 1), 2), ((6, 16, 16, 160, 320, 3, 2, 1), 4)])
+def test_wgrad8r_batch_of_layers(g, n):
+    """rn_conv_wgrad8r_batch: the weight gradients of n layers of one geometry as ONE launch (a table of layer records, items = (split, tile) per record, slabs
+    in every record's own workspace, summed right behind): every layer against torch-CPU, one of them accumulating into an existing gradient; the launch is
+    bitwise reproducible."""
+    import ctypes as C
+    import gpu_harness as h                               # noqa: F401
+    L = _lib.lib()
+    vp = C.c_void_p
+
+    class Desc(C.Structure):
+        _fields_ = [('x', vp), ('dy', vp), ('dw', vp), ('ws', vp), ('ws_bytes', C.c_size_t), ('g', _lib.RnConvGeom), ('flags', C.c_int32)]
+    L.rn_conv_wgrad8r_batch.argtypes = [C.POINTER(Desc), C.c_int, C.c_int, C.c_int, vp]
+    N, Hh, W, Cc, K, k, st, p = g
+    gm = geom(*g)
+    gs = _lib.geom_struct(gm)
+    P, Q = gm['P'], gm['Q']
+    dev = torch.device('cuda', 0)
+    rng = np.random.RandomState(5)
+    L.rn_set_variant2(W8R_ANY)
+    try:
+        wsb = int(L.rn_conv_wgrad_ws_bytes(C.byref(gs)))
+        xs = [torch.from_numpy(rng.randn(N, Hh, W, Cc).astype(np.float32)).to(torch.float16) for _ in range(n)]
+        dys = [torch.from_numpy(rng.randn(N, P, Q, K).astype(np.float32)).to(torch.float16) for _ in range(n)]
+        old = torch.from_numpy(rng.randn(K, k, k, Cc).astype(np.float32))
+        outs = []
+        for rep in range(2):
+            keep = []
+            descs = (Desc * n)()
+            dws = []
+            for i in range(n):
+                xd, dyd = xs[i].to(dev), dys[i].to(dev)
+                dw = old.to(dev).clone() if i == 1 else torch.full((K, k, k, Cc), float('nan'), device=dev)
+                ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+                keep += [xd, dyd, ws]
+                dws.append(dw)
+                descs[i] = Desc(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsb, gs, ir.F_ACCUM if i == 1 else 0)
+            L.rn_kernel_log(1)
+            _lib.check(L.rn_conv_wgrad8r_batch(descs, n, ir.RN_F16, 256, vp(torch.cuda.current_stream().cuda_stream)))
+            torch.cuda.synchronize()
+            names = L.rn_kernel_log_read().decode()
+            assert names.count('wgrad8r<320x160>') + names.count('wgrad9<288x160>') == n, names
+            L.rn_kernel_log(0)
+            outs.append([d.cpu() for d in dws])
+    finally:
+        L.rn_kernel_log(0)
+        L.rn_set_variant2(0)
+    for i in range(n):
+        ref = torch.nn.grad.conv2d_weight(_nchw(xs[i].float()), (K, Cc, k, k), _nchw(dys[i].float()), st, p).permute(0, 2, 3, 1)
+        if i == 1:
+            ref = ref + old
+        err = float((outs[0][i] - ref).abs().max() / ref.abs().max())
+        assert err < 2e-4, (i, err)
+        assert torch.equal(outs[0][i], outs[1][i])
+
+
+# ---- the nine-tap 288 x 160 weight-gradient kernel (conv_wgrad9.hip): 3x3 stride-1 layers with 160 n output channels ----
+W9_SMALL = [
+    (2, 16, 16, 160, 160, 3, 1, 1),      # W = 16: four image rows per K tile, five channel slices, 8 K tiles
+    (3, 8, 8, 320, 160, 3, 1, 1),        # W = 8: a K tile = one image (every vertical tap leaves it)
+    (2, 32, 32, 160, 320, 3, 1, 1),      # W = 32: two image rows per K tile; two output-channel tiles
+    (1, 64, 64, 32, 160, 3, 1, 1),       # W = 64: one image row per K tile; a single 32-channel slice
+    (5, 16, 16, 96, 160, 3, 1, 1),       # 96 input channels: three slices
+    (37, 16, 16, 160, 160, 3, 1, 1),     # 148 K tiles x 5 tiles: pixel splits, more than one item per workgroup
+]
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('g', W9_SMALL)
+def test_wgrad9_on_small_geometries(g, dtype):
+    """the nine-tap weight-gradient kernel forced onto small shapes: the staged input patch (pad columns, rows above / below the K tile's image rows, image
+    borders as out-of-range DMA offsets), the nine shifted transposed reads of it, the row-bit swizzles of both LDS images, every map width it takes."""
+    ran = run_conv_case(g, dtype, variant2=W8R_ANY | R8_ANY)
+    assert 'wgrad9<288x160>' in ran, ran
+
+
+def test_wgrad9_exact_integers():
+    """integer operands: bit for bit against the reference (tap <-> wave row tile map, channel halves, shifted patch rows, slab sums in fixed order)."""
+    for g in [(2, 16, 16, 160, 160, 3, 1, 1), (3, 8, 8, 320, 320, 3, 1, 1), (2, 32, 32, 64, 160, 3, 1, 1)]:
+        N, Hh, W, C, K, k, s_, p = g
+        eng, sl = _one_op_engine(ir.OP_CONV_WGRAD, g, dict(x=((N, Hh, W, C), 'T'), dy=((N, Hh, W, K), 'T'), dw=((K, 3, 3, C), 'f32'), ws=((0,), 'u8')))
+        rng = np.random.RandomState(0)
+        xv = rng.randint(-3, 4, size=(N, Hh, W, C)).astype(np.float32)
+        dv = rng.randint(-2, 3, size=(N, Hh, W, K)).astype(np.float32)
+        eng.tensors[sl['x']].copy_(torch.from_numpy(xv).to(torch.float16)); eng.tensors[sl['dy']].copy_(torch.from_numpy(dv).to(torch.float16))
+        eng.bind({})
+        L = _lib.lib()
+        L.rn_set_variant2(W8R_ANY)
+        try:
+            L.rn_kernel_log(1)
+            eng.run(0, 1, 0)
+            torch.cuda.synchronize()
+            assert 'wgrad9<288x160>' in L.rn_kernel_log_read().decode()
         finally:
             L.rn_kernel_log(0)
             L.rn_set_variant2(0)

@@ -248,6 +248,73 @@ def test_training_loop_lagged_logging_is_complete_and_ordered():
     assert global_means_async(met, 1).result() == global_means(met, 1)
 
 
+@pytest.mark.parametrize('strategy', ['frequency', 'performance'])
+def test_batch_checkpoints_hold_the_state_after_exactly_k_steps(tmp_path, strategy):
+    """training.py:129-139: the files written for step k hold the weights and the optimizer state after exactly k steps -- although the loop reads its logging
+    values one microbatch late -- and saving at k, then resuming, continues the uninterrupted run bit for bit (any module works on CPU: host logic)."""
+    from pytorch_ddp_resnet_amd.algos.training import training_loop, train_step
+    from pytorch_ddp_resnet_amd.utils.checkpoint_util import FrequencyCheckpointStrategy, PerformanceCheckpointStrategy, maybe_load_checkpoints, ddp_keys
+    torch.manual_seed(0)
+    xs = [(torch.randn(6, 12), torch.randint(0, 10, (6,))) for _ in range(4)]
+
+    def make():
+        torch.manual_seed(1)
+        m = torch.nn.Linear(12, 10)
+        return m, torch.optim.SGD(m.parameters(), lr=0.1, momentum=0.9)
+
+    def strat():
+        return FrequencyCheckpointStrategy('batch', 2) if strategy == 'frequency' else PerformanceCheckpointStrategy('batch')
+    m, opt = make()
+    d = str(tmp_path / 'ck')
+    import os
+    os.makedirs(d)
+    training_loop(0, 1, torch.device('cpu'), xs, None, m, opt, num_microbatches=1, max_steps=7, log=lambda s: None, checkpoint_strategy=strat(), checkpoint_dir=d)
+    # the reference states: after k steps, for every k
+    m2, opt2 = make()
+    states, k = {0: None}, 0
+    while k < 7:
+        for x, y in xs:
+            train_step(m2, x, y, opt2)
+            k += 1
+            states[k] = ({n: v.clone() for n, v in m2.state_dict().items()}, {i: s['momentum_buffer'].clone() for i, s in opt2.state_dict()['state'].items()})
+            if k == 7:
+                break
+    saved = sorted(int(f.split('_')[1].split('.')[0]) for f in os.listdir(d) if f.startswith('classifier_'))
+    assert saved and (strategy != 'frequency' or saved == [1, 3, 5, 7]), saved          # observations 0, 2, 4, 6 -> files of steps 1, 3, 5, 7
+    for ksaved in saved:
+        m3, opt3 = make()
+        x0, y0 = xs[0]
+        train_step(m3, x0, y0, opt3)                       # (a momentum buffer to load into)
+        assert maybe_load_checkpoints(d, {'classifier': ddp_keys(m3), 'optimizer': opt3}, 'cpu', steps=ksaved) == ksaved
+        want_w, want_mom = states[ksaved]
+        for n, v in m3.state_dict().items():
+            assert torch.equal(v, want_w[n]), (ksaved, n)
+        for i, st in opt3.state_dict()['state'].items():
+            assert torch.equal(st['momentum_buffer'], want_mom[i]), (ksaved, i)
+
+
+def test_resumed_run_continues_the_epoch_count(tmp_path):
+    """training.py:87-88: the epoch handed to the sampler continues from the checkpoint strategy's epoch counter after a resume."""
+    from pytorch_ddp_resnet_amd.algos.training import training_loop
+    from pytorch_ddp_resnet_amd.utils.checkpoint_util import FrequencyCheckpointStrategy
+
+    class Sampler:
+        def __init__(self):
+            self.epochs = []
+
+        def set_epoch(self, e):
+            self.epochs.append(e)
+    torch.manual_seed(0)
+    xs = [(torch.randn(6, 12), torch.randint(0, 10, (6,))) for _ in range(2)]
+    m = torch.nn.Linear(12, 10)
+    opt = torch.optim.SGD(m.parameters(), lr=0.1)
+    cs = FrequencyCheckpointStrategy('epoch', 1)
+    cs.step('epoch'); cs.step('epoch'); cs.step('epoch')            # as loaded from a checkpoint written after three epochs
+    sm = Sampler()
+    training_loop(0, 1, torch.device('cpu'), xs, None, m, opt, max_steps=4, log=lambda s: None, sampler_train=sm, checkpoint_strategy=cs, checkpoint_dir=None)
+    assert sm.epochs == [3, 4], sm.epochs
+
+
 @pytest.mark.parametrize('name,preact,proj', [('rn20', False, False), ('wrn2810', True, True), ('v2_164', True, True), ('wrn50a', False, True), ('wrn50b', False, True)])
 def test_state_dict_keys_and_shapes_match_the_reference(golden, name, preact, proj):
     """G5: ordered state_dict keys, shapes, parameter order and parameter count of the reference module for the five BASELINE specs."""
