@@ -722,7 +722,8 @@ template <typename T> int launch_igemm(const IgemmArgs& a, hipStream_t s) {
   // row-patch kernel (conv_igemm8r.hip): 3x3 stride 1 with 160 n output channels -- the WRN-28-10 family, which the tiles above do not divide.
   // rn_set_variant2: 1 = never, 2 = on any grid size.
   if constexpr (sizeof(T) == 2) {
-    if (!(g_rn_variant2 & 1) && rn_igemm8r_ok(a) && ((g_rn_variant2 & 2) || (long)cdiv(a.M, 256) * (K / 160) >= 192)) {
+    if (!(g_rn_variant2 & 1) && rn_igemm8r_ok(a) &&
+        ((g_rn_variant2 & 2) || (long)cdiv(a.M, 256) * (K / 160) >= 192 || rn_igemm8r_split_ok(a)))  {
       const int e = rn_launch_igemm8r(a, std::is_same<T, bf16_t>::value ? RN_BF16 : RN_F16, s);
       if (e >= 0) return e;
     }

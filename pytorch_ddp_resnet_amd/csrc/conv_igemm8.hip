@@ -817,6 +817,12 @@ extern "C" int rn_set_conv_workspace(void* p, size_t bytes) {
   g_sk_ws = p; g_sk_ws_bytes = p ? bytes : 0;
   return 0;
 }
+// the same workspace for the split reductions of conv_igemm8r.hip (tickets in the first 4 KiB, one slot of SK_SLOT_BYTES per work item): NULL when it is
+// not set or smaller than rn_conv_workspace_bytes()
+void* rn_sk_workspace(size_t* slot_bytes) {
+  if (slot_bytes) *slot_bytes = SK_SLOT_BYTES;
+  return (g_sk_ws && g_sk_ws_bytes >= SK_CNT_BYTES + 2 * SK_GRID * SK_SLOT_BYTES) ? g_sk_ws : nullptr;
+}
 
 // geometry the eight-phase kernel covers: 16-bit elements, channel count a multiple of 64 (a K tile never straddles a tap), output channels a
 // multiple of the column tile, 1..16 taps in a separable progression, 32-bit tile offsets; the grid rule (enough tiles for the chip) is the caller's

@@ -27,6 +27,10 @@
 //   WAR  the weight stage of tile kt-1 is re-staged in phase 1 of tile kt: two phases after its reads (retired by the lgkmcnt(0) that opens the
 //        reading phase's C segment).  The A buffer of group g-1 is re-staged in phase 1 of group g, ONE phase after its last reads (second phase of
 //        the group's last K tile), which is why every second phase retires its reads (lgkmcnt(0)) in FRONT of its M segment's closing barrier.
+// Split reduction (grids of <= 128 tiles: WRN-28-10's 640-channel stage at batch 128): every tile is TWO work items, the halves of its group range, on two
+// CUs; each half writes its fp32 accumulators write-through into its slot of the stream-K workspace (rn_set_conv_workspace) and draws a ticket; the half
+// that draws the second ticket adds the partner's part to its registers (two parts: the sum does not depend on who arrived last) and runs the epilogue.
+// Nobody waits for anybody (conv_igemm8.hip's stream-K hand-off).
 // Epilogue: the register epilogue of conv_igemm8.hip (transposed products; a 4 x 4 transpose over the wave's lane rows gives a lane 16 consecutive
 // channels of one pixel) for 64 of a wave's 80 columns; the fifth column tile is transposed over the wave's four PIXEL tiles instead, which gives a
 // lane 16 consecutive channels (columns 64..79) of pixel 16 * (lane row) + lane column.  Same fused operand sets, per template parameter.
@@ -251,7 +255,8 @@ __host__ __device__ inline int r8_mode(const IgemmArgs& a) {     // -1: an opera
 struct Items { int i0, h0, i1, h1; };          // the two (kernel row, half chunk) items of a group; i >= 3: past the end
 
 // PROBE (diagnostic instantiations, rn_set_variant2 bits 4-6; wrong results, timing only): 1 = no LDS-DMA in the K loop, 2 = no MFMA, 3 = no fragment reads
-template <typename T, int EPM, int PROBE = 0>
+// SPLIT: the two-halves form (a template parameter: its bookkeeping beside the widest operand sets tipped them into scratch)
+template <typename T, int EPM, int PROBE = 0, int SPLIT = 0>
 __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
   constexpr int BM = 256, BN = 160, ES = 2;
   constexpr int WN = 2;                                     // 4 x 2 waves of 64 x 80
@@ -273,6 +278,8 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
   const int nhc = a.w8_cpc;                                 // half chunks per pixel: C / 32
   const int G = a.nk / 3;                                   // groups
   const int nnt = a.Kd / BN, nmt = (a.M + BM - 1) / BM, ntiles = nmt * nnt;
+  constexpr int S = SPLIT ? 2 : 1;                          // 2: every tile is two work items (the halves of its group range)
+  const int nitems = ntiles * S, gcut = (G + 1) >> 1;
   const int pq = H * W;
   const unsigned pixb = (unsigned)(a.Cs * ES);
   const size_t img_bytes = (size_t)pq * pixb;
@@ -462,20 +469,27 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
 
   // ---- persistent walk over whole tiles: column tiles fastest, an XCD's workgroups (b, b + 8, ...) on a contiguous range of the order ----
   const int Gw = gridDim.x;
-  int pm0 = -1, pn0 = 0;
+  int pm0 = -1, pn0 = 0, pitem = 0;
   for (int itn = 0;; ++itn) {
     const int vb = itn * Gw + blockIdx.x;
-    const bool more = vb < ntiles;                          // wave-uniform
+    const bool more = SPLIT ? itn == 0 : vb < nitems;       // wave-uniform; the split form's grid holds one work item per workgroup (launcher)
     const unsigned long long* stp = itn < 2 ? a.stamps : nullptr;      // diagnostic (rn_set_stamp_buffer): the workgroup's first two tiles, slots 6 itn + 0..5
     const int sb = 6 * itn;
     stamp(stp, sb);
-    int m0 = 0, n0 = 0;
+    int m0 = 0, n0 = 0, item = 0, g_lo = 0, g_hi = G;
     Items cur{0, 0, 0, 1}, nxt{0, 0, 0, 0};
     if (more) {
-      int tile = vb;
+      item = vb;
       if (a.xcd_remap) {
-        const int xcd = vb & 7, q = ntiles >> 3, r = ntiles & 7;
-        tile = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+        const int xcd = vb & 7, q = nitems >> 3, r = nitems & 7;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (vb >> 3);
+      }
+      int tile = item;
+      if constexpr (S == 2) {
+        tile = item >> 1;
+        if (item & 1) g_lo = gcut; else g_hi = gcut;
+        const int i0 = (2 * g_lo) / nhc, i1 = (2 * g_lo + 1) / nhc;
+        cur = Items{i0, 2 * g_lo - i0 * nhc, i1, 2 * g_lo + 1 - i1 * nhc};
       }
       int mt = (int)__umulhi((unsigned)tile, (unsigned)a.w8_magic_nnt);
       if (tile - mt * nnt >= nnt) ++mt;
@@ -503,8 +517,49 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
     // the previous tile leaves the registers while this one's first pieces are in flight
     bool stores_behind = false;
     if (pm0 >= 0) {
-      stores_behind = pm0 + BM <= a.M;
-      epilogue8r<T, EPM>(a, acc, pm0 + wm * WTM, pn0 + wn * WTN, lane, corner, (wm & 1) != 0, WN * CORNER);
+      bool finish = true;
+      if constexpr (S == 2) {
+        // ---- one half of a tile's reduction: publish it, draw a ticket; the second arriver adds the halves ----
+        const int ptile = pitem >> 1;
+        f32x4* slots = reinterpret_cast<f32x4*>(reinterpret_cast<char*>(a.w8_ws) + 4096);
+        constexpr size_t SLOT = (size_t)512 * 128 / 4;       // f32x4 per slot (conv_igemm8.hip's SK_SLOT_BYTES); register-major, thread-minor: coalesced 16-byte accesses
+        {
+          const __amdgpu_buffer_rsrc_t wsr = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(slots), 0, 0x7FFFFFF0, 0x00020000);
+          const unsigned mine_off = (unsigned)(((size_t)pitem * SLOT + tid) * 16);
+#pragma unroll
+          for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j)           // write-through (sc1): the bytes leave this XCD's L2 at once, publishing needs no release fence
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u32, acc[i][j]), wsr, (int)(mine_off + (unsigned)((i * CT + j) * 512 * 16)), 0, 16);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every storing wave drains, then the workgroup meets, then ONE lane signals
+        __syncthreads();
+        int* cnt = reinterpret_cast<int*>(a.w8_ws) + ptile;
+        volatile int* flagw = reinterpret_cast<volatile int*>(reinterpret_cast<float*>(&smem[C_0]) + 500);      // a word of wave 0's corner that no epilogue uses
+        if (tid == 0) *flagw = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        finish = *flagw == 1;                                // wave-uniform
+        if (finish) {
+          if (tid == 0) {
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // both halves have arrived: the counter is clean for the next launch
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __syncthreads();
+          // the partner's part is added to the registers: fp32 addition commutes, so the sum of TWO parts does not depend on who arrived last
+          const f32x4* so = slots + (size_t)(pitem ^ 1) * SLOT + tid;
+#pragma unroll
+          for (int i = 0; i < RT; ++i)
+#pragma unroll
+            for (int j = 0; j < CT; ++j) acc[i][j] += so[(size_t)(i * CT + j) * 512];
+        } else {
+          __syncthreads();                                   // same barrier count on both paths
+        }
+      }
+      if (finish) {
+        stores_behind = pm0 + BM <= a.M;
+        epilogue8r<T, EPM>(a, acc, pm0 + wm * WTM, pn0 + wn * WTN, lane, corner, (wm & 1) != 0, WN * CORNER);
+      }
     }
     stamp(stp, sb + 3);
     if (!more) break;
@@ -522,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
     stamp(stp, sb + 4);
 
     int a_cur = 0;
-    for (int g = 0; g + 1 < G; ++g) {
+    for (int g = g_lo; g + 1 < g_hi; ++g) {
       const unsigned a_nxt = lds0 + (unsigned)((a_cur ^ A_SZ) * 16);
       const int mi = lane_i(nxt);
       const unsigned sa = lane_src(nxt);
@@ -537,7 +592,7 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
     ktile(I2{}, std::integral_constant<int, 0>{}, a_cur, 0u, 0, 0u, 0u, false);
     if (wave < 4) raw_barrier();                            // the first group waits for the second: every wave has executed the same barriers
     stamp(stp, sb + 5);
-    pm0 = m0; pn0 = n0;
+    pm0 = m0; pn0 = n0; pitem = item;
   }
 }
 
@@ -559,7 +614,7 @@ bool r8_geom_ok(const IgemmArgs& a) {
 template <typename T> int launch8r(IgemmArgs& a, hipStream_t s) {
   const int epm = r8_mode(a);
   static const char* const EPN[] = {"plain", "res", "?", "?", "bnb", "bnb+res", "bnb+acc"};
-  rn_note_kernel("igemm8r<256x160:%s>", EPN[epm]);
+  rn_note_kernel(rn_igemm8r_split_ok(a) ? "igemm8r<256x160/2:%s>" : "igemm8r<256x160:%s>", EPN[epm]);
   if (rn_dry_run()) return 0;
   const int W = a.Ws;
   int lw = 0;
@@ -570,7 +625,11 @@ template <typename T> int launch8r(IgemmArgs& a, hipStream_t s) {
   a.w8_magic_ntw = (unsigned)((65536 + W + 1) / (W + 2));
   { const unsigned nnt = (unsigned)(a.Kd / 160); a.w8_magic_nnt = nnt <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / nnt); }
   const int ntiles = cdiv(a.M, 256) * (a.Kd / 160);
-  const int grid = ntiles < 256 ? ntiles : 256;
+  a.w8_dp_tiles = 1;
+  a.w8_ws = nullptr;
+  if (rn_igemm8r_split_ok(a)) { a.w8_dp_tiles = 2; a.w8_ws = rn_sk_workspace(nullptr); }
+  const int nitems = ntiles * a.w8_dp_tiles;
+  const int grid = nitems < 256 ? nitems : 256;
   if constexpr (std::is_same<T, f16_t>::value) {
     const int probe = (g_rn_variant2 >> 4) & 7;
     if (probe && epm == R8_PLAIN) {
@@ -580,6 +639,17 @@ template <typename T> int launch8r(IgemmArgs& a, hipStream_t s) {
       RN_CHECK_LAUNCH("igemm8r probe");
       return 0;
     }
+  }
+  if (a.w8_dp_tiles == 2) {
+    switch (epm) {
+      case R8_PLAIN: hipLaunchKernelGGL((igemm8r_kernel<T, R8_PLAIN, 0, 1>), dim3(grid), dim3(512), 0, s, a); break;
+      case R8_RES: hipLaunchKernelGGL((igemm8r_kernel<T, R8_RES, 0, 1>), dim3(grid), dim3(512), 0, s, a); break;
+      case R8_BNB: hipLaunchKernelGGL((igemm8r_kernel<T, R8_BNB, 0, 1>), dim3(grid), dim3(512), 0, s, a); break;
+      case R8_BNB | R8_RES: hipLaunchKernelGGL((igemm8r_kernel<T, R8_BNB | R8_RES, 0, 1>), dim3(grid), dim3(512), 0, s, a); break;
+      default: hipLaunchKernelGGL((igemm8r_kernel<T, R8_BNB | R8_ACC, 0, 1>), dim3(grid), dim3(512), 0, s, a); break;
+    }
+    RN_CHECK_LAUNCH("igemm8r split");
+    return 0;
   }
   switch (epm) {
     case R8_PLAIN: hipLaunchKernelGGL((igemm8r_kernel<T, R8_PLAIN>), dim3(grid), dim3(512), 0, s, a); break;
@@ -602,6 +672,17 @@ int rn_igemm8r_ok(const IgemmArgs& a) {
   if ((256 / pq + 3) * (double)img_bytes >= 4.0e9) return 0;         // per-tile source offsets are 32-bit
   if (((double)a.Kd + 256.0) * a.wrs * a.Cs * 2 >= 4.0e9) return 0;
   return 1;
+}
+
+// the split form: 2 x tiles work items fit one round of the chip, the reduction is long enough to cut, the workspace is there (rn_set_variant2 131072: never; 262144: on grids of < 96 tiles too)
+int rn_igemm8r_split_ok(const IgemmArgs& a) {
+  if (g_rn_variant2 & 131072) return 0;
+  const long ntiles = (long)cdiv(a.M, 256) * (a.Kd / 160);
+  const int groups = (3 * (a.Cs / 32) + 1) / 2;
+  size_t slot = 0;
+  if (2 * ntiles > 256 || groups < 8 || !rn_sk_workspace(&slot)) return 0;
+  if (ntiles < 96 && !(g_rn_variant2 & 262144)) return 0;                      // (262144: at any size, tests)
+  return slot >= (size_t)512 * 80 * 4 ? 1 : 0;
 }
 
 int rn_launch_igemm8r(const IgemmArgs& a_in, int dtype, hipStream_t s) {

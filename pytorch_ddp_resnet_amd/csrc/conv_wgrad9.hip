@@ -21,6 +21,8 @@
 #include "igemm_shared.h"
 #include <string.h>
 
+extern int g_rn_variant2;
+
 namespace {
 
 constexpr int W9_MAX = 12;
@@ -77,7 +79,13 @@ __device__ inline void wait_vm9(int n) {                     // wave-uniform cou
 constexpr int XB = 9216, YB = 20480, STG = XB + YB;          // bytes of a stage: patch (up to 136 pixel rows of 64 B, padded to 9 DMA pieces) | dy
 
 // PROBE (diagnostic instantiations, rn_set_variant2 bits 8-10; wrong results, timing only): 1 = no LDS-DMA in the K loop, 2 = no MFMA, 3 = no fragment reads
-template <typename T, int PROBE = 0>
+// SCHED 1 (default; rn_set_variant2 8192 selects 0 for A/B): the LDS-DMA pieces of K tile kt + 2 are issued INSIDE the MFMA segment of the second phase (behind its
+// first five MFMAs) instead of in that phase's read segment, and the wait in front of them is a plain vmcnt(0): what is in flight there is K tile kt + 1 alone
+// SCHED 2 (rn_set_variant2 32768 selects 1): ONE barrier per K tile.  No wave groups and no per-phase barriers: a wave reads a k-step's fragments, waits for them
+// and multiplies; the SIMD's other two waves fill its read latency (three waves per SIMD drift apart by themselves).  The barrier at the end of a K tile orders
+// both hazards: every wave has waited for its own pieces of K tile kt + 1 in front of it (RAW), and every wave's reads of K tile kt are retired in front of it,
+// so the stage may be re-staged -- as K tile kt + 3 -- from the next K tile on (WAR).
+template <typename T, int PROBE = 0, int SCHED = 2>
 __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
   constexpr int ES = 2;
   __shared__ uint4 smem[3 * STG / 16];
@@ -203,22 +211,40 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
     }
     __builtin_amdgcn_sched_barrier(0);
     if constexpr (ks == 1) {
-      if constexpr (PROBE != 1) issue_tile(gn, dst_lds);
-      wait_vm9(PROBE == 1 ? 0 : nw);                         // everything older than this K tile's own pieces: K tile kt + 1 has landed
+      if constexpr (SCHED == 0) {
+        if constexpr (PROBE != 1) issue_tile(gn, dst_lds);
+        wait_vm9(PROBE == 1 ? 0 : nw);                       // everything older than this K tile's own pieces: K tile kt + 1 has landed
+      } else if constexpr (SCHED == 1) {
+        wait_vm9(0);                                         // K tile kt + 1 (issued one K tile ago) has landed
+      }
     }
-    bar9();
+    if constexpr (SCHED != 2) bar9();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
+#define W9_MF(i, j)                                                                                                   \
+  do {                                                                                                                \
+    if constexpr (PROBE != 2) Mfma16<T>::run(af[i], bfr[j], acc[i][j]);                                               \
+    else asm volatile("" : "+v"(acc[i][j]) : "v"(af[i].x), "v"(af[i].w), "v"(bfr[j].x), "v"(bfr[j].w));               \
+  } while (0)
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 5; ++j) W9_MF(0, j);
+    if constexpr (ks == 1 && SCHED != 0 && PROBE != 1) {
+      __builtin_amdgcn_sched_barrier(0);
+      issue_tile(gn, dst_lds);
+      __builtin_amdgcn_sched_barrier(0);
+    }
 #pragma unroll
-      for (int j = 0; j < 5; ++j) {
-        if constexpr (PROBE != 2) Mfma16<T>::run(af[i], bfr[j], acc[i][j]);
-        else asm volatile("" : "+v"(acc[i][j]) : "v"(af[i].x), "v"(af[i].w), "v"(bfr[j].x), "v"(bfr[j].w));
-      }
+    for (int i = 1; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) W9_MF(i, j);
+#undef W9_MF
     __builtin_amdgcn_s_setprio(0);
-    bar9();
+    if constexpr (SCHED != 2) bar9();
+    else if constexpr (ks == 1) {
+      wait_vm9(nw);                                          // K tile kt + 1 has landed; this K tile's own pieces (K tile kt + 2) stay in flight
+      bar9();
+    }
   };
   using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
 
@@ -276,7 +302,7 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
     // K tile kb has landed; kb + 1's pieces (and the previous item's 15 stores, which are younger) may fly
     wait_vm9(stores_behind ? nw + 15 : nw);
     bar9();
-    if (wave >= 4) bar9();                                   // waves 4-11 run one barrier behind waves 0-3
+    if (SCHED != 2 && wave >= 4) bar9();                     // waves 4-11 run one barrier behind waves 0-3
 
     int s_cur = 0, s_nxt = STG, s_free = 2 * STG;            // stage of K tile kt, of kt + 1, and the one kt + 2 goes into (kt - 1's)
     const int nseg_k = kend - kb;
@@ -285,14 +311,12 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
       phase(K1{}, s_cur, kb + kt + 2, lds0 + (unsigned)s_free);
       const int t = s_cur; s_cur = s_nxt; s_nxt = s_free; s_free = t;
     }
-    if (wave < 4) bar9();
+    if (SCHED != 2 && wave < 4) bar9();
     prec = rec; ptile = tile; psplit = split;
   }
 }
 
 }  // namespace
-
-extern int g_rn_variant2;
 
 static int w9_pick_splits(long ntiles, long nk, double n_floats, long cap = 128) {
   int best = 1;
@@ -315,7 +339,7 @@ static bool w9_geom_ok(const rn_conv_geom* g, int dtype) {
   if (g->R != 3 || g->S != 3 || g->stride != 1 || g->pad != 1 || g->P != g->H || g->Q != g->W) return false;
   if (g->C % 32 || g->C < 32 || g->K % 160) return false;
   const int W = g->W;
-  if (W < 8 || W > 64 || (W & (W - 1))) return false;                          // a K tile = 64 / W whole image rows
+  if (W < 8 || W > 32 || (W & (W - 1))) return false;                          // a K tile = 64 / W whole image rows; the patch of W = 64 (3 x 66 pixel rows) would not fit XB
   if (g->H % (64 / W)) return false;
   if ((double)g->N * g->H * g->W * g->C * 2 >= 4.0e9 || (double)g->N * g->H * g->W * g->K * 2 >= 4.0e9) return false;      // 32-bit DMA offsets
   return true;
@@ -348,10 +372,12 @@ static void w9_fill(W9Rec& r, const void* x, const void* dy, float* out, int spl
 template <typename T> static void w9_launch(const W9Batch& b, int grid, hipStream_t s) {
   if constexpr (std::is_same<T, f16_t>::value) {
     const int probe = (g_rn_variant2 >> 8) & 7;
-    if (probe == 1) { hipLaunchKernelGGL((wgrad9_kernel<T, 1>), dim3(grid), dim3(768), 0, s, b); return; }
-    if (probe == 2) { hipLaunchKernelGGL((wgrad9_kernel<T, 2>), dim3(grid), dim3(768), 0, s, b); return; }
-    if (probe == 3) { hipLaunchKernelGGL((wgrad9_kernel<T, 3>), dim3(grid), dim3(768), 0, s, b); return; }
+    if (probe == 1) { hipLaunchKernelGGL((wgrad9_kernel<T, 1, 0>), dim3(grid), dim3(768), 0, s, b); return; }
+    if (probe == 2) { hipLaunchKernelGGL((wgrad9_kernel<T, 2, 0>), dim3(grid), dim3(768), 0, s, b); return; }
+    if (probe == 3) { hipLaunchKernelGGL((wgrad9_kernel<T, 3, 0>), dim3(grid), dim3(768), 0, s, b); return; }
   }
+  if (g_rn_variant2 & 8192) { hipLaunchKernelGGL((wgrad9_kernel<T, 0, 0>), dim3(grid), dim3(768), 0, s, b); return; }
+  if (g_rn_variant2 & 32768) { hipLaunchKernelGGL((wgrad9_kernel<T, 0, 1>), dim3(grid), dim3(768), 0, s, b); return; }
   hipLaunchKernelGGL((wgrad9_kernel<T>), dim3(grid), dim3(768), 0, s, b);
 }
 

@@ -536,3 +536,5 @@ int rn_igemm8_fast(const IgemmArgs& a);
 int rn_launch_igemm8r(const IgemmArgs& a, int dtype, hipStream_t s);
 int rn_igemm8r_ok(const IgemmArgs& a);
 extern int g_rn_variant2;         // round-4 switches (rn_set_variant2), defined in conv_igemm8r.hip
+void* rn_sk_workspace(size_t* slot_bytes);      // conv_igemm8.hip: the stream-K workspace (rn_set_conv_workspace) or NULL
+int rn_igemm8r_split_ok(const IgemmArgs& a);    // 1: a grid of <= 128 tiles that the row-patch kernel runs as two reduction halves per tile

@@ -559,7 +559,6 @@ def test_s2d_stem(shape, variant, fwd_name, dtype):
     eng.bind({})
     L = _lib.lib()
     L.rn_set_variant(variant)
-    L.rn_set_variant2(variant2)
     try:
         L.rn_kernel_log(1)
         eng.run(0, len(plan.ops), 0)
@@ -691,6 +690,56 @@ def test_igemm8r_production_operand_sets(g, ops, dtype):
     assert ran[1] == 'igemm8r<256x160:' + {'none': 'bnb>', 'res': 'bnb+res>', 'acc': 'bnb+acc>'}[ops[1]], ran
 
 
+R8_SPLIT_ANY = 262144                # rn_set_variant2: the two-halves form on grids of < 96 tiles too
+R8_SPLIT_SMALL = [
+    (2, 32, 32, 160, 160, 3, 1, 1),      # 8 groups: 4 + 4
+    (1, 16, 16, 320, 320, 3, 1, 1),      # 15 groups: 8 + 7, the second half starts inside a kernel row
+    (3, 8, 8, 640, 640, 3, 1, 1),        # the stage it ships on: 30 groups, a partly empty tile, four column tiles
+    (2, 16, 16, 480, 160, 3, 1, 1),      # 45 items: 23 groups (12 + 11), the last group half empty
+]
+
+
+@pytest.mark.parametrize('dtype', ['bf16', 'fp16'])
+@pytest.mark.parametrize('merge', ['none', 'res', 'acc'])
+@pytest.mark.parametrize('g', R8_SPLIT_SMALL)
+def test_igemm8r_split_reduction(g, merge, dtype):
+    """the row-patch kernel with every tile's reduction cut into two work items (conv_igemm8r.hip, split form): group ranges that start inside a kernel row,
+    the hand-off through the stream-K workspace (write-through parts, ticket, the second arriver adds both parts in slice order), every operand set."""
+    ran = run_conv_case(g, dtype, variant2=R8_ANY | R8_SPLIT_ANY, fwd_res=(merge == 'none'), dgrad_merge=merge)
+    assert ran[0] == 'igemm8r<256x160/2:' + ('res>' if merge == 'none' else 'plain>'), ran
+    if g[3] % 160 == 0:
+        assert ran[1] == 'igemm8r<256x160/2:' + {'none': 'bnb>', 'res': 'bnb+res>', 'acc': 'bnb+acc>'}[merge], ran
+
+
+def test_igemm8r_split_is_reproducible_and_ships_on_the_640_stage():
+    """WRN-28-10's 640-channel layers at batch 128 (128 tiles) take the split form by the shipped rule; two runs give the same bits (the parts are added in
+    slice order, whoever arrives last), and the tickets are left at zero."""
+    g = (128, 8, 8, 640, 640, 3, 1, 1)
+    N, Hh, W, C, K, k, s_, p = g
+    eng, sl = _one_op_engine(ir.OP_CONV_FWD, g, dict(x=((N, Hh, W, C), 'T'), w_fwd=((K, 9, C), 'T'), y=((N, Hh, W, K), 'T')))
+    gen = torch.Generator().manual_seed(5)
+    eng.tensors[sl['x']].copy_(torch.randn(N, Hh, W, C, generator=gen).to(torch.float16))
+    eng.tensors[sl['w_fwd']].copy_((torch.randn(K, 9, C, generator=gen) * 0.02).to(torch.float16))
+    eng.bind({})
+    L = _lib.lib()
+    outs = []
+    try:
+        L.rn_kernel_log(1)
+        for _ in range(3):
+            eng.tensors[sl['y']].zero_()
+            eng.run(0, 1, 0)
+            torch.cuda.synchronize()
+            outs.append(eng.tensors[sl['y']].clone())
+        assert 'igemm8r<256x160/2:plain>' in L.rn_kernel_log_read().decode()
+    finally:
+        L.rn_kernel_log(0)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    x = eng.tensors[sl['x']].float().cpu(); w = eng.tensors[sl['w_fwd']].float().cpu().reshape(K, 3, 3, C)
+    ref = torch.nn.functional.conv2d(_nchw(x[:8]), w.permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+    err = float((outs[0][:8].float().cpu() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-3, err
+
+
 # ---- the 320 x 160 weight-gradient kernel of the 160-channel family (conv_wgrad8r.hip) ----
 W8R_ANY = 8                          # rn_set_variant2: at any size (its rule wants >= 2,048 tile x K-tile units)
 NO_W9 = 16384                        # rn_set_variant2: never the nine-tap kernel (which otherwise takes the 3x3 stride-1 geometries first)
@@ -799,7 +848,7 @@ W9_SMALL = [
     (2, 16, 16, 160, 160, 3, 1, 1),      # W = 16: four image rows per K tile, five channel slices, 8 K tiles
     (3, 8, 8, 320, 160, 3, 1, 1),        # W = 8: a K tile = one image (every vertical tap leaves it)
     (2, 32, 32, 160, 320, 3, 1, 1),      # W = 32: two image rows per K tile; two output-channel tiles
-    (1, 64, 64, 32, 160, 3, 1, 1),       # W = 64: one image row per K tile; a single 32-channel slice
+    (1, 32, 32, 32, 160, 3, 1, 1),       # a single 32-channel slice, one image
     (5, 16, 16, 96, 160, 3, 1, 1),       # 96 input channels: three slices
     (37, 16, 16, 160, 160, 3, 1, 1),     # 148 K tiles x 5 tiles: pixel splits, more than one item per workgroup
 ]
