@@ -14,9 +14,9 @@
 // <= 168 registers) as 6 x 2, a wave = 3 x 5 tiles = 60 accumulator registers; a wave's three row tiles are fixed (tap, 16-channel half) pairs.
 // LDS: three stages of [patch 9 KiB | dy 20 KiB]; rows are XOR-swizzled by bit 3 of the row index (the two 16-lane groups of a half-wave's transposed read
 // are 8 rows apart: the swap of the 32-byte halves / pairs puts them on different bank groups), on the DMA source side.
-// Schedule: a K tile = two phases (32-pixel k-steps: 16 transposed reads, 15 MFMAs per wave); waves 0-3 (one per SIMD) run one barrier ahead of waves
-// 4-11, so a SIMD alternates between one and two waves in their MFMA segment while the others read; K tile kt+2 is issued in the second phase of K tile kt
-// (its stage was last read one K tile earlier) and waited for one K tile later: one counted vmcnt per K tile, raw s_barrier.
+// Schedule: a K tile = two k-steps of 32 pixels (16 transposed reads, 15 MFMAs per wave each), ONE barrier per K tile (SCHED 2 below; the first form of
+// this round ran waves 0-3 one barrier ahead of waves 4-11 with two barriers per k-step); K tile kt+2 is issued during K tile kt (its stage was last read one
+// K tile earlier) and waited for one K tile later: one counted vmcnt per K tile, raw s_barrier.
 // Work: item = (pixel split, tile) over a table of layers, as conv_wgrad8r.hip; slabs summed by the fixed-order kernels of conv_wgrad.hip.
 #include "igemm_shared.h"
 #include <string.h>
@@ -79,12 +79,14 @@ __device__ inline void wait_vm9(int n) {                     // wave-uniform cou
 constexpr int XB = 9216, YB = 20480, STG = XB + YB;          // bytes of a stage: patch (up to 136 pixel rows of 64 B, padded to 9 DMA pieces) | dy
 
 // PROBE (diagnostic instantiations, rn_set_variant2 bits 8-10; wrong results, timing only): 1 = no LDS-DMA in the K loop, 2 = no MFMA, 3 = no fragment reads
-// SCHED 1 (default; rn_set_variant2 8192 selects 0 for A/B): the LDS-DMA pieces of K tile kt + 2 are issued INSIDE the MFMA segment of the second phase (behind its
-// first five MFMAs) instead of in that phase's read segment, and the wait in front of them is a plain vmcnt(0): what is in flight there is K tile kt + 1 alone
-// SCHED 2 (rn_set_variant2 32768 selects 1): ONE barrier per K tile.  No wave groups and no per-phase barriers: a wave reads a k-step's fragments, waits for them
-// and multiplies; the SIMD's other two waves fill its read latency (three waves per SIMD drift apart by themselves).  The barrier at the end of a K tile orders
-// both hazards: every wave has waited for its own pieces of K tile kt + 1 in front of it (RAW), and every wave's reads of K tile kt are retired in front of it,
-// so the stage may be re-staged -- as K tile kt + 3 -- from the next K tile on (WAR).
+// SCHED 2 (shipped; rn_set_variant2 8192 selects 0, the first form, for A/B): ONE barrier per K tile and no wave groups.  A wave reads a k-step's fragments,
+// waits for them and multiplies; the SIMD's other two waves fill its read latency (three waves per SIMD drift apart by themselves); the LDS-DMA pieces of
+// K tile kt + 2 go out behind the first five MFMAs of the second k-step (an LDS-DMA piece costs ~60 cycles of issue among MFMAs, 100-185 in a read
+// segment).  The barrier at the end of a K tile orders both hazards: every wave has waited for its own pieces of K tile kt + 1 in front of it (RAW), and
+// every wave's reads of K tile kt are retired in front of it, so its stage may be re-staged -- as K tile kt + 3 -- from the next K tile on (WAR).
+// Measured in one process (tools/conv_bench.py wgrad, batch 128): first form 88.1 / 80.6 / 80.2 us on the 160 / 320 / 640-channel layers; pieces moved into
+// the MFMA segment, barriers kept 81.0 / 74.6 / 73.8; this form 75.0 / 70.5 / 72.5 (round-3 kernel: 88.3 / 79.4 / 84.5).  A second register set that holds
+// both k-steps' fragments from the head of the K tile (162 registers) lost 3-5 % against it; removed.
 template <typename T, int PROBE = 0, int SCHED = 2>
 __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
   constexpr int ES = 2;
@@ -214,8 +216,6 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
       if constexpr (SCHED == 0) {
         if constexpr (PROBE != 1) issue_tile(gn, dst_lds);
         wait_vm9(PROBE == 1 ? 0 : nw);                       // everything older than this K tile's own pieces: K tile kt + 1 has landed
-      } else if constexpr (SCHED == 1) {
-        wait_vm9(0);                                         // K tile kt + 1 (issued one K tile ago) has landed
       }
     }
     if constexpr (SCHED != 2) bar9();
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
     // K tile kb has landed; kb + 1's pieces (and the previous item's 15 stores, which are younger) may fly
     wait_vm9(stores_behind ? nw + 15 : nw);
     bar9();
-    if (SCHED != 2 && wave >= 4) bar9();                     // waves 4-11 run one barrier behind waves 0-3
+    if (SCHED == 0 && wave >= 4) bar9();                     // waves 4-11 run one barrier behind waves 0-3
 
     int s_cur = 0, s_nxt = STG, s_free = 2 * STG;            // stage of K tile kt, of kt + 1, and the one kt + 2 goes into (kt - 1's)
     const int nseg_k = kend - kb;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
       phase(K1{}, s_cur, kb + kt + 2, lds0 + (unsigned)s_free);
       const int t = s_cur; s_cur = s_nxt; s_nxt = s_free; s_free = t;
     }
-    if (SCHED != 2 && wave < 4) bar9();
+    if (SCHED == 0 && wave < 4) bar9();
     prec = rec; ptile = tile; psplit = split;
   }
 }
@@ -377,7 +377,6 @@ template <typename T> static void w9_launch(const W9Batch& b, int grid, hipStrea
     if (probe == 3) { hipLaunchKernelGGL((wgrad9_kernel<T, 3, 0>), dim3(grid), dim3(768), 0, s, b); return; }
   }
   if (g_rn_variant2 & 8192) { hipLaunchKernelGGL((wgrad9_kernel<T, 0, 0>), dim3(grid), dim3(768), 0, s, b); return; }
-  if (g_rn_variant2 & 32768) { hipLaunchKernelGGL((wgrad9_kernel<T, 0, 1>), dim3(grid), dim3(768), 0, s, b); return; }
   hipLaunchKernelGGL((wgrad9_kernel<T>), dim3(grid), dim3(768), 0, s, b);
 }
 

@@ -417,7 +417,7 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
   // Wide layers of the 160-channel family (WRN-28-10): the FORKED weight gradients the 320 x 160 kernel takes wait as well, per geometry, and go to the
   // side stream as ONE launch of up to w8r_batch layers (rn_conv_wgrad8r_batch: 1 / n of the pixel splits and slab traffic per layer, one ramp and tail).
   // RN_W8R_BATCH=<n> (1: every layer on its own, as before round 4).
-  static const int w8r_batch = getenv("RN_W8R_BATCH") ? std::max(1, std::min(RN_WGRAD8R_BATCH_MAX, atoi(getenv("RN_W8R_BATCH")))) : 4;
+  static const int w8r_batch = getenv("RN_W8R_BATCH") ? std::max(1, std::min(RN_WGRAD8R_BATCH_MAX, atoi(getenv("RN_W8R_BATCH")))) : 8;
   static const int w8r_fork_grid = getenv("RN_W8_FORK_GRID") ? atoi(getenv("RN_W8_FORK_GRID")) : 256;
   struct W8Queue { int n = 0; rn_wgrad8r_desc d[RN_WGRAD8R_BATCH_MAX]; int xs[RN_WGRAD8R_BATCH_MAX], dys[RN_WGRAD8R_BATCH_MAX], dws[RN_WGRAD8R_BATCH_MAX]; } w8q;
   auto launch_w8q = [&]() -> int {
