@@ -110,8 +110,8 @@ typedef struct rn_plan rn_plan;
 const char* rn_last_error(void);
 /* ABI version: bumped with EVERY change of an entry point's signature or meaning; a binding refuses a library of another version (a stale
  * librn_hip.so would otherwise take shifted pointer / integer arguments).  3: round 3 (operand-set flags of rn_conv_kernel_names, workspaces).
- * 9: round 4 (rn_set_variant2). */
-#define RN_ABI_VERSION 9
+ * 9: round 4 (rn_set_variant2).  10: rn_conv_wgrad8r_best_batch. */
+#define RN_ABI_VERSION 10
 int rn_version(void);
 /* kernel-variant switch for A/B measurements (tools/conv_bench.py; bits documented in csrc/conv_igemm.hip); 0 = shipped */
 void rn_set_variant(int v);
@@ -282,6 +282,9 @@ typedef struct rn_wgrad8r_desc {
 } rn_wgrad8r_desc;
 int rn_conv_wgrad8r_ok(const rn_conv_geom* g, int dtype);
 int rn_conv_wgrad8r_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, rn_stream s);
+/* how many layers of geometry g are worth collecting for one rn_conv_wgrad8r_batch launch (1..max_n): the count whose tiles fill whole rounds of the chip best
+ * (modelled time per layer; csrc/conv_wgrad9.hip) */
+int rn_conv_wgrad8r_best_batch(const rn_conv_geom* g, int dtype, int max_n);
 unsigned rn_op_output_mask(int kind);    /* bit b set: an op of this kind WRITES buf[b] (rn_plan_run sends a queued weight gradient out before an op that
                                           * would rewrite one of its operands); mirrored by engine/ir.py OP_OUTPUTS, checked by tests/test_abi.py */
 long rn_wgrad_batch_launches(void);      /* diagnostic: batched launches this process has issued (the kernel log keeps the per-record tile names) */

@@ -94,7 +94,17 @@ enum { R8_PLAIN = 0, R8_RES = 1, R8_ACC = 2, R8_BNB = 4 };
 // wave of the upper 64 rows of a 128-row statistics group hands to its partner
 constexpr int CORNER = 512, CX = 320;
 
-template <typename T, int MODE>
+// The 16 pixels of an MFMA tile are INTERLEAVED over the lanes -- lanes l16 in {0-3, 12-15} hold the even pixels, {4-11} the odd ones -- so that the two
+// 8-lane halves of a ds_read_b128 lane group ({0-3, 12-15 | 20-27}: logical chunks lq and lq + 1) read patch rows of DIFFERENT parity = different halves
+// of the 256-byte bank window, whatever the alignment of the 16-row run (a kernel column shifts it by one row).  With pixel = l16 the two halves collide
+// whenever the run does not start on a multiple of 4 rows (2 of 3 kernel columns): 21-30 % of the kernel's LDS cycles were conflicts
+// (profiles/r04b_conv_bench_model_operands_pmc.txt).  PERM 0 (rn_set_variant2 4096, plain operand set only): pixel = l16, for A/B.
+__device__ inline int pix16(int l16, bool perm) {
+  if (!perm) return l16;
+  return (l16 >= 4 && l16 < 12) ? 2 * (l16 - 4) + 1 : (l16 < 4 ? 2 * l16 : 2 * (l16 - 8));
+}
+
+template <typename T, int MODE, int PERM>
 __device__ inline void epilogue8r(const IgemmArgs& a, f32x4 (&acc)[4][5], int mw, int kw, int lane, float* corner, bool upper, int partner_floats) {
   constexpr int CE = 8;
   constexpr bool C_RES = (MODE & R8_RES) != 0, C_ACC = (MODE & R8_ACC) != 0, C_BNB = (MODE & R8_BNB) != 0;
@@ -112,7 +122,7 @@ __device__ inline void epilogue8r(const IgemmArgs& a, f32x4 (&acc)[4][5], int mw
   // unit u < 4: pixel tile u, channels kw + 16 lq .. + 15; unit 4: pixel 16 lq + l16, channels kw + 64 .. + 15
   struct Ops { bool ok; size_t off; Chunk<T> cr[2], co[2], cx[2], cm[2]; };
   auto fetch = [&](int u, Ops& o) {
-    const int m = mw + (u < 4 ? 16 * u : 16 * lq) + l16;
+    const int m = mw + (u < 4 ? 16 * u : 16 * lq) + pix16(l16, PERM != 0);
     const int kc = kw + (u < 4 ? 16 * lq : 64);
     o.ok = m < a.M;
     o.off = (size_t)m * a.Kd + kc;
@@ -256,7 +266,7 @@ struct Items { int i0, h0, i1, h1; };          // the two (kernel row, half chun
 
 // PROBE (diagnostic instantiations, rn_set_variant2 bits 4-6; wrong results, timing only): 1 = no LDS-DMA in the K loop, 2 = no MFMA, 3 = no fragment reads
 // SPLIT: the two-halves form (a template parameter: its bookkeeping beside the widest operand sets tipped them into scratch)
-template <typename T, int EPM, int PROBE = 0, int SPLIT = 0>
+template <typename T, int EPM, int PROBE = 0, int SPLIT = 0, int PERM = 1>
 __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
   constexpr int BM = 256, BN = 160, ES = 2;
   constexpr int WN = 2;                                     // 4 x 2 waves of 64 x 80
@@ -315,7 +325,7 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
   int fa[3][RT];
 #pragma unroll
   for (int i = 0; i < RT; ++i) {
-    const int ml = wm * WTM + 16 * i + l16;
+    const int ml = wm * WTM + 16 * i + pix16(l16, PERM != 0);
     const int pr0 = (ml >> lw) * W2 + (ml & (W - 1)) + 1;
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -558,7 +568,7 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
       }
       if (finish) {
         stores_behind = pm0 + BM <= a.M;
-        epilogue8r<T, EPM>(a, acc, pm0 + wm * WTM, pn0 + wn * WTN, lane, corner, (wm & 1) != 0, WN * CORNER);
+        epilogue8r<T, EPM, PERM>(a, acc, pm0 + wm * WTM, pn0 + wn * WTN, lane, corner, (wm & 1) != 0, WN * CORNER);
       }
     }
     stamp(stp, sb + 3);
@@ -639,6 +649,11 @@ template <typename T> int launch8r(IgemmArgs& a, hipStream_t s) {
       RN_CHECK_LAUNCH("igemm8r probe");
       return 0;
     }
+  }
+  if ((g_rn_variant2 & 4096) && epm == R8_PLAIN && a.w8_dp_tiles == 1) {
+    hipLaunchKernelGGL((igemm8r_kernel<T, R8_PLAIN, 0, 0, 0>), dim3(grid), dim3(512), 0, s, a);
+    RN_CHECK_LAUNCH("igemm8r");
+    return 0;
   }
   if (a.w8_dp_tiles == 2) {
     switch (epm) {

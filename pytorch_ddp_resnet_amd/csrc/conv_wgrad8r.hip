@@ -362,6 +362,15 @@ extern "C" int rn_conv_wgrad8r_ok(const rn_conv_geom* g, int dtype) { return g &
 // The weight gradients of n layers of ONE geometry as one launch (the plan executor queues the forked weight gradients of a residual stage: the tiles of
 // n layers share the chip, so a layer is cut into ~1/n of the pixel splits a launch of its own takes -- 1/n of the slab traffic -- and the launch's ramp,
 // tail and tile quantisation are paid once).  Every record's slabs go to its own workspace and are summed into its dw (+= with RN_F_ACCUM) right behind.
+int rn_wgrad9_best_batch(const rn_conv_geom* g, int dtype, int max_n);      // conv_wgrad9.hip
+// the number of layers of geometry g worth collecting for one launch (<= max_n)
+extern "C" int rn_conv_wgrad8r_best_batch(const rn_conv_geom* g, int dtype, int max_n) {
+  if (!g || max_n < 1 || !rn_conv_wgrad8r_ok(g, dtype)) return 1;
+  if (max_n > RN_WGRAD8R_BATCH_MAX) max_n = RN_WGRAD8R_BATCH_MAX;
+  if (rn_wgrad9_splits(g, dtype) > 0) return rn_wgrad9_best_batch(g, dtype, max_n);
+  return max_n < 4 ? max_n : 4;
+}
+
 extern "C" int rn_conv_wgrad8r_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, rn_stream s) {
   static_assert(RN_WGRAD8R_BATCH_MAX == W8R_MAX, "header and kernel disagree");
   RN_CHECK_ARG(descs && n > 0 && n <= RN_WGRAD8R_BATCH_MAX, "rn_conv_wgrad8r_batch: n=%d out of range (1..%d)", n, RN_WGRAD8R_BATCH_MAX);

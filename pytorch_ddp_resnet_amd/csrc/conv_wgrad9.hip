@@ -318,7 +318,9 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
 
 }  // namespace
 
-static int w9_pick_splits(long ntiles, long nk, double n_floats, long cap = 128) {
+// pixel splits of a launch of ntiles tiles (all layers of the launch together) over nk K tiles, and its modelled time in microseconds (calibrated on the
+// one-barrier schedule, batch 128: ~1.6 us per K tile of a full chip, ~6 us of ramp per round; slabs written and re-read at ~4 TB/s)
+static int w9_pick_splits(long ntiles, long nk, double n_floats, long cap = 128, double* cost_us = nullptr) {
   int best = 1;
   double best_cost = 1e30;
   long smax = nk / 4 < 128 ? (nk / 4 < 1 ? 1 : nk / 4) : 128;
@@ -327,9 +329,10 @@ static int w9_pick_splits(long ntiles, long nk, double n_floats, long cap = 128)
     const long per = (nk + S - 1) / S;
     if (per * (S - 1) >= nk) continue;                                       // an empty last split
     const long rounds = (ntiles * S + 255) / 256;
-    const double cost = rounds * (per * 0.9 + 8.0) + (S > 1 ? S * n_floats * 8.0 / 4.0e6 : 0.0) + (S > 1 ? 6.0 : 0.0);
+    const double cost = rounds * (per * 1.6 + 6.0) + (S > 1 ? S * n_floats * 8.0 / 4.0e6 : 0.0) + (S > 1 ? 6.0 : 0.0);
     if (cost < best_cost - 1e-9) { best_cost = cost; best = (int)S; }
   }
+  if (cost_us) *cost_us = best_cost;
   return best;
 }
 
@@ -343,6 +346,24 @@ static bool w9_geom_ok(const rn_conv_geom* g, int dtype) {
   if (g->H % (64 / W)) return false;
   if ((double)g->N * g->H * g->W * g->C * 2 >= 4.0e9 || (double)g->N * g->H * g->W * g->K * 2 >= 4.0e9) return false;      // 32-bit DMA offsets
   return true;
+}
+
+// how many layers of this geometry the plan executor should collect for ONE launch (rn_conv_wgrad8r_batch): the count in 1..max_n with the lowest modelled
+// time per layer.  The tiles of n layers share one grid of 256 persistent workgroups, so the count decides how well the items fill whole rounds: WRN-28-10's
+// 640-channel layers (80 tiles each) fill 0.94 of one round in threes (no slabs at all), 0.62 of two rounds in fours, 0.73 of three rounds in sevens.
+int rn_wgrad9_best_batch(const rn_conv_geom* g, int dtype, int max_n) {
+  if (!w9_geom_ok(g, dtype) || max_n < 1) return 1;
+  const long M = (long)g->N * g->H * g->W, nk = M / 64;
+  const long ntiles = (long)(g->C / 32) * (g->K / 160);
+  const double nel = (double)g->K * 9 * g->C;
+  int best = 1;
+  double best_per_layer = 1e30;
+  for (int n = 1; n <= max_n && n <= W9_MAX; ++n) {
+    double c = 0;
+    w9_pick_splits(ntiles * n, nk, nel * n, 128, &c);
+    if (c / n < best_per_layer * 0.98) { best_per_layer = c / n; best = n; }      // a larger batch has to be worth 2 %: it delays the gradients
+  }
+  return best;
 }
 
 // 0: rn_conv_wgrad does not take this kernel for the geometry; S >= 1: it does, with S pixel splits

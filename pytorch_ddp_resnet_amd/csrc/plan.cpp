@@ -416,10 +416,10 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
   };
   // Wide layers of the 160-channel family (WRN-28-10): the FORKED weight gradients the 320 x 160 kernel takes wait as well, per geometry, and go to the
   // side stream as ONE launch of up to w8r_batch layers (rn_conv_wgrad8r_batch: 1 / n of the pixel splits and slab traffic per layer, one ramp and tail).
-  // RN_W8R_BATCH=<n> (1: every layer on its own, as before round 4).
+  // RN_W8R_BATCH=<n>: the largest batch (1: every layer on its own, as before round 4); the batch of a geometry is rn_conv_wgrad8r_best_batch(<= n).
   static const int w8r_batch = getenv("RN_W8R_BATCH") ? std::max(1, std::min(RN_WGRAD8R_BATCH_MAX, atoi(getenv("RN_W8R_BATCH")))) : 8;
   static const int w8r_fork_grid = getenv("RN_W8_FORK_GRID") ? atoi(getenv("RN_W8_FORK_GRID")) : 256;
-  struct W8Queue { int n = 0; rn_wgrad8r_desc d[RN_WGRAD8R_BATCH_MAX]; int xs[RN_WGRAD8R_BATCH_MAX], dys[RN_WGRAD8R_BATCH_MAX], dws[RN_WGRAD8R_BATCH_MAX]; } w8q;
+  struct W8Queue { int n = 0, target = 1; rn_wgrad8r_desc d[RN_WGRAD8R_BATCH_MAX]; int xs[RN_WGRAD8R_BATCH_MAX], dys[RN_WGRAD8R_BATCH_MAX], dws[RN_WGRAD8R_BATCH_MAX]; } w8q;
   auto launch_w8q = [&]() -> int {
     if (!w8q.n) return 0;
     if (hipEventRecord(plan->ev_fork, as_stream(stream)) != hipSuccess || hipStreamWaitEvent(plan->side, plan->ev_fork, 0) != hipSuccess) {
@@ -538,9 +538,10 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
       if (P(0) && P(1) && P(2) && P(3) && rn_conv_wgrad8r_ok(&g, plan->dtype)) {
         if (w8q.n && memcmp(&w8q.d[0].g, &g, sizeof(g)) != 0)
           if (int e2 = launch_w8q()) return e2;
+        if (!w8q.n) w8q.target = rn_conv_wgrad8r_best_batch(&g, plan->dtype, w8r_batch);      // the count that fills whole rounds of the chip best
         w8q.xs[w8q.n] = o.buf[0]; w8q.dys[w8q.n] = o.buf[1]; w8q.dws[w8q.n] = o.buf[2];
         w8q.d[w8q.n++] = rn_wgrad8r_desc{P(0), P(1), (float*)P(2), P(3), plan->ws_bytes[o.buf[3]], g, o.flags};
-        if (w8q.n == w8r_batch)
+        if (w8q.n >= w8q.target)
           if (int e2 = launch_w8q()) return e2;
         continue;
       }

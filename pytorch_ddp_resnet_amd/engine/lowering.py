@@ -120,7 +120,7 @@ class Lowering:
         self.fuse = True                # BN batch statistics in the producing conv's epilogue (free: no extra operand reads)
         # BN-backward sums reduced in the dgrad epilogue (its operands are read as 16-byte chunks by the LDS-staged epilogue):
         # removes the bn_bwd_reduce pass (-1.15 ms) for +0.36 ms of dgrad per WRN-28-10 step (measured)
-        self.fuse_dgrad = fuse_dgrad
+        self.fuse_dgrad = fuse_dgrad and os.environ.get('RN_NO_DGRAD_FUSION', '0') != '1'      # (A/B: the BatchNorm-backward sums as a pass of their own)
         # a top-level "n [a] mp" as ONE pass forward and two gather passes backward (RN_NO_POOL_FUSION=1: the separate ops, A/B)
         self.fuse_pool = os.environ.get('RN_NO_POOL_FUSION', '0') != '1'
 
