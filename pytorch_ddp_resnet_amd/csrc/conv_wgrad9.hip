@@ -426,8 +426,16 @@ int rn_wgrad9_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid
   const long ntiles = (long)(g0.C / 32) * (g0.K / 160);
   const size_t nel = (size_t)g0.K * 9 * g0.C;
   long ws_cap = 128;
+  // records may share ONE workspace (the plan executor's side workspace): record i then takes the share-th region of it, share = the records before it
+  // that name the same pointer, and the workspace has to hold the slabs of all of them
+  int share[16], sharers[16];
   for (int i = 0; i < n; ++i) {
-    const long c = descs[i].ws ? (long)(descs[i].ws_bytes / (nel * sizeof(float))) : 0;
+    share[i] = 0; sharers[i] = 0;
+    for (int j = 0; j < n; ++j)
+      if (descs[j].ws == descs[i].ws) { ++sharers[i]; if (j < i) ++share[i]; }
+  }
+  for (int i = 0; i < n; ++i) {
+    const long c = descs[i].ws ? (long)(descs[i].ws_bytes / (nel * sizeof(float) * (size_t)sharers[i])) : 0;
     if (c < ws_cap) ws_cap = c;
   }
   const int splits = w9_pick_splits(ntiles * n, nk, (double)nel * n, ws_cap);
@@ -439,9 +447,9 @@ int rn_wgrad9_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid
     RN_CHECK_ARG(d.x && d.dy && d.dw, "rn_conv_wgrad8r_batch: record %d: null pointer", i);
     RN_CHECK_ARG(memcmp(&d.g, &g0, sizeof(g0)) == 0, "rn_conv_wgrad8r_batch: record %d has another geometry", i);
     const bool direct = splits == 1 && !(d.flags & RN_F_ACCUM);
-    RN_CHECK_ARG(direct || (d.ws && d.ws_bytes >= (size_t)splits * nel * sizeof(float)), "rn_conv_wgrad8r_batch: record %d: workspace too small (%zu < %zu)", i, d.ws_bytes,
-                 (size_t)splits * nel * sizeof(float));
-    w9_fill(b.r[i], d.x, d.dy, direct ? d.dw : reinterpret_cast<float*>(d.ws), splits, &g0, 0);
+    RN_CHECK_ARG(direct || (d.ws && d.ws_bytes >= (size_t)sharers[i] * splits * nel * sizeof(float)), "rn_conv_wgrad8r_batch: record %d: workspace too small (%zu < %zu)", i, d.ws_bytes,
+                 (size_t)sharers[i] * splits * nel * sizeof(float));
+    w9_fill(b.r[i], d.x, d.dy, direct ? d.dw : reinterpret_cast<float*>(d.ws) + (size_t)share[i] * splits * nel, splits, &g0, 0);
     b.first[i] = items;
     items += b.r[i].nct * b.r[i].nkt * splits;
     rn_note_kernel("wgrad9<288x160>");
@@ -456,7 +464,7 @@ int rn_wgrad9_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid
   for (int i = 0; i < n; ++i) {
     const rn_wgrad8r_desc& d = descs[i];
     if (splits == 1 && !(d.flags & RN_F_ACCUM)) continue;             // written in place
-    if (int e = rn_wgrad_reduce_slabs(reinterpret_cast<const float*>(d.ws), d.dw, (long)nel, splits, (d.flags & RN_F_ACCUM) ? 1 : 0, 1, s)) return e;
+    if (int e = rn_wgrad_reduce_slabs(reinterpret_cast<const float*>(d.ws) + (size_t)share[i] * splits * nel, d.dw, (long)nel, splits, (d.flags & RN_F_ACCUM) ? 1 : 0, 1, s)) return e;
   }
   return 0;
 }

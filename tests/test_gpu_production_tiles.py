@@ -787,10 +787,12 @@ def test_wgrad8r_exact_integers():
         assert torch.equal(eng.tensors[sl['dw']].cpu(), ref.contiguous()), g
 
 
-@pytest.mark.parametrize('g,n', [((2, 16, 16, 160, 160, 3, 1, 1), 3), ((3, 8, 8, 320, 320, 3, 1, 1), 2), ((6, 16, 16, 160, 320, 3, 2, 1), 4)])
-def test_wgrad8r_batch_of_layers(g, n):
+@pytest.mark.parametrize('shared_ws', [False, True])
+@pytest.mark.parametrize('g,n', [((2, 16, 16, 160, 160, 3, 1, 1), 3), ((3, 8, 8, 320, 320, 3, 1, 1), 2), ((6, 16, 16, 160, 320, 3, 2, 1), 4), ((16, 16, 16, 320, 320, 3, 1, 1), 6)])
+def test_wgrad8r_batch_of_layers(g, n, shared_ws):
     """rn_conv_wgrad8r_batch: the weight gradients of n layers of one geometry as ONE launch (a table of layer records, items = (split, tile) per record, slabs
-    in every record's own workspace, summed right behind): every layer against torch-CPU, one of them accumulating into an existing gradient; the launch is
+    in every record's own workspace -- or, shared_ws, in ONE workspace that all records name, as the plan executor's side workspace is: every record then
+    takes a region of its own -- summed right behind): every layer against torch-CPU, one of them accumulating into an existing gradient; the launch is
     bitwise reproducible."""
     import ctypes as C
     import gpu_harness as h                               # noqa: F401
@@ -813,6 +815,7 @@ def test_wgrad8r_batch_of_layers(g, n):
         dys = [torch.from_numpy(rng.randn(N, P, Q, K).astype(np.float32)).to(torch.float16) for _ in range(n)]
         old = torch.from_numpy(rng.randn(K, k, k, Cc).astype(np.float32))
         outs = []
+        one_ws = torch.empty(max(n * wsb, 16), dtype=torch.uint8, device=dev)       # (the executor's side workspace is sized for the largest single layer; here: room for all)
         for rep in range(2):
             keep = []
             descs = (Desc * n)()
@@ -820,10 +823,10 @@ def test_wgrad8r_batch_of_layers(g, n):
             for i in range(n):
                 xd, dyd = xs[i].to(dev), dys[i].to(dev)
                 dw = old.to(dev).clone() if i == 1 else torch.full((K, k, k, Cc), float('nan'), device=dev)
-                ws = torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
+                ws = one_ws if shared_ws else torch.empty(max(wsb, 16), dtype=torch.uint8, device=dev)
                 keep += [xd, dyd, ws]
                 dws.append(dw)
-                descs[i] = Desc(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), wsb, gs, ir.F_ACCUM if i == 1 else 0)
+                descs[i] = Desc(xd.data_ptr(), dyd.data_ptr(), dw.data_ptr(), ws.data_ptr(), n * wsb if shared_ws else wsb, gs, ir.F_ACCUM if i == 1 else 0)
             L.rn_kernel_log(1)
             _lib.check(L.rn_conv_wgrad8r_batch(descs, n, ir.RN_F16, 256, vp(torch.cuda.current_stream().cuda_stream)))
             torch.cuda.synchronize()
