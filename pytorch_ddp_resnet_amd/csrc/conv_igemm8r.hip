@@ -413,6 +413,13 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
     const uint4* SA = &smem[a_cur];
     const unsigned b_nxt = lds0 + (unsigned)((B_0 + ((J + 2) % 3) * B_SZ) * 16);
     // ---- phase 1: all B fragments, A rows 0-31 of the wave ----
+    if constexpr (PERM == 2 && (IA || IB)) {                 // experiment: the pieces in FRONT of the fragment reads
+      const unsigned keep = m0_save();
+      if constexpr (IA) { if (2 * J < 4 || nAw > 4) issue_a(2 * J, a_nxt, my_i_n, sel_a_n); }
+      if constexpr (IB) issue_b(0, b_nxt, sel_b, ok_b);
+      m0_restore(keep);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (PROBE != 3) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) { bf[ct][0] = SB[fb0 + ct * 128]; bf[ct][1] = SB[(fb0 ^ 4) + ct * 128]; }
@@ -420,7 +427,7 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
       for (int i = 0; i < 2; ++i) { af[i][0] = SA[fa[J][i]]; af[i][1] = SA[fa[J][i] ^ 4]; }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (IA || IB) {
+    if constexpr (PERM != 2 && (IA || IB)) {
       const unsigned keep = m0_save();
       if constexpr (IA) { if (2 * J < 4 || nAw > 4) issue_a(2 * J, a_nxt, my_i_n, sel_a_n); }
       if constexpr (IB) issue_b(0, b_nxt, sel_b, ok_b);
@@ -442,12 +449,22 @@ __global__ __launch_bounds__(512, 2) void igemm8r_kernel(const IgemmArgs a) {
     __builtin_amdgcn_s_setprio(0);
     raw_barrier();
     // ---- phase 2: A rows 32-63 of the wave, B from registers ----
+    if constexpr (PERM == 2 && (IA || IB)) {
+      const unsigned keep = m0_save();
+      if constexpr (IA && J < 2) issue_a(2 * J + 1, a_nxt, my_i_n, sel_a_n);
+      if constexpr (IB) {
+        issue_b(1, b_nxt, sel_b, ok_b);
+        if (nBw > 2) issue_b(2, b_nxt, sel_b, ok_b);
+      }
+      m0_restore(keep);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     if constexpr (PROBE != 3) {
 #pragma unroll
       for (int i = 0; i < 2; ++i) { af[i][0] = SA[fa[J][2 + i]]; af[i][1] = SA[fa[J][2 + i] ^ 4]; }
     }
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (IA || IB) {
+    if constexpr (PERM != 2 && (IA || IB)) {
       const unsigned keep = m0_save();
       if constexpr (IA && J < 2) issue_a(2 * J + 1, a_nxt, my_i_n, sel_a_n);
       if constexpr (IB) {
@@ -649,6 +666,11 @@ template <typename T> int launch8r(IgemmArgs& a, hipStream_t s) {
       RN_CHECK_LAUNCH("igemm8r probe");
       return 0;
     }
+  }
+  if ((g_rn_variant2 & 2097152) && epm == R8_PLAIN && a.w8_dp_tiles == 1) {
+    hipLaunchKernelGGL((igemm8r_kernel<T, R8_PLAIN, 0, 0, 2>), dim3(grid), dim3(512), 0, s, a);
+    RN_CHECK_LAUNCH("igemm8r");
+    return 0;
   }
   if ((g_rn_variant2 & 4096) && epm == R8_PLAIN && a.w8_dp_tiles == 1) {
     hipLaunchKernelGGL((igemm8r_kernel<T, R8_PLAIN, 0, 0, 0>), dim3(grid), dim3(512), 0, s, a);

@@ -393,9 +393,9 @@ static void w9_fill(W9Rec& r, const void* x, const void* dy, float* out, int spl
 template <typename T> static void w9_launch(const W9Batch& b, int grid, hipStream_t s) {
   if constexpr (std::is_same<T, f16_t>::value) {
     const int probe = (g_rn_variant2 >> 8) & 7;
-    if (probe == 1) { hipLaunchKernelGGL((wgrad9_kernel<T, 1, 0>), dim3(grid), dim3(768), 0, s, b); return; }
-    if (probe == 2) { hipLaunchKernelGGL((wgrad9_kernel<T, 2, 0>), dim3(grid), dim3(768), 0, s, b); return; }
-    if (probe == 3) { hipLaunchKernelGGL((wgrad9_kernel<T, 3, 0>), dim3(grid), dim3(768), 0, s, b); return; }
+    if (probe == 1) { hipLaunchKernelGGL((wgrad9_kernel<T, 1, 2>), dim3(grid), dim3(768), 0, s, b); return; }
+    if (probe == 2) { hipLaunchKernelGGL((wgrad9_kernel<T, 2, 2>), dim3(grid), dim3(768), 0, s, b); return; }
+    if (probe == 3) { hipLaunchKernelGGL((wgrad9_kernel<T, 3, 2>), dim3(grid), dim3(768), 0, s, b); return; }
   }
   if (g_rn_variant2 & 8192) { hipLaunchKernelGGL((wgrad9_kernel<T, 0, 0>), dim3(grid), dim3(768), 0, s, b); return; }
   hipLaunchKernelGGL((wgrad9_kernel<T>), dim3(grid), dim3(768), 0, s, b);
