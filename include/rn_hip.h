@@ -110,8 +110,8 @@ typedef struct rn_plan rn_plan;
 const char* rn_last_error(void);
 /* ABI version: bumped with EVERY change of an entry point's signature or meaning; a binding refuses a library of another version (a stale
  * librn_hip.so would otherwise take shifted pointer / integer arguments).  3: round 3 (operand-set flags of rn_conv_kernel_names, workspaces).
- * 9: round 4 (rn_set_variant2).  10: rn_conv_wgrad8r_best_batch. */
-#define RN_ABI_VERSION 10
+ * 9: round 4 (rn_set_variant2).  10: rn_conv_wgrad8r_best_batch.  11: rn_bn_side_friendly. */
+#define RN_ABI_VERSION 11
 int rn_version(void);
 /* kernel-variant switch for A/B measurements (tools/conv_bench.py; bits documented in csrc/conv_igemm.hip); 0 = shipped */
 void rn_set_variant(int v);
@@ -316,6 +316,9 @@ int rn_bn_bwd_reduce(const void* dout, const void* x, const void* mask_src, cons
                      int nblk, int dtype, int64_t M, int C, int flags, float gscale, float drop_p, uint32_t site,
                      uint64_t step_seed, rn_stream s);
 /* partial -> dsum [2][C]; dgamma/dbeta written (or accumulated with RN_F_ACCUM) */
+/* 1: the calling thread's following BatchNorm-backward launches (finalize, apply) take the forms that fit beside the forked weight gradients' persistent
+ * workgroups (256-thread finalize, two rows in flight); rn_plan_run sets it for ranges that fork onto the side stream and clears it again */
+void rn_bn_side_friendly(int on);
 int rn_bn_bwd_finalize(const float* partial, int nblk, float* dsum, float* dgamma, float* dbeta, int C, int flags,
                        rn_stream s);
 /* dx = scale*(g - dsum0/count - xhat*dsum1/count) [train] | scale*g [eval]  [+ add operand];  optional g_out */

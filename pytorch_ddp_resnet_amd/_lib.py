@@ -7,7 +7,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'librn_hip.so')
 
 OP_NBUF, OP_NDIM = 8, 20
-ABI_VERSION = 10         # include/rn_hip.h RN_ABI_VERSION this binding was written for
+ABI_VERSION = 11         # include/rn_hip.h RN_ABI_VERSION this binding was written for
 
 
 class RnOp(C.Structure):

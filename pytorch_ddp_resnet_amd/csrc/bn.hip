@@ -87,10 +87,21 @@ __global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, 
   }
 }
 
+// The backward's BatchNorm kernels in forms that fit BESIDE the forked weight gradients' persistent workgroups (three waves of 136 registers per SIMD leave
+// 104 of 512): 256-thread finalize workgroups, two rows of loads in flight in the apply pass.  The plan executor switches it on for ranges that fork
+// (rn_bn_side_friendly); RN_BN_LIGHT=0 keeps the wide forms (A/B).  Measured on one box, WRN-28-10: 6.131 / 6.128 / 6.122 -> 5.974 / 5.979 / 6.002 ms per step.
+static thread_local int t_bn_side_friendly = 0;
+inline bool bn_light() {
+  static const bool off = getenv("RN_BN_LIGHT") && atoi(getenv("RN_BN_LIGHT")) == 0;
+  return t_bn_side_friendly && !off;
+}
+
 // reduces [nblk][2][C] partials in double: 16 channels x 64 slab-lanes per workgroup (the fused conv epilogues write one
 // partial row per 128 output pixels: up to 1024 rows)
 constexpr int FC = 16, FL = 64;
-__device__ inline void reduce_partials(const float* __restrict__ partial, int nblk, int C, int c, int bl, double& s, double& ss, double (*red)[FL][FC], int b_lo = 0) {
+template <int FLT = FL>
+__device__ inline void reduce_partials(const float* __restrict__ partial, int nblk, int C, int c, int bl, double& s, double& ss, double (*red)[FLT][FC], int b_lo = 0) {
+  constexpr int FL = FLT;                                  // (shadows the namespace constant: the row lanes of THIS instantiation)
   // fixed-order tree (bitwise reproducible): rows b = bl, bl+64, ... per thread; the 4 row lanes of a wave by shuffles; the 16
   // waves through LDS, 4 per lane group of wave 0, then shuffles again.  The result is valid in threads 0..15 (bl == 0).
   // (a serial 64-step LDS loop here cost ~2.8 us of a 6 us kernel)
@@ -123,7 +134,7 @@ __device__ inline void reduce_partials(const float* __restrict__ partial, int nb
       }
     }
   }
-  static_assert(FC == 16 && FL == 64, "reduction tree is written for 16 channels x 64 row lanes");
+  static_assert(FC == 16 && (FL == 64 || FL == 16), "reduction tree is written for 16 channels x 64 (or 16) row lanes");
   const int tid = threadIdx.x, cl = tid % FC, wave = tid >> 6, lane = tid & 63;
   s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
   s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
@@ -133,22 +144,25 @@ __device__ inline void reduce_partials(const float* __restrict__ partial, int nb
     const int g = lane >> 4;
     s = 0.0; ss = 0.0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) { s += red[0][g + 4 * w][cl]; ss += red[1][g + 4 * w][cl]; }
+    for (int w = 0; w < FL / 16; ++w) { s += red[0][g + 4 * w][cl]; ss += red[1][g + 4 * w][cl]; }
     s += __shfl_xor(s, 16); ss += __shfl_xor(ss, 16);
     s += __shfl_xor(s, 32); ss += __shfl_xor(ss, 32);
   }
 }
 
-__global__ __launch_bounds__(FC * FL) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, double count, const float* __restrict__ gamma,
+// FLT = 16 (256-thread workgroups, a quarter of the registers per SIMD): the form launched beside forked weight gradients, whose persistent workgroups leave
+// ~100 registers per SIMD lane free -- a 1,024-thread workgroup does not fit beside them and waited for a whole CU
+template <int FLT>
+__global__ __launch_bounds__(FC * FLT) void bn_finalize_kernel(const float* __restrict__ partial, int nblk, double count, const float* __restrict__ gamma,
                                    const float* __restrict__ beta, float* __restrict__ rmean, float* __restrict__ rvar,
                                    long long* __restrict__ nbt, float* __restrict__ coef, int C, float eps, float momentum, int train) {
-  __shared__ double red[2][FL][FC];
+  __shared__ double red[2][FLT][FC];
   const int c = blockIdx.x * FC + threadIdx.x % FC, bl = threadIdx.x / FC;
   if (blockIdx.x == 0 && threadIdx.x == 0 && train && nbt) nbt[0] += 1;
   double mean = 0.0, var = 0.0;
   if (train) {
     double s, ss;
-    reduce_partials(partial, nblk, C, c, bl, s, ss, red);
+    reduce_partials<FLT>(partial, nblk, C, c, bl, s, ss, red);
     if (bl != 0 || c >= C) return;
     mean = s / count;
     var = ss / count - mean * mean;
@@ -169,12 +183,13 @@ __global__ __launch_bounds__(FC * FL) void bn_finalize_kernel(const float* __res
   coef[3 * C + c] = (float)invstd;
 }
 
-__global__ __launch_bounds__(FC * FL) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dsum, float* __restrict__ dgamma,
+template <int FLT>
+__global__ __launch_bounds__(FC * FLT) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, float* __restrict__ dsum, float* __restrict__ dgamma,
                                        float* __restrict__ dbeta, int C, int accum) {
-  __shared__ double red[2][FL][FC];
+  __shared__ double red[2][FLT][FC];
   const int c = blockIdx.x * FC + threadIdx.x % FC, bl = threadIdx.x / FC;
   double s, ss;
-  reduce_partials(partial, nblk, C, c, bl, s, ss, red);
+  reduce_partials<FLT>(partial, nblk, C, c, bl, s, ss, red);
   if (bl != 0 || c >= C) return;
   dsum[c] = (float)s;
   dsum[C + c] = (float)ss;
@@ -544,6 +559,13 @@ inline int slab_rows_stream(long M, int C, int ce) {
 template <typename T, int MASK, int ADD>
 void launch_bwd_apply_stream(int grid, hipStream_t st, const void* dout, const void* x, const void* mask, const float* coef, const float* dsum, const ResDesc& r,
                              void* dx, void* g, int M, int H, int W, int C, int rows, int train, float gscale, float inv_count, uint32_t key, uint32_t thr) {
+  if constexpr (sizeof(T) == 2 && MASK != 2) {
+    if (bn_light()) {       // two rows of loads in flight instead of four: <= 104 registers, a wave per SIMD fits beside a forked weight gradient's three
+      hipLaunchKernelGGL((bn_bwd_apply_stream_kernel<T, MASK, ADD, 2>), dim3(grid), dim3(NT), 0, st, (const T*)dout, (const T*)x, (const T*)mask, coef, dsum, r, (T*)dx, (T*)g,
+                         M, H, W, C, rows, train, gscale, inv_count, key, thr);
+      return;
+    }
+  }
   hipLaunchKernelGGL((bn_bwd_apply_stream_kernel<T, MASK, ADD, 4>), dim3(grid), dim3(NT), 0, st, (const T*)dout, (const T*)x, (const T*)mask, coef, dsum, r, (T*)dx, (T*)g,
                      M, H, W, C, rows, train, gscale, inv_count, key, thr);
 }
@@ -594,7 +616,7 @@ extern "C" int rn_bn_finalize(const float* partial, int nblk, double count, cons
   const int train = (flags & RN_F_TRAIN) ? 1 : 0;
   RN_CHECK_ARG(gamma && beta && running_mean && running_var && coef && C > 0, "rn_bn_finalize: null pointer");
   RN_CHECK_ARG(!train || (partial && nblk > 0 && count > 0), "rn_bn_finalize: train mode needs partial sums");
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3(cdiv(C, FC)), dim3(FC * FL), 0, as_stream(s), partial, nblk, count, gamma, beta, running_mean, running_var,
+  hipLaunchKernelGGL(bn_finalize_kernel<FL>, dim3(cdiv(C, FC)), dim3(FC * FL), 0, as_stream(s), partial, nblk, count, gamma, beta, running_mean, running_var,
                      (long long*)nbt, coef, C, eps, momentum, train);
   RN_CHECK_LAUNCH("bn_finalize");
   return 0;
@@ -653,9 +675,16 @@ extern "C" int rn_bn_bwd_reduce(const void* dout, const void* x, const void* mas
   return 0;
 }
 
+extern "C" void rn_bn_side_friendly(int on) { t_bn_side_friendly = on; }
+
 extern "C" int rn_bn_bwd_finalize(const float* partial, int nblk, float* dsum, float* dgamma, float* dbeta, int C, int flags, rn_stream s) {
   RN_CHECK_ARG(partial && dsum && dgamma && dbeta && nblk > 0 && C > 0, "rn_bn_bwd_finalize: bad argument");
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3(cdiv(C, FC)), dim3(FC * FL), 0, as_stream(s), partial, nblk, dsum, dgamma, dbeta, C, (flags & RN_F_ACCUM) ? 1 : 0);
+  if (bn_light() && nblk <= 1024) {
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel<16>, dim3(cdiv(C, FC)), dim3(FC * 16), 0, as_stream(s), partial, nblk, dsum, dgamma, dbeta, C, (flags & RN_F_ACCUM) ? 1 : 0);
+    RN_CHECK_LAUNCH("bn_bwd_finalize");
+    return 0;
+  }
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel<FL>, dim3(cdiv(C, FC)), dim3(FC * FL), 0, as_stream(s), partial, nblk, dsum, dgamma, dbeta, C, (flags & RN_F_ACCUM) ? 1 : 0);
   RN_CHECK_LAUNCH("bn_bwd_finalize");
   return 0;
 }

@@ -399,6 +399,11 @@ static int run_op(rn_plan* p, int idx, uint64_t step_seed, rn_stream s) {
 extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_seed, rn_stream stream) {
   RN_CHECK_ARG(plan != nullptr, "rn_plan_run: null plan");
   RN_CHECK_ARG(first >= 0 && last <= (int)plan->ops.size() && first <= last, "rn_plan_run: bad range [%d, %d)", first, last);
+  // a range that forks weight gradients onto the side stream: the chain's BatchNorm-backward kernels take the forms that fit beside them on a CU
+  bool forks = false;
+  if (plan->overlap && !plan->profile)
+    for (int i = first; i < last && !forks; ++i) forks = (plan->ops[i].flags & RN_F_FORK) != 0;
+  struct SideFriendly { bool on; explicit SideFriendly(bool f) : on(f) { if (on) rn_bn_side_friendly(1); } ~SideFriendly() { if (on) rn_bn_side_friendly(0); } } side_friendly(forks);
   rn_reduce_desc pending[RN_REDUCE_BATCH_MAX];
   int pending_slot[RN_REDUCE_BATCH_MAX];                  // the dw buffer of each pending sum: an op that touches one forces the flush first
   int n_pending = 0;
@@ -416,8 +421,10 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
   };
   // Wide layers of the 160-channel family (WRN-28-10): the FORKED weight gradients the 320 x 160 kernel takes wait as well, per geometry, and go to the
   // side stream as ONE launch of up to w8r_batch layers (rn_conv_wgrad8r_batch: 1 / n of the pixel splits and slab traffic per layer, one ramp and tail).
-  // RN_W8R_BATCH=<n>: the largest batch (1: every layer on its own, as before round 4); the batch of a geometry is rn_conv_wgrad8r_best_batch(<= n).
-  static const int w8r_batch = getenv("RN_W8R_BATCH") ? std::max(1, std::min(RN_WGRAD8R_BATCH_MAX, atoi(getenv("RN_W8R_BATCH")))) : 8;
+  // RN_W8R_BATCH=<n>: the largest batch; the batch of a geometry is rn_conv_wgrad8r_best_batch(<= n).  Default 1 (every layer on its own) since the chain's
+  // BatchNorm kernels run BESIDE the forked launches (rn_bn_side_friendly): short launches interleave with them layer by layer -- 6.06 ms per step against 6.17-6.19
+  // (2, 4 layers) / 6.26 (8) / 6.35 (12) on one box; with the wide BatchNorm kernels it was the other way round (6.64 / 6.55 / 6.51 / 6.50 for 2 / 4 / 8 / 12).
+  static const int w8r_batch = getenv("RN_W8R_BATCH") ? std::max(1, std::min(RN_WGRAD8R_BATCH_MAX, atoi(getenv("RN_W8R_BATCH")))) : 1;
   static const int w8r_fork_grid = getenv("RN_W8_FORK_GRID") ? atoi(getenv("RN_W8_FORK_GRID")) : 256;
   struct W8Queue { int n = 0, target = 1; rn_wgrad8r_desc d[RN_WGRAD8R_BATCH_MAX]; int xs[RN_WGRAD8R_BATCH_MAX], dys[RN_WGRAD8R_BATCH_MAX], dws[RN_WGRAD8R_BATCH_MAX]; } w8q;
   auto launch_w8q = [&]() -> int {
