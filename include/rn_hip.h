@@ -110,7 +110,7 @@ typedef struct rn_plan rn_plan;
 const char* rn_last_error(void);
 /* ABI version: bumped with EVERY change of an entry point's signature or meaning; a binding refuses a library of another version (a stale
  * librn_hip.so would otherwise take shifted pointer / integer arguments).  3: round 3 (operand-set flags of rn_conv_kernel_names, workspaces).
- * 9: round 4 (rn_set_variant2).  10: rn_conv_wgrad8r_best_batch.  11: rn_bn_side_friendly. */
+ * 9: round 4 (rn_set_variant2).  10: rn_conv_wgrad8r_best_batch.  11: rn_bn_side_friendly, rn_conv_wgrad8r_batch2. */
 #define RN_ABI_VERSION 11
 int rn_version(void);
 /* kernel-variant switch for A/B measurements (tools/conv_bench.py; bits documented in csrc/conv_igemm.hip); 0 = shipped */
@@ -282,6 +282,9 @@ typedef struct rn_wgrad8r_desc {
 } rn_wgrad8r_desc;
 int rn_conv_wgrad8r_ok(const rn_conv_geom* g, int dtype);
 int rn_conv_wgrad8r_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, rn_stream s);
+/* the same with the slab sums on s_reduce behind `ev` (a hipEvent_t of the caller, recorded on s behind the kernel): light launches that share CUs with the next
+ * weight gradient; the caller orders the workspace's re-use and folds s_reduce back before the gradients are consumed (csrc/plan.cpp does both) */
+int rn_conv_wgrad8r_batch2(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, rn_stream s, rn_stream s_reduce, void* ev);
 /* how many layers of geometry g are worth collecting for one rn_conv_wgrad8r_batch launch (1..max_n): the count whose tiles fill whole rounds of the chip best
  * (modelled time per layer; csrc/conv_wgrad9.hip) */
 int rn_conv_wgrad8r_best_batch(const rn_conv_geom* g, int dtype, int max_n);

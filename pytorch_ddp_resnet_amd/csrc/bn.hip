@@ -14,10 +14,11 @@ constexpr int NT = 256;
 
 // ---- per-channel partial reductions over a slab of rows --------------------------------------------------
 // MODE 0: (sum x, sum x^2)            MODE 1: (sum g, sum g*xhat), g = dout*gscale*[mask>0]
-template <typename T, int MODE>
+template <typename T, int MODE, int UNR = 4, int UM = -1>
 __global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, const T* __restrict__ dout, const T* __restrict__ mask,
                                                        const float* __restrict__ coef, float* __restrict__ partial, int M, int C,
-                                                       int rows_per_blk, int use_mask, float gscale, uint32_t key, uint32_t thr) {
+                                                       int rows_per_blk, int use_mask_rt, float gscale, uint32_t key, uint32_t thr) {
+  const int use_mask = UM >= 0 ? UM : use_mask_rt;         // (UM: the mask mode at compile time -- the light form: the recompute path's coefficients and hash leave the registers)
   // use_mask: 0 none, 1 read `mask`, 2 recompute [x*scale+shift > 0] (and the dropout keep hash when thr != 0)
   constexpr int CE = Elem<T>::CE;
   __shared__ float red[2][NT][CE + 1];
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, 
           sc[e] = coef[cg * CE + e]; sh[e] = coef[C + cg * CE + e];
         }
       }
-#pragma unroll 4
+#pragma unroll UNR
       for (int r = r_begin + rl; r < r_end; r += lanes) {
         const size_t off = (size_t)r * C + (size_t)cg * CE;
         Chunk<T> cx = load_chunk<T>(x + off);
@@ -670,7 +671,11 @@ extern "C" int rn_bn_bwd_reduce(const void* dout, const void* x, const void* mas
   RN_CHECK_ARG(drop_p == 0.f || (use_mask == 2 && M * C < (1L << 32)), "rn_bn_bwd_reduce: dropout recompute needs RN_F_MASK_RECOMPUTE and < 2^32 elements");
   const uint32_t thr = drop_p > 0.f ? rn_drop_threshold(drop_p) : 0u, key = rn_drop_key(site, step_seed);
   const int rows = (int)((M + nblk - 1) / nblk);
-  RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T_, 1>), dim3(nblk), dim3(NT), 0, as_stream(s), (const T_*)x, (const T_*)dout, (const T_*)mask_src, coef, partial, (int)M, C, rows, use_mask, gscale, key, thr));
+  if (bn_light() && use_mask == 1) {      // two rows in flight, the mask mode fixed: fits beside the forked weight gradients
+    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T_, 1, 2, 1>), dim3(nblk), dim3(NT), 0, as_stream(s), (const T_*)x, (const T_*)dout, (const T_*)mask_src, coef, partial, (int)M, C, rows, use_mask, gscale, key, thr));
+  } else {
+    RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_reduce_kernel<T_, 1>), dim3(nblk), dim3(NT), 0, as_stream(s), (const T_*)x, (const T_*)dout, (const T_*)mask_src, coef, partial, (int)M, C, rows, use_mask, gscale, key, thr));
+  }
   RN_CHECK_LAUNCH("bn_bwd_reduce");
   return 0;
 }

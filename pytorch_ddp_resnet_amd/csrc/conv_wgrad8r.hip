@@ -355,7 +355,7 @@ int rn_launch_wgrad8r(const void* x, const void* dy, float* out, int splits, int
 int rn_wgrad_reduce_slabs(const float* ws, float* dw_krsc, long n, int splits, int accum, int eight_phase, hipStream_t s);      // conv_wgrad.hip
 
 int rn_wgrad9_splits(const rn_conv_geom* g, int dtype);                                                                      // conv_wgrad9.hip
-int rn_wgrad9_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, hipStream_t s);
+int rn_wgrad9_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, hipStream_t s, hipStream_t s_reduce, hipEvent_t ev);
 
 extern "C" int rn_conv_wgrad8r_ok(const rn_conv_geom* g, int dtype) { return g && (rn_wgrad9_splits(g, dtype) > 0 || rn_wgrad8r_splits(g, dtype) > 0) ? 1 : 0; }
 
@@ -371,12 +371,23 @@ extern "C" int rn_conv_wgrad8r_best_batch(const rn_conv_geom* g, int dtype, int 
   return max_n < 4 ? max_n : 4;
 }
 
+static int w8r_batch_impl(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, rn_stream s, hipStream_t s_reduce, hipEvent_t ev);
 extern "C" int rn_conv_wgrad8r_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, rn_stream s) {
+  return w8r_batch_impl(descs, n, dtype, max_grid, s, nullptr, nullptr);
+}
+// the same with the slab sums on a stream of their own: `ev` (a hipEvent_t of the caller) is recorded on s behind the kernel, s_reduce waits for it and runs
+// the sums -- they are light HBM-bound launches that fit beside the NEXT weight gradient's (and a data gradient's) workgroups on a CU.  The caller orders the
+// workspace's re-use (the next launch into the same region waits for these sums) and folds s_reduce back before anything consumes the gradients.
+extern "C" int rn_conv_wgrad8r_batch2(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, rn_stream s, rn_stream s_reduce, void* ev) {
+  RN_CHECK_ARG(s_reduce && ev, "rn_conv_wgrad8r_batch2: null reduce stream / event");
+  return w8r_batch_impl(descs, n, dtype, max_grid, s, as_stream(s_reduce), reinterpret_cast<hipEvent_t>(ev));
+}
+static int w8r_batch_impl(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, rn_stream s, hipStream_t s_reduce, hipEvent_t ev) {
   static_assert(RN_WGRAD8R_BATCH_MAX == W8R_MAX, "header and kernel disagree");
   RN_CHECK_ARG(descs && n > 0 && n <= RN_WGRAD8R_BATCH_MAX, "rn_conv_wgrad8r_batch: n=%d out of range (1..%d)", n, RN_WGRAD8R_BATCH_MAX);
   const rn_conv_geom& g0 = descs[0].g;
   RN_CHECK_ARG(rn_conv_wgrad8r_ok(&g0, dtype), "rn_conv_wgrad8r_batch: the geometry is not one the 320 x 160 / 288 x 160 kernels take");
-  if (rn_wgrad9_splits(&g0, dtype) > 0) return rn_wgrad9_batch(descs, n, dtype, max_grid, as_stream(s));      // 3x3 stride 1: the nine-tap kernel
+  if (rn_wgrad9_splits(&g0, dtype) > 0) return rn_wgrad9_batch(descs, n, dtype, max_grid, as_stream(s), s_reduce, ev);      // 3x3 stride 1: the nine-tap kernel
   const long M = (long)g0.N * g0.P * g0.Q, nk = (M + 63) / 64;
   const long nseg = (long)g0.R * g0.S * (g0.C / 160), ntiles = ((nseg + 1) / 2) * (g0.K / 160);
   const size_t nel = (size_t)g0.K * g0.R * g0.S * g0.C;
@@ -417,10 +428,15 @@ extern "C" int rn_conv_wgrad8r_batch(const rn_wgrad8r_desc* descs, int n, int dt
   if (dtype == RN_BF16) hipLaunchKernelGGL((wgrad8r_kernel<bf16_t>), dim3(grid), dim3(512), 0, as_stream(s), b);
   else hipLaunchKernelGGL((wgrad8r_kernel<f16_t>), dim3(grid), dim3(512), 0, as_stream(s), b);
   RN_CHECK_LAUNCH("wgrad8r batch");
+  hipStream_t sr = as_stream(s);
+  if (s_reduce && ev) {
+    if (hipEventRecord(ev, as_stream(s)) != hipSuccess || hipStreamWaitEvent(s_reduce, ev, 0) != hipSuccess) { rn_set_error("rn_conv_wgrad8r_batch: event record / wait failed"); return 2; }
+    sr = s_reduce;
+  }
   for (int i = 0; i < n; ++i) {
     const rn_wgrad8r_desc& d = descs[i];
     if (splits == 1 && !(d.flags & RN_F_ACCUM)) continue;             // written in place
-    if (int e = rn_wgrad_reduce_slabs(reinterpret_cast<const float*>(d.ws) + (size_t)share[i] * splits * nel, d.dw, (long)nel, splits, (d.flags & RN_F_ACCUM) ? 1 : 0, 1, as_stream(s))) return e;
+    if (int e = rn_wgrad_reduce_slabs(reinterpret_cast<const float*>(d.ws) + (size_t)share[i] * splits * nel, d.dw, (long)nel, splits, (d.flags & RN_F_ACCUM) ? 1 : 0, 1, sr)) return e;
   }
   return 0;
 }

@@ -419,7 +419,8 @@ int rn_launch_wgrad9(const void* x, const void* dy, float* out, int splits, int 
 int rn_wgrad_reduce_slabs(const float* ws, float* dw_krsc, long n, int splits, int accum, int eight_phase, hipStream_t s);      // conv_wgrad.hip
 
 // n layers of ONE geometry as one launch (see rn_conv_wgrad8r_batch, which hands the geometries this kernel takes over to it)
-int rn_wgrad9_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, hipStream_t s) {
+// s_reduce / ev (both or neither): the slab sums go to s_reduce behind event ev, which is recorded on s behind the kernel
+int rn_wgrad9_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, hipStream_t s, hipStream_t s_reduce, hipEvent_t ev) {
   static_assert(RN_WGRAD8R_BATCH_MAX == W9_MAX, "header and kernel disagree");
   const rn_conv_geom& g0 = descs[0].g;
   const long M = (long)g0.N * g0.H * g0.W, nk = M / 64;
@@ -461,6 +462,10 @@ int rn_wgrad9_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid
   const int grid = items < cap ? items : cap;
   if (dtype == RN_BF16) w9_launch<bf16_t>(b, grid, s); else w9_launch<f16_t>(b, grid, s);
   RN_CHECK_LAUNCH("wgrad9 batch");
+  if (s_reduce && ev) {
+    if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(s_reduce, ev, 0) != hipSuccess) { rn_set_error("rn_conv_wgrad8r_batch: event record / wait failed"); return 2; }
+    s = s_reduce;
+  }
   for (int i = 0; i < n; ++i) {
     const rn_wgrad8r_desc& d = descs[i];
     if (splits == 1 && !(d.flags & RN_F_ACCUM)) continue;             // written in place

@@ -92,7 +92,19 @@ struct rn_plan {
   char* arena = nullptr;           // deferral is on iff it is set
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr, ev_peek = nullptr;
+  // The slab sums of the forked weight gradients run on a THIRD stream (light HBM-bound launches that share CUs with the next weight gradient and with the data
+  // gradients); the side workspace is used in two halves alternately, a launch into a half waits for the sums that last read it (ev_red), and side2 is folded
+  // back into the side stream before anything waits for the side stream (fold_side2).
+  hipStream_t side2 = nullptr;
+  hipEvent_t ev_wg = nullptr, ev_red[2] = {nullptr, nullptr}, ev_s2 = nullptr;
+  bool red_rec[2] = {false, false}, side2_pending = false;
+  int w_parity = 0;
   ~rn_plan() {
+    if (ev_wg) (void)hipEventDestroy(ev_wg);
+    if (ev_red[0]) (void)hipEventDestroy(ev_red[0]);
+    if (ev_red[1]) (void)hipEventDestroy(ev_red[1]);
+    if (ev_s2) (void)hipEventDestroy(ev_s2);
+    if (side2) (void)hipStreamDestroy(side2);
     for (auto e : ev) (void)hipEventDestroy(e);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
@@ -191,8 +203,13 @@ extern "C" int rn_plan_set_overlap(rn_plan* plan, int enable) {
     if (hipStreamCreateWithPriority(&plan->side, hipStreamNonBlocking, least) != hipSuccess ||
         hipEventCreateWithFlags(&plan->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&plan->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&plan->ev_peek, hipEventDisableTiming) != hipSuccess) {
-      rn_set_error("rn_plan_set_overlap: could not create the side stream / events");
+        hipEventCreateWithFlags(&plan->ev_peek, hipEventDisableTiming) != hipSuccess ||
+        hipStreamCreateWithPriority(&plan->side2, hipStreamNonBlocking, least) != hipSuccess ||
+        hipEventCreateWithFlags(&plan->ev_wg, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&plan->ev_red[0], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&plan->ev_red[1], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&plan->ev_s2, hipEventDisableTiming) != hipSuccess) {
+      rn_set_error("rn_plan_set_overlap: could not create the side streams / events");
       return 2;
     }
   }
@@ -200,10 +217,22 @@ extern "C" int rn_plan_set_overlap(rn_plan* plan, int enable) {
   return 0;
 }
 
+// the side stream waits for the slab sums issued on side2 so far: whoever then waits for the side stream waits for them too
+static int fold_side2(rn_plan* plan) {
+  if (!plan->side2_pending) return 0;
+  if (hipEventRecord(plan->ev_s2, plan->side2) != hipSuccess || hipStreamWaitEvent(plan->side, plan->ev_s2, 0) != hipSuccess) {
+    rn_set_error("rn_plan: folding the slab-sum stream back failed");
+    return 2;
+  }
+  plan->side2_pending = false;
+  return 0;
+}
+
 // makes `stream` wait for every weight-gradient op forked so far (no-op when none is pending)
 extern "C" int rn_plan_join(rn_plan* plan, rn_stream stream) {
   RN_CHECK_ARG(plan != nullptr, "rn_plan_join: null plan");
   if (!plan->side_pending) return 0;
+  if (int e = fold_side2(plan)) return e;
   if (hipEventRecord(plan->ev_join, plan->side) != hipSuccess || hipStreamWaitEvent(as_stream(stream), plan->ev_join, 0) != hipSuccess) {
     rn_set_error("rn_plan_join: event record / wait failed");
     return 2;
@@ -217,6 +246,7 @@ extern "C" int rn_plan_join(rn_plan* plan, rn_stream stream) {
 extern "C" int rn_plan_side_wait(rn_plan* plan, rn_stream stream) {
   RN_CHECK_ARG(plan != nullptr, "rn_plan_side_wait: null plan");
   if (!plan->side_pending) return 0;
+  if (int e = fold_side2(plan)) return e;
   if (hipEventRecord(plan->ev_peek, plan->side) != hipSuccess || hipStreamWaitEvent(as_stream(stream), plan->ev_peek, 0) != hipSuccess) {
     rn_set_error("rn_plan_side_wait: event record / wait failed");
     return 2;
@@ -426,6 +456,7 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
   // (2, 4 layers) / 6.26 (8) / 6.35 (12) on one box; with the wide BatchNorm kernels it was the other way round (6.64 / 6.55 / 6.51 / 6.50 for 2 / 4 / 8 / 12).
   static const int w8r_batch = getenv("RN_W8R_BATCH") ? std::max(1, std::min(RN_WGRAD8R_BATCH_MAX, atoi(getenv("RN_W8R_BATCH")))) : 1;
   static const int w8r_fork_grid = getenv("RN_W8_FORK_GRID") ? atoi(getenv("RN_W8_FORK_GRID")) : 256;
+  static const bool use_side2 = !(getenv("RN_NO_SIDE2") && atoi(getenv("RN_NO_SIDE2")) == 1);      // (A/B: the slab sums behind their kernel on the side stream)
   struct W8Queue { int n = 0, target = 1; rn_wgrad8r_desc d[RN_WGRAD8R_BATCH_MAX]; int xs[RN_WGRAD8R_BATCH_MAX], dys[RN_WGRAD8R_BATCH_MAX], dws[RN_WGRAD8R_BATCH_MAX]; } w8q;
   auto launch_w8q = [&]() -> int {
     if (!w8q.n) return 0;
@@ -434,7 +465,24 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
       return 2;
     }
     plan->side_pending = true;
-    const int e = rn_conv_wgrad8r_batch(w8q.d, w8q.n, plan->dtype, w8r_fork_grid, reinterpret_cast<rn_stream>(plan->side));
+    // every record names the ONE side workspace (the lowering's slot): with room for two regions the slab sums move to side2
+    bool two = use_side2 && plan->side2 != nullptr;
+    for (int i = 0; i < w8q.n && two; ++i) two = w8q.d[i].ws == w8q.d[0].ws && w8q.d[i].ws_bytes == w8q.d[0].ws_bytes && w8q.d[i].ws_bytes >= (1u << 20);
+    int e;
+    if (two) {
+      const int p = plan->w_parity;
+      plan->w_parity ^= 1;
+      const size_t half = (w8q.d[0].ws_bytes / 2) & ~(size_t)255;
+      for (int i = 0; i < w8q.n; ++i) { w8q.d[i].ws = static_cast<char*>(w8q.d[i].ws) + (size_t)p * half; w8q.d[i].ws_bytes = half; }
+      if (plan->red_rec[p] && hipStreamWaitEvent(plan->side, plan->ev_red[p], 0) != hipSuccess) { rn_set_error("rn_plan_run: wait for the slab sums failed"); return 2; }
+      e = rn_conv_wgrad8r_batch2(w8q.d, w8q.n, plan->dtype, w8r_fork_grid, reinterpret_cast<rn_stream>(plan->side), reinterpret_cast<rn_stream>(plan->side2), plan->ev_wg);
+      if (!e && hipEventRecord(plan->ev_red[p], plan->side2) != hipSuccess) { rn_set_error("rn_plan_run: event record failed"); e = 2; }
+      plan->red_rec[p] = true;
+      plan->side2_pending = true;
+    } else {
+      if (int e2 = fold_side2(plan)) return e2;
+      e = rn_conv_wgrad8r_batch(w8q.d, w8q.n, plan->dtype, w8r_fork_grid, reinterpret_cast<rn_stream>(plan->side));
+    }
     w8q.n = 0;
     return e;
   };
@@ -559,6 +607,7 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
         rn_set_error("rn_plan_run: fork onto the side stream failed at op %d", i);
         return 2;
       }
+      if (int e2 = fold_side2(plan)) return e2;             // (it may use the side workspace from its base: the pending slab sums read it)
       s = reinterpret_cast<rn_stream>(plan->side);
       plan->side_pending = true;
     }

@@ -79,8 +79,8 @@ class Engine:
                 self.tensors[i] = self.flat_grad[o:o + s.numel].view(s.shape if s.shape else ())
             elif s.role == 'u8':
                 self.tensors[i] = torch.zeros(s.shape, dtype=torch.uint8, device=device)
-            elif s.role == 'ws':
-                self.tensors[i] = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=device)
+            elif s.role == 'ws':                    # (the side stream's workspace holds two regions: plan.cpp alternates them, the slab sums run on a stream of their own)
+                self.tensors[i] = torch.empty(max(ws_bytes, 16) * (2 if s.name == 'workspace_side' else 1), dtype=torch.uint8, device=device)
             else:
                 dt = self.T if s.dtype == 'T' else _TORCH_DT[s.dtype]
                 self.tensors[i] = torch.zeros(s.shape if s.shape else (), dtype=dt, device=device)
@@ -99,7 +99,7 @@ class Engine:
         _lib.check(self.L.rn_plan_create(ops, len(plan.ops), len(plan.slots), self.rn_dtype, C.byref(self._h)))
         for i, sl in enumerate(plan.slots):
             if sl.role == 'ws':                     # the main-stream workspace and the side stream's own
-                _lib.check(self.L.rn_plan_set_bytes(self._h, i, max(ws_bytes, 16)))
+                _lib.check(self.L.rn_plan_set_bytes(self._h, i, max(ws_bytes, 16) * (2 if sl.name == 'workspace_side' else 1)))
             elif sl.role == 'fold':                 # hand-off buffer of a split finalize (zeroed above): the launch checks its size
                 _lib.check(self.L.rn_plan_set_bytes(self._h, i, int(sl.shape[0]) * 4))
         # ---- deferred weight-gradient slab sums: on thin networks every weight gradient is a ~10 us kernel followed by a ~5 us launch that
