@@ -430,9 +430,15 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
   RN_CHECK_ARG(plan != nullptr, "rn_plan_run: null plan");
   RN_CHECK_ARG(first >= 0 && last <= (int)plan->ops.size() && first <= last, "rn_plan_run: bad range [%d, %d)", first, last);
   // a range that forks weight gradients onto the side stream: the chain's BatchNorm-backward kernels take the forms that fit beside them on a CU
+  // -- where those are the 12-wave kernels of the 160-channel family (three waves of 136 registers per SIMD leave room for a fourth); the eight-phase kernels of
+  // the 256-channel family hold every register of a CU, nothing fits beside them and the narrow BatchNorm forms only lose bandwidth (WRN-50-2-B: 52.9-53.1 vs 52.4-52.5 ms)
   bool forks = false;
   if (plan->overlap && !plan->profile)
-    for (int i = first; i < last && !forks; ++i) forks = (plan->ops[i].flags & RN_F_FORK) != 0;
+    for (int i = first; i < last && !forks; ++i)
+      if ((plan->ops[i].flags & RN_F_FORK) && plan->ops[i].kind == RN_OP_CONV_WGRAD) {
+        const rn_conv_geom g = geom_of(plan->ops[i]);
+        forks = rn_conv_wgrad8r_ok(&g, plan->dtype) != 0;
+      }
   struct SideFriendly { bool on; explicit SideFriendly(bool f) : on(f) { if (on) rn_bn_side_friendly(1); } ~SideFriendly() { if (on) rn_bn_side_friendly(0); } } side_friendly(forks);
   rn_reduce_desc pending[RN_REDUCE_BATCH_MAX];
   int pending_slot[RN_REDUCE_BATCH_MAX];                  // the dw buffer of each pending sum: an op that touches one forces the flush first
