@@ -110,7 +110,7 @@ typedef struct rn_plan rn_plan;
 const char* rn_last_error(void);
 /* ABI version: bumped with EVERY change of an entry point's signature or meaning; a binding refuses a library of another version (a stale
  * librn_hip.so would otherwise take shifted pointer / integer arguments).  3: round 3 (operand-set flags of rn_conv_kernel_names, workspaces).
- * 9: round 4 (rn_set_variant2).  10: rn_conv_wgrad8r_best_batch.  11: rn_bn_side_friendly, rn_conv_wgrad8r_batch2. */
+ * 9: round 4 (rn_set_variant2).  10: rn_conv_wgrad8r_best_batch.  11: rn_bn_side_friendly, rn_conv_wgrad8r_batch2, rn_wgrad_desc.splits / slab_bytes. */
 #define RN_ABI_VERSION 11
 int rn_version(void);
 /* kernel-variant switch for A/B measurements (tools/conv_bench.py; bits documented in csrc/conv_igemm.hip); 0 = shipped */
@@ -262,6 +262,9 @@ typedef struct rn_wgrad_desc {
   float* slabs;
   rn_conv_geom g;
   int32_t flags;
+  int32_t splits;       /* the split count the slab region was sized for (rn_conv_wgrad_splits when the plan was built): the launch refuses another one --
+                         * rn_set_variant between planning and running would otherwise write past the region or sum the wrong number of slabs; 0 = unchecked */
+  uint64_t slab_bytes;  /* bytes of the region at `slabs` (0 = unchecked) */
 } rn_wgrad_desc;
 int rn_conv_wgrad_batch_key(const rn_conv_geom* g, int dtype, int flags);
 int rn_conv_wgrad_batch(const rn_wgrad_desc* descs, int n, int dtype, rn_stream s);

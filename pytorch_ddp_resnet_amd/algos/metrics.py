@@ -50,7 +50,12 @@ class PendingMeans:
     def result(self):
         if self._event is not None:
             self._event.synchronize()
-        return Counter(dict(zip(self.keys, self._host.tolist())))
+        vals = self._host.tolist()
+        # the fused loss turns a label outside [0, classes) into a NaN loss (torch's cross_entropy device-asserts there); under the fp16 GradScaler a NaN is
+        # just a skipped step and a halved scale, so a corrupted label stream would degrade training silently -- make it loud where the value reaches the host
+        if 'loss' in self.keys and vals[self.keys.index('loss')] != vals[self.keys.index('loss')]:
+            raise FloatingPointError('loss is NaN: a label outside [0, num_classes) (the fused loss marks those rows NaN) or a diverged forward')
+        return Counter(dict(zip(self.keys, vals)))
 
 
 def global_means_async(metrics, world_size):

@@ -33,6 +33,11 @@
 
 static void* g_sk_ws = nullptr;
 static size_t g_sk_ws_bytes = 0;
+static int g_sk_ws_dev = -1;                              // the device the workspace lives on: launches on another device run without it (whole tiles)
+static bool sk_ws_here() {
+  int dev = -1;
+  return g_sk_ws && hipGetDevice(&dev) == hipSuccess && dev == g_sk_ws_dev;
+}
 
 namespace {
 
@@ -779,10 +784,11 @@ template <typename T, int BN> int launch8(IgemmArgs& a, hipStream_t s) {
   int grid = ntiles < SK_GRID ? ntiles : SK_GRID;
   a.w8_dp_tiles = ntiles;
   a.w8_drain = (g_rn_variant & (1 << 26)) ? 1 : 0;
-  a.w8_ws = g_sk_ws;
+  const bool ws_here = sk_ws_here();
+  a.w8_ws = ws_here ? g_sk_ws : nullptr;
   const int rem = ntiles % SK_GRID, full = ntiles / SK_GRID;
   const bool sk_forced = (g_rn_variant & (1u << 31)) != 0;
-  if (rem != 0 && g_sk_ws && g_sk_ws_bytes >= SK_CNT_BYTES + 2 * SK_GRID * SK_SLOT_BYTES && !(g_rn_variant & (1 << 28)) && (sk_forced || 2 * ntiles <= SK_GRID)) {
+  if (rem != 0 && ws_here && g_sk_ws_bytes >= SK_CNT_BYTES + 2 * SK_GRID * SK_SLOT_BYTES && !(g_rn_variant & (1 << 28)) && (sk_forced || 2 * ntiles <= SK_GRID)) {
     const int sk_tiles = full >= 1 ? SK_GRID + rem : rem;
     const long units = (long)sk_tiles * a.nk;
     if (units >= 4L * SK_GRID && units * SK_GRID < (1L << 31) && sk_tiles <= (int)(SK_CNT_BYTES / 4)) {
@@ -815,13 +821,19 @@ extern "C" size_t rn_conv_workspace_bytes(void) { return SK_CNT_BYTES + 2 * SK_G
 // data gradient on its launch stream).  NULL (the default): no stream-K, whole tiles only.
 extern "C" int rn_set_conv_workspace(void* p, size_t bytes) {
   g_sk_ws = p; g_sk_ws_bytes = p ? bytes : 0;
+  g_sk_ws_dev = -1;
+  if (p) {                                               // (one process-wide pointer -- at least never hand it to a launch on another device)
+    hipPointerAttribute_t at;
+    if (hipPointerGetAttributes(&at, p) == hipSuccess) g_sk_ws_dev = at.device;
+    else { (void)hipGetLastError(); (void)hipGetDevice(&g_sk_ws_dev); }
+  }
   return 0;
 }
 // the same workspace for the split reductions of conv_igemm8r.hip (tickets in the first 4 KiB, one slot of SK_SLOT_BYTES per work item): NULL when it is
 // not set or smaller than rn_conv_workspace_bytes()
 void* rn_sk_workspace(size_t* slot_bytes) {
   if (slot_bytes) *slot_bytes = SK_SLOT_BYTES;
-  return (g_sk_ws && g_sk_ws_bytes >= SK_CNT_BYTES + 2 * SK_GRID * SK_SLOT_BYTES) ? g_sk_ws : nullptr;
+  return (sk_ws_here() && g_sk_ws_bytes >= SK_CNT_BYTES + 2 * SK_GRID * SK_SLOT_BYTES) ? g_sk_ws : nullptr;
 }
 
 // geometry the eight-phase kernel covers: 16-bit elements, channel count a multiple of 64 (a K tile never straddles a tap), output channels a

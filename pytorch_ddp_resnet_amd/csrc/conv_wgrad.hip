@@ -708,6 +708,10 @@ extern "C" int rn_conv_wgrad_batch(const rn_wgrad_desc* descs, int n, int dtype,
     WgradSel sel;
     WgradArgs a{};
     wgrad_fill(a, sel, d.x, d.dy, &d.g, dtype, d.flags);
+    RN_CHECK_ARG(d.splits == 0 || d.splits == a.splits, "rn_conv_wgrad_batch: record %d was planned with %d pixel splits, the launch would take %d (rn_set_variant changed in between?)", i,
+                 d.splits, a.splits);
+    RN_CHECK_ARG(d.slab_bytes == 0 || d.slab_bytes >= (uint64_t)a.splits * d.g.K * d.g.R * d.g.S * d.g.C * sizeof(float), "rn_conv_wgrad_batch: record %d: slab region of %llu bytes is too small for %d splits", i,
+                 (unsigned long long)d.slab_bytes, a.splits);
     WgradArgsS& o = wb.a[i];
     o.x = a.x; o.dy = a.dy; o.out = d.slabs;
     o.N = a.N; o.H = a.H; o.W = a.W; o.C = a.C; o.P = a.P; o.Q = a.Q; o.K = a.K;

@@ -525,7 +525,7 @@ extern "C" int rn_plan_run(rn_plan* plan, int first, int last, uint64_t step_see
         if (!e) {
           q->key = key;
           q->xs[q->n] = o.buf[0]; q->dys[q->n] = o.buf[1];
-          q->d[q->n++] = rn_wgrad_desc{P(0), P(1), reinterpret_cast<float*>(slabs), g, o.flags};
+          q->d[q->n++] = rn_wgrad_desc{P(0), P(1), reinterpret_cast<float*>(slabs), g, o.flags, plan->slab_splits[i], (uint64_t)plan->slab_splits[i] * nel * sizeof(float)};
           if (q->n == RN_WGRAD_BATCH_MAX) e = launch_queue(*q);
         }
       } else {

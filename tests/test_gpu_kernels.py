@@ -488,7 +488,7 @@ def test_batched_weight_gradient_launch_writes_the_same_slabs(dt):
     vp, i32 = C.c_void_p, C.c_int32
 
     class WDesc(C.Structure):
-        _fields_ = [('x', vp), ('dy', vp), ('slabs', vp), ('g', _lib.RnConvGeom), ('flags', i32)]
+        _fields_ = [('x', vp), ('dy', vp), ('slabs', vp), ('g', _lib.RnConvGeom), ('flags', i32), ('splits', i32), ('slab_bytes', C.c_uint64)]
     L.rn_conv_wgrad.argtypes = [vp, vp, vp, vp, C.c_size_t, i32, i32, C.POINTER(_lib.RnConvGeom), vp]
     L.rn_conv_wgrad_splits.argtypes = [C.POINTER(_lib.RnConvGeom), i32, i32]
     L.rn_conv_wgrad_batch_key.argtypes = [C.POINTER(_lib.RnConvGeom), i32, i32]
@@ -513,7 +513,7 @@ def test_batched_weight_gradient_launch_writes_the_same_slabs(dt):
         ws0, ws1 = torch.full((splits * n,), 7.0, device='cuda'), torch.full((splits * n,), -7.0, device='cuda')
         dw = torch.zeros(n, device='cuda')
         _lib.check(L.rn_conv_wgrad(vp(x.data_ptr()), vp(dy.data_ptr()), vp(dw.data_ptr()), vp(ws0.data_ptr()), ws0.numel() * 4, ir.F_DEFER_REDUCE, dt, C.byref(g), st))
-        descs[j] = WDesc(x.data_ptr(), dy.data_ptr(), ws1.data_ptr(), g, 0)
+        descs[j] = WDesc(x.data_ptr(), dy.data_ptr(), ws1.data_ptr(), g, 0, splits, ws1.numel() * 4)
         keep += [x, dy, dw]
         want.append(ws0); got.append(ws1)
     nmax = 16
@@ -526,8 +526,12 @@ def test_batched_weight_gradient_launch_writes_the_same_slabs(dt):
     # a record of another tile shape in the same launch is an argument error, not a wrong gradient
     g_big = _lib.RnConvGeom(32, 16, 16, 64, 16, 16, 64, 3, 3, 1, 1)
     assert int(L.rn_conv_wgrad_batch_key(C.byref(g_big), dt, 0)) not in (0, key0)
-    bad = (WDesc * 2)(descs[0], WDesc(descs[0].x, descs[0].dy, descs[0].slabs, g_big, 0))
+    bad = (WDesc * 2)(descs[0], WDesc(descs[0].x, descs[0].dy, descs[0].slabs, g_big, 0, 0, 0))
     assert L.rn_conv_wgrad_batch(bad, 2, dt, st) != 0
+    # a record planned with another split count, or a region too small for the launch's splits, is refused (the region would be overrun / mis-summed)
+    d0 = descs[0]
+    assert L.rn_conv_wgrad_batch((WDesc * 1)(WDesc(d0.x, d0.dy, d0.slabs, d0.g, 0, d0.splits + 1, d0.slab_bytes)), 1, dt, st) != 0
+    assert L.rn_conv_wgrad_batch((WDesc * 1)(WDesc(d0.x, d0.dy, d0.slabs, d0.g, 0, d0.splits, d0.slab_bytes - 4)), 1, dt, st) != 0
     # forked launches and the stem's im2col form stay single launches
     assert int(L.rn_conv_wgrad_batch_key(C.byref(descs[0].g), dt, ir.F_FORK)) == 0
     g_stem = _lib.RnConvGeom(32, 32, 32, 4 if dt == 0 else 8, 32, 32, 16, 3, 3, 1, 1)
