@@ -7,6 +7,7 @@
 // of one pixel row, so a wave reads/writes whole 1 KiB rows-of-rows; statistics are wave/LDS-reduced per workgroup
 // into [nblk][2][C] partial sums and combined in double by the finalize kernels (no float atomics: bitwise stable).
 #include "common.h"
+#include <string.h>
 
 namespace {
 
@@ -55,12 +56,13 @@ __global__ __launch_bounds__(NT) void bn_reduce_kernel(const T* __restrict__ x, 
           Chunk<T> cd = load_chunk<T>(dout + off);
           Chunk<T> cm;
           if (use_mask == 1) cm = load_chunk<T>(mask + off);
+          const uint32_t kp = (use_mask == 2 && thr) ? rn_keep_chunk<CE>(key, (uint32_t)off, thr) : 0xFFFFFFFFu;
 #pragma unroll
           for (int e = 0; e < CE; ++e) {
             float g = Elem<T>::to_f(cd.e[e]) * gscale;
             const float xv = Elem<T>::to_f(cx.e[e]);
             if (use_mask == 1 && !(Elem<T>::to_f(cm.e[e]) > 0.f)) g = 0.f;
-            if (use_mask == 2 && (!(fmaf(xv, sc[e], sh[e]) > 0.f) || (thr && !rn_keep(key, (uint32_t)(off + e), thr)))) g = 0.f;
+            if (use_mask == 2 && (!(fmaf(xv, sc[e], sh[e]) > 0.f) || !((kp >> e) & 1u))) g = 0.f;
             float xh = (xv - mean[e]) * invstd[e];
             s0[e] += g; s1[e] += g * xh;
           }
@@ -362,8 +364,9 @@ __global__ __launch_bounds__(NT) void bn_apply_kernel(const T* __restrict__ x, c
         for (int e = 0; e < CE; ++e) v[e] = fmaxf(v[e], 0.f);
       }
       if (thr) {
+        const uint32_t kp = rn_keep_chunk<CE>(key, (uint32_t)off, thr);
 #pragma unroll
-        for (int e = 0; e < CE; ++e) v[e] = rn_keep(key, (uint32_t)(off + e), thr) ? v[e] * inv_keep : 0.f;
+        for (int e = 0; e < CE; ++e) v[e] = ((kp >> e) & 1u) ? v[e] * inv_keep : 0.f;
       }
       Chunk<T> co;
 #pragma unroll
@@ -433,12 +436,13 @@ __global__ __launch_bounds__(NT) void bn_bwd_apply_stream_kernel(const T* __rest
     const int hw = H * W;
     auto one = [&](size_t off, int r, const Chunk<T>& cd, const Chunk<T>& cx, const Chunk<T>& cm, const Chunk<T>& cr) {
       float v[CE], g[CE];
+      const uint32_t kp = (MASK == 2 && thr) ? rn_keep_chunk<CE>(key, (uint32_t)off, thr) : 0xFFFFFFFFu;
 #pragma unroll
       for (int e = 0; e < CE; ++e) {
         float gg = Elem<T>::to_f(cd.e[e]);
         const float xv = Elem<T>::to_f(cx.e[e]);
         if (MASK == 1 && !(Elem<T>::to_f(cm.e[e]) > 0.f)) gg = 0.f;
-        if (MASK == 2 && (!(fmaf(xv, sc[e], sh[e]) > 0.f) || (thr && !rn_keep(key, (uint32_t)(off + e), thr)))) gg = 0.f;
+        if (MASK == 2 && (!(fmaf(xv, sc[e], sh[e]) > 0.f) || !((kp >> e) & 1u))) gg = 0.f;
         g[e] = __fmul_rn(gg, gscale);
         v[e] = __fmaf_rn(ka[e], gg, __fmaf_rn(kb[e], xv, kc[e]));
       }
@@ -654,6 +658,7 @@ extern "C" int rn_bn_apply(const void* x, const float* coef, const void* res, vo
   const int relu = (flags & RN_F_RELU) ? 1 : 0;
   RN_CHECK_ARG(M < (1L << 31), "rn_bn_apply: too many pixels");
   (void)nchunks;
+  // (measured, round 4: 10 rows per thread = one round of 1,092 workgroups instead of 4 rows = 1.33 rounds of 2,731: 0.343 vs 0.322 ms per step -- the short form stays)
   const int rows = slab_rows(M, C, ce);
   const int grid = cdiv(M, rows);
   RN_BY_DTYPE(dtype, hipLaunchKernelGGL((bn_apply_kernel<T_>), dim3(grid), dim3(NT), 0, as_stream(s), (const T_*)x, coef, r, (T_*)out, (int)M, H, W, C, rows, relu, inv_keep, key, thr));

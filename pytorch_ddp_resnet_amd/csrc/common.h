@@ -103,7 +103,27 @@ __host__ __device__ inline uint32_t rn_drop_threshold(float p) {
   double t = (double)p * 4294967296.0;
   return t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
 }
-__device__ inline bool rn_keep(uint32_t key, uint32_t idx, uint32_t thr) { return rn_lowbias32(idx ^ key) >= thr; }
+// keep element idx iff its 16-bit half of the hash of the element PAIR idx >> 1 is >= the threshold's upper 16 bits: one hash per two elements (the mask of a
+// chunk of 8 costs 4 hashes; per element the hash was ~40 % of bn_apply's issue slots on a dropout network).  p is quantised to 2^-16.
+// tests/np_interp.py:keep_mask is the specification the kernels are tested against.
+__device__ inline bool rn_keep(uint32_t key, uint32_t idx, uint32_t thr) {
+  const uint32_t h = rn_lowbias32((idx >> 1) ^ key);
+  return ((idx & 1u) ? (h >> 16) : (h & 0xFFFFu)) >= (thr >> 16);
+}
+// the keep bits of CE consecutive elements from an EVEN index base (a 16-byte chunk: base is a multiple of CE): bit e = element base + e
+template <int CE>
+__device__ inline uint32_t rn_keep_chunk(uint32_t key, uint32_t base, uint32_t thr) {
+  static_assert(CE % 2 == 0, "pairs");
+  const uint32_t t16 = thr >> 16;
+  uint32_t bits = 0;
+#pragma unroll
+  for (int q = 0; q < CE / 2; ++q) {
+    const uint32_t h = rn_lowbias32(((base >> 1) + (uint32_t)q) ^ key);
+    bits |= ((h & 0xFFFFu) >= t16 ? 1u : 0u) << (2 * q);
+    bits |= ((h >> 16) >= t16 ? 1u : 0u) << (2 * q + 1);
+  }
+  return bits;
+}
 
 // ---- residual / merge operand (RN_RES_*): value seen at destination (n,h,w,c) of a [N,H,W,C] tensor ----
 struct ResDesc {

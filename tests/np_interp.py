@@ -22,11 +22,14 @@ def lowbias32(x):
 
 
 def keep_mask(n, p, site, step_seed):
-    """must match csrc/common.h: rn_keep().  keep iff hash >= p * 2^32."""
+    """must match csrc/common.h: rn_keep().  One 32-bit hash per PAIR of elements; element idx keeps iff its 16-bit half (low half: even idx, high half: odd idx)
+    >= floor(p * 2^32) >> 16."""
     key = lowbias32((site * 0x9E3779B9) ^ (step_seed & 0xFFFFFFFF) ^ ((step_seed >> 32) * 0x85EBCA6B))
-    h = lowbias32(np.arange(n, dtype=np.uint64) ^ key)
-    thr = np.uint64(min(int(p * 4294967296.0), 0xFFFFFFFF))
-    return h >= thr
+    idx = np.arange(n, dtype=np.uint64)
+    h = lowbias32((idx >> np.uint64(1)) ^ key)
+    half = np.where((idx & np.uint64(1)) == 1, h >> np.uint64(16), h & np.uint64(0xFFFF))
+    thr = np.uint64(min(int(p * 4294967296.0), 0xFFFFFFFF)) >> np.uint64(16)
+    return half >= thr
 
 
 def pool_winner(x, arg, k, stride, pad):
