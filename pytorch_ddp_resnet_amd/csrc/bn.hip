@@ -564,7 +564,7 @@ inline int slab_rows_stream(long M, int C, int ce) {
 template <typename T, int MASK, int ADD>
 void launch_bwd_apply_stream(int grid, hipStream_t st, const void* dout, const void* x, const void* mask, const float* coef, const float* dsum, const ResDesc& r,
                              void* dx, void* g, int M, int H, int W, int C, int rows, int train, float gscale, float inv_count, uint32_t key, uint32_t thr) {
-  if constexpr (sizeof(T) == 2 && MASK != 2) {
+  if constexpr (sizeof(T) == 2) {
     if (bn_light()) {       // two rows of loads in flight instead of four: <= 104 registers, a wave per SIMD fits beside a forked weight gradient's three
       hipLaunchKernelGGL((bn_bwd_apply_stream_kernel<T, MASK, ADD, 2>), dim3(grid), dim3(NT), 0, st, (const T*)dout, (const T*)x, (const T*)mask, coef, dsum, r, (T*)dx, (T*)g,
                          M, H, W, C, rows, train, gscale, inv_count, key, thr);

@@ -86,7 +86,9 @@ constexpr int XB = 9216, YB = 20480, STG = XB + YB;          // bytes of a stage
 // every wave's reads of K tile kt are retired in front of it, so its stage may be re-staged -- as K tile kt + 3 -- from the next K tile on (WAR).
 // Measured in one process (tools/conv_bench.py wgrad, batch 128): first form 88.1 / 80.6 / 80.2 us on the 160 / 320 / 640-channel layers; pieces moved into
 // the MFMA segment, barriers kept 81.0 / 74.6 / 73.8; this form 75.0 / 70.5 / 72.5 (round-3 kernel: 88.3 / 79.4 / 84.5).  A second register set that holds
-// both k-steps' fragments from the head of the K tile (162 registers) lost 3-5 % against it; removed.
+// both k-steps' fragments from the head of the K tile (162 registers) lost 3-5 % against it; removed.  TWO K tiles per barrier on a ring of four stages: 77.1 / 70.1 / 69.3 us
+// against 79.3 / 72.8 / 71.3 alone (+3 %) -- but hipcc keeps 156 registers for it, and the step went 6.06 -> 6.48 ms: at most 136 registers per wave is what lets the
+// chain's BatchNorm-backward kernels run BESIDE this kernel (tests/test_abi.py holds the budget); removed.
 template <typename T, int PROBE = 0, int SCHED = 2>
 __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
   constexpr int ES = 2;
@@ -304,8 +306,8 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
     bar9();
     if (SCHED == 0 && wave >= 4) bar9();                     // waves 4-11 run one barrier behind waves 0-3
 
-    int s_cur = 0, s_nxt = STG, s_free = 2 * STG;            // stage of K tile kt, of kt + 1, and the one kt + 2 goes into (kt - 1's)
     const int nseg_k = kend - kb;
+    int s_cur = 0, s_nxt = STG, s_free = 2 * STG;            // stage of K tile kt, of kt + 1, and the one kt + 2 goes into (kt - 1's)
     for (int kt = 0; kt < nseg_k; ++kt) {
       phase(K0{}, s_cur, 0, 0u);
       phase(K1{}, s_cur, kb + kt + 2, lds0 + (unsigned)s_free);

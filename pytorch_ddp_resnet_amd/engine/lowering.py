@@ -317,6 +317,7 @@ class Lowering:
             assert abs(p_fwd - p) < 1e-12
             fl |= ir.F_MASK_RECOMPUTE
             mslot = -1
+        apply_fl, apply_mslot, apply_site = fl, mslot, site
         if dout.s in self._dpart_of:                       # the two sums were reduced by the dgrad that produced dout
             part, nblk = self._dpart_of[dout.s]
         else:
@@ -335,10 +336,10 @@ class Lowering:
         dx = self.act(dx_name, x.N, x.H, x.W, C)
         g = self.act(write_g_name, x.N, x.H, x.W, C) if write_g_name else None
         ops.append(Op(ir.OP_BN_BWD_APPLY,
-                      buf=dict(dout=dout.s, x=x.s, mask=mslot, coef=coef, dsum=dsum,
+                      buf=dict(dout=dout.s, x=x.s, mask=apply_mslot, coef=coef, dsum=dsum,
                                add=add.s if add else -1, dx=dx.s, g_out=g.s if g else -1),
                       dim=dict(N=x.N, H=x.H, W=x.W, C=C, add_mode=add_mode, add_C=add.C if add else 0, count=count),
-                      fp=dict(gscale=gscale, p=p if mslot < 0 else 0.0), flags=fl | (ir.F_WRITE_G if g else 0), seed=site, note=pre))
+                      fp=dict(gscale=gscale, p=p if apply_mslot < 0 else 0.0), flags=apply_fl | (ir.F_WRITE_G if g else 0), seed=apply_site, note=pre))
         return dx, g
 
     # ---- residual blocks --------------------------------------------------------------------------------

@@ -169,6 +169,22 @@ def test_hot_kernels_keep_their_occupancy():
             assert k['Occupancy'] >= 2 and k['VGPRs'] <= 256 and k['ScratchSize'] == 0, (ep, k)
         k = find(f'wgrad8_kernelI{dt}E')
         assert k['Occupancy'] >= 2 and k['VGPRs'] <= 256 and k['LDS Size'] <= LDS_CU and k['ScratchSize'] == 0, k
+        # round 4, the row-patch kernel of the 160-channel family: every operand set spill-free at two waves per SIMD (whole-tile and split forms)
+        for ep in (0, 1, 4, 5, 6):
+            for split in (0, 1):
+                k = find(f'igemm8r_kernelI{dt}Li{ep}ELi0ELi{split}ELi1E')
+                assert k['Occupancy'] >= 2 and k['VGPRs'] <= 256 and k['LDS Size'] <= LDS_CU and k['ScratchSize'] == 0, (ep, split, k)
+        # ... and its weight gradient: three waves per SIMD of AT MOST 136 registers, so that a fourth wave of <= 104 fits on every SIMD -- the chain's
+        # BatchNorm-backward kernels run BESIDE the forked weight gradients (a 156-register form of this kernel was 3 % faster alone
+        # and made the step 7 % slower); the co-runners' side of the budget follows
+        k = find(f'wgrad9_kernelI{dt}Li0ELi2E')
+        assert k['Occupancy'] >= 3 and k['VGPRs'] <= 136 and k['LDS Size'] + 18 * 1024 <= LDS_CU and k['ScratchSize'] == 0, k
+        for name in (f'bn_bwd_apply_stream_kernelI{dt}Li0ELi0ELi2E', f'bn_bwd_apply_stream_kernelI{dt}Li1ELi0ELi2E', f'bn_bwd_apply_stream_kernelI{dt}Li1ELi1ELi2E',
+                     f'bn_bwd_apply_stream_kernelI{dt}Li1ELi2ELi2E', f'bn_reduce_kernelI{dt}Li1ELi2ELi1E'):
+            k = find(name)
+            assert k['VGPRs'] <= 104 and k['ScratchSize'] == 0, (name, k)
+    k = find('bn_bwd_finalize_kernelILi16E')
+    assert k['VGPRs'] <= 104 and k['ScratchSize'] == 0, k
     spilling = ('igemm8_kernel',)          # its bnb+res / bnb+acc / general epilogues spill a few registers (known): checked above per mode
     # two fp16 forms of the fused BatchNorm + MaxPool passes trade two spilled dwords for a wave per SIMD (misc.hip PoolWaves: measured 2.16 -> 1.99 ms and
     # 1.98 -> 1.75 ms on WRN-50-2-B's stem map): the exception holds only while the occupancy it buys is there
