@@ -71,12 +71,14 @@ __device__ inline void wait_vm9(int n) {                     // wave-uniform cou
     case 1: wait_vmcnt<1>(); break;
     case 2: wait_vmcnt<2>(); break;
     case 3: wait_vmcnt<3>(); break;
+    case 4: wait_vmcnt<4>(); break;
     case 17: wait_vmcnt<17>(); break;
-    default: wait_vmcnt<18>(); break;
+    case 18: wait_vmcnt<18>(); break;
+    default: wait_vmcnt<19>(); break;
   }
 }
 
-constexpr int XB = 9216, YB = 20480, STG = XB + YB;          // bytes of a stage: patch (up to 136 pixel rows of 64 B, padded to 9 DMA pieces) | dy
+constexpr int YB = 20480;         // bytes of a stage's dy tile; the patch region in front of it: 9 KiB (stride 1: up to 136 pixel rows of 64 B), 20 KiB (stride 2: 306)
 
 // PROBE (diagnostic instantiations, rn_set_variant2 bits 8-10; wrong results, timing only): 1 = no LDS-DMA in the K loop, 2 = no MFMA, 3 = no fragment reads
 // SCHED 2 (shipped; rn_set_variant2 8192 selects 0, the first form, for A/B): ONE barrier per K tile and no wave groups.  A wave reads a k-step's fragments,
@@ -89,9 +91,14 @@ constexpr int XB = 9216, YB = 20480, STG = XB + YB;          // bytes of a stage
 // both k-steps' fragments from the head of the K tile (162 registers) lost 3-5 % against it; removed.  TWO K tiles per barrier on a ring of four stages: 77.1 / 70.1 / 69.3 us
 // against 79.3 / 72.8 / 71.3 alone (+3 %) -- but hipcc keeps 156 registers for it, and the step went 6.06 -> 6.48 ms: at most 136 registers per wave is what lets the
 // chain's BatchNorm-backward kernels run BESIDE this kernel (tests/test_abi.py holds the budget); removed.
-template <typename T, int PROBE = 0, int SCHED = 2>
+// STR 2 (round 4, second session): the family's stride-2 3x3 layers (padding 1, output map = input map / 2).  The patch of a K tile is then the 2 rows + 1 input rows
+// its output rows read, ALL columns (306 pixel rows for 16- and 8-wide output maps: 20 DMA pieces, a stage = 20 + 20 KiB), and a k index reads patch row
+// (2 r + 1 + dh)(W + 2) + 2 q + 1 + dw; everything else is the stride-1 kernel.
+template <typename T, int PROBE = 0, int SCHED = 2, int STR = 1>
 __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
   constexpr int ES = 2;
+  constexpr int XB = STR == 2 ? 20480 : 9216, STG = XB + YB;          // (shadow the stride-1 constants of the namespace)
+  constexpr int NS = STR == 2 ? 4 : 3;                                 // DMA pieces per wave and K tile, at most
   __shared__ uint4 smem[3 * STG / 16];
   const char* lds = reinterpret_cast<const char*>(&smem[0]);
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);
@@ -104,19 +111,20 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
 
   // every layer of a launch has ONE geometry (launcher): the lane roles are computed once
   const W9Rec& R0 = b.r[0];
-  const int W = R0.W, H = R0.H, lw = R0.lw, RW = R0.rows, W2 = W + 2;
-  const int NPR = (RW + 2) * W2;                             // pixel rows of the patch
+  const int W = R0.W, H = R0.H, lw = R0.lw, RW = R0.rows, W2 = W + 2;      // W, H: the INPUT map; lw = log2 of the OUTPUT map's width; RW = output rows per K tile
+  const int WQ = W / STR;                                    // output map width
+  const int NPR = (STR * RW + 3 - STR) * W2;                 // pixel rows of the patch: RW + 2 input rows (stride 1), 2 RW + 1 (stride 2)
   const int NXI = (NPR * 4 + 63) >> 6;                       // DMA pieces of the patch; the dy tile has 20
   const int NDI = NXI + 20;
   const unsigned cb = (unsigned)(R0.C * ES), kb_ = (unsigned)(R0.K * ES);
 
   // ---- DMA roles: this wave's pieces are list entries wave, wave + 12, wave + 24 of [patch pieces | dy pieces] ----
-  const int nw = (NDI - wave + 11) / 12;                     // 2 or 3
-  int dkind[3];                                              // 0 patch, 1 dy, -1 none
-  int dconst[3], dir[3];                                     // lane constant of the source offset; patch: the lane's patch row (vertical range check), -1 = never valid
-  unsigned ddst[3];                                          // LDS byte offset of the piece inside a stage
+  const int nw = (NDI - wave + 11) / 12;                     // 2 or 3 (stride 2: 3 or 4)
+  int dkind[NS];                                             // 0 patch, 1 dy, -1 none
+  int dconst[NS], dir[NS];                                   // lane constant of the source offset; patch: the lane's patch row (vertical range check), -1 = never valid
+  unsigned ddst[NS];                                         // LDS byte offset of the piece inside a stage
 #pragma unroll
-  for (int s = 0; s < 3; ++s) {
+  for (int s = 0; s < NS; ++s) {
     const int e = wave + 12 * s;
     dkind[s] = e < NXI ? 0 : (e < NDI ? 1 : -1);
     dconst[s] = 0; dir[s] = -1; ddst[s] = 0;
@@ -150,7 +158,7 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int idx = 32 * ks + 8 * lq + tq + 4 * u;
-        const int prow = ((idx >> lw) + 1 + dh) * W2 + (idx & (W - 1)) + 1 + dw;
+        const int prow = (STR * (idx >> lw) + 1 + dh) * W2 + STR * (idx & (WQ - 1)) + 1 + dw;
         xa[i][ks][u] = prow * 64 + 32 * (hf ^ ((prow >> 3) & 1)) + 16 * (tp >> 1) + 8 * (tp & 1);
       }
   }
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
     if (dkind[s] == 0) {
       int n = (int)__umulhi((unsigned)g, imagic);            // K tile -> image n, first row p0 = (g - n * inb) * rows
       if (g - n * inb >= inb) ++n;
-      const int p0 = (g - n * inb) * RW;
+      const int p0 = STR * (g - n * inb) * RW;              // first INPUT row of the K tile's output rows
       const unsigned sbase = (unsigned)((n * H + p0) * W) * cb + xo;
       const bool ok = live && dir[s] >= 0 && (unsigned)(p0 + dir[s] - 1) < (unsigned)H;
       dma16(descr(xw0, xw1, xw2), ok ? sbase + (unsigned)dconst[s] : OOB, (unsigned)__builtin_amdgcn_readfirstlane((int)(stage_lds + ddst[s])));
@@ -184,7 +192,7 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
   auto issue_tile = [&](int g, unsigned stage_lds) {
     const unsigned keep = m0_save();
 #pragma unroll
-    for (int s = 0; s < 3; ++s) issue(s, g, stage_lds);
+    for (int s = 0; s < NS; ++s) issue(s, g, stage_lds);
     m0_restore(keep);
   };
 
@@ -268,7 +276,7 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
       kb = split * R.per; kend = min(R.nk, kb + R.per);
       const int ct = tile % R.nct, kt_ = tile / R.nct;
       xo = (unsigned)(ct * 32 * ES); yo = (unsigned)(kt_ * 160 * ES);
-      inb = R.H / R.rows; imagic = R.magic_h;
+      inb = (R.H / STR) / R.rows; imagic = R.magic_h;
       { const v4i32 d = make_desc(R.x, (size_t)R.N * R.H * R.W * R.C * ES); xw0 = d[0]; xw1 = d[1]; xw2 = d[2]; }
       { const v4i32 d = make_desc(R.dy, (size_t)R.M * R.K * ES); yw0 = d[0]; yw1 = d[1]; yw2 = d[2]; }
       // prologue: K tiles kb and kb + 1 into stages 0 and 1 (every wave has left the previous K loop)
@@ -341,12 +349,14 @@ static int w9_pick_splits(long ntiles, long nk, double n_floats, long cap = 128,
 static bool w9_geom_ok(const rn_conv_geom* g, int dtype) {
   if (dtype != RN_BF16 && dtype != RN_F16) return false;
   if (g_rn_variant2 & 16384) return false;                                     // A/B: never
-  if (g->R != 3 || g->S != 3 || g->stride != 1 || g->pad != 1 || g->P != g->H || g->Q != g->W) return false;
+  if (g->R != 3 || g->S != 3 || g->pad != 1 || (g->stride != 1 && g->stride != 2)) return false;
+  if (g->P * g->stride != g->H || g->Q * g->stride != g->W) return false;     // (stride 2: even maps, output = input / 2)
   if (g->C % 32 || g->C < 32 || g->K % 160) return false;
-  const int W = g->W;
-  if (W < 8 || W > 32 || (W & (W - 1))) return false;                          // a K tile = 64 / W whole image rows; the patch of W = 64 (3 x 66 pixel rows) would not fit XB
-  if (g->H % (64 / W)) return false;
-  if ((double)g->N * g->H * g->W * g->C * 2 >= 4.0e9 || (double)g->N * g->H * g->W * g->K * 2 >= 4.0e9) return false;      // 32-bit DMA offsets
+  const int W = g->Q;                                                          // the OUTPUT map: a K tile = 64 / Q whole output rows
+  if (W < 8 || W > (g->stride == 2 ? 16 : 32) || (W & (W - 1))) return false;  // the patch has to fit its LDS region (stride 1: 64-wide maps would not; stride 2: 32-wide outputs)
+  if (g->stride == 2 && (g_rn_variant2 & 524288)) return false;                // A/B: the stride-2 form off (the 320 x 160 kernel takes those layers)
+  if (g->P % (64 / W)) return false;
+  if ((double)g->N * g->H * g->W * g->C * 2 >= 4.0e9 || (double)g->N * g->P * g->Q * g->K * 2 >= 4.0e9) return false;      // 32-bit DMA offsets
   return true;
 }
 
@@ -355,7 +365,7 @@ static bool w9_geom_ok(const rn_conv_geom* g, int dtype) {
 // 640-channel layers (80 tiles each) fill 0.94 of one round in threes (no slabs at all), 0.62 of two rounds in fours, 0.73 of three rounds in sevens.
 int rn_wgrad9_best_batch(const rn_conv_geom* g, int dtype, int max_n) {
   if (!w9_geom_ok(g, dtype) || max_n < 1) return 1;
-  const long M = (long)g->N * g->H * g->W, nk = M / 64;
+  const long M = (long)g->N * g->P * g->Q, nk = M / 64;
   const long ntiles = (long)(g->C / 32) * (g->K / 160);
   const double nel = (double)g->K * 9 * g->C;
   int best = 1;
@@ -371,7 +381,7 @@ int rn_wgrad9_best_batch(const rn_conv_geom* g, int dtype, int max_n) {
 // 0: rn_conv_wgrad does not take this kernel for the geometry; S >= 1: it does, with S pixel splits
 int rn_wgrad9_splits(const rn_conv_geom* g, int dtype) {
   if (!w9_geom_ok(g, dtype)) return 0;
-  const long M = (long)g->N * g->H * g->W, nk = M / 64;
+  const long M = (long)g->N * g->P * g->Q, nk = M / 64;
   const long ntiles = (long)(g->C / 32) * (g->K / 160);
   if (ntiles * nk < 8L * 256 && !(g_rn_variant2 & 8)) return 0;               // too small to fill the chip (rn_set_variant2 8: any size, tests)
   return w9_pick_splits(ntiles, nk, (double)g->K * 9 * g->C);
@@ -380,19 +390,20 @@ int rn_wgrad9_splits(const rn_conv_geom* g, int dtype) {
 static void w9_fill(W9Rec& r, const void* x, const void* dy, float* out, int splits, const rn_conv_geom* g, int accumulate) {
   r.x = x; r.dy = dy; r.out = out;
   r.N = g->N; r.H = g->H; r.W = g->W; r.C = g->C; r.K = g->K;
-  r.M = g->N * g->H * g->W; r.nk = r.M / 64;
+  r.M = g->N * g->P * g->Q; r.nk = r.M / 64;
   r.nct = g->C / 32; r.nkt = g->K / 160;
   r.lw = 0;
-  while ((1 << r.lw) < g->W) ++r.lw;
+  while ((1 << r.lw) < g->Q) ++r.lw;
   r.rows = 64 >> r.lw;
-  const unsigned nb = (unsigned)(g->H / r.rows);
+  const unsigned nb = (unsigned)(g->P / r.rows);
   r.magic_h = nb <= 1 ? 0xFFFFFFFFu : (unsigned)((1ull << 32) / nb);
   r.splits = splits; r.per = (r.nk + splits - 1) / splits;
   r.slab_stride = splits > 1 ? (long)g->K * 9 * g->C : 0;
   r.accumulate = (splits == 1 && accumulate) ? 1 : 0;
 }
 
-template <typename T> static void w9_launch(const W9Batch& b, int grid, hipStream_t s) {
+template <typename T> static void w9_launch(const W9Batch& b, int grid, hipStream_t s, int stride) {
+  if (stride == 2) { hipLaunchKernelGGL((wgrad9_kernel<T, 0, 2, 2>), dim3(grid), dim3(768), 0, s, b); return; }
   if constexpr (std::is_same<T, f16_t>::value) {
     const int probe = (g_rn_variant2 >> 8) & 7;
     if (probe == 1) { hipLaunchKernelGGL((wgrad9_kernel<T, 1, 2>), dim3(grid), dim3(768), 0, s, b); return; }
@@ -413,7 +424,7 @@ int rn_launch_wgrad9(const void* x, const void* dy, float* out, int splits, int 
   if (rn_dry_run()) return 0;
   const int cap = max_grid > 0 && max_grid < 256 ? max_grid : 256;
   const int grid = b.first[1] < cap ? b.first[1] : cap;
-  if (dtype == RN_BF16) w9_launch<bf16_t>(b, grid, s); else w9_launch<f16_t>(b, grid, s);
+  if (dtype == RN_BF16) w9_launch<bf16_t>(b, grid, s, g->stride); else w9_launch<f16_t>(b, grid, s, g->stride);
   RN_CHECK_LAUNCH("wgrad9");
   return 0;
 }
@@ -425,7 +436,7 @@ int rn_wgrad_reduce_slabs(const float* ws, float* dw_krsc, long n, int splits, i
 int rn_wgrad9_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid, hipStream_t s, hipStream_t s_reduce, hipEvent_t ev) {
   static_assert(RN_WGRAD8R_BATCH_MAX == W9_MAX, "header and kernel disagree");
   const rn_conv_geom& g0 = descs[0].g;
-  const long M = (long)g0.N * g0.H * g0.W, nk = M / 64;
+  const long M = (long)g0.N * g0.P * g0.Q, nk = M / 64;
   const long ntiles = (long)(g0.C / 32) * (g0.K / 160);
   const size_t nel = (size_t)g0.K * 9 * g0.C;
   long ws_cap = 128;
@@ -462,7 +473,7 @@ int rn_wgrad9_batch(const rn_wgrad8r_desc* descs, int n, int dtype, int max_grid
   if (rn_dry_run()) return 0;
   const int cap = max_grid > 0 && max_grid < 256 ? max_grid : 256;
   const int grid = items < cap ? items : cap;
-  if (dtype == RN_BF16) w9_launch<bf16_t>(b, grid, s); else w9_launch<f16_t>(b, grid, s);
+  if (dtype == RN_BF16) w9_launch<bf16_t>(b, grid, s, g0.stride); else w9_launch<f16_t>(b, grid, s, g0.stride);
   RN_CHECK_LAUNCH("wgrad9 batch");
   if (s_reduce && ev) {
     if (hipEventRecord(ev, s) != hipSuccess || hipStreamWaitEvent(s_reduce, ev, 0) != hipSuccess) { rn_set_error("rn_conv_wgrad8r_batch: event record / wait failed"); return 2; }

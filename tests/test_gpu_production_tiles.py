@@ -783,7 +783,7 @@ def test_wgrad8r_exact_integers():
         finally:
             L.rn_kernel_log(0)
             L.rn_set_variant2(0)
-        ref = torch.nn.grad.conv2d_weight(_nchw(torch.from_numpy(xv)), (K, C, 3, 3), _nchw(torch.from_numpy(dv)), 1, 1).permute(0, 2, 3, 1)
+        ref = torch.nn.grad.conv2d_weight(_nchw(torch.from_numpy(xv)), (K, C, 3, 3), _nchw(torch.from_numpy(dv)), s_, 1).permute(0, 2, 3, 1)
         assert torch.equal(eng.tensors[sl['dw']].cpu(), ref.contiguous()), g
 
 
@@ -854,6 +854,9 @@ W9_SMALL = [
     (1, 32, 32, 32, 160, 3, 1, 1),       # a single 32-channel slice, one image
     (5, 16, 16, 96, 160, 3, 1, 1),       # 96 input channels: three slices
     (37, 16, 16, 160, 160, 3, 1, 1),     # 148 K tiles x 5 tiles: pixel splits, more than one item per workgroup
+    (2, 32, 32, 160, 320, 3, 2, 1),      # stride 2, 16-wide output: a K tile = 4 output rows = a 9-row input patch (20 DMA pieces), two output-channel tiles
+    (3, 16, 16, 320, 160, 3, 2, 1),      # stride 2, 8-wide output: a K tile = one image's 8 output rows, 17 input rows of 18 pixels
+    (5, 32, 32, 64, 160, 3, 2, 1),       # stride 2, two channel slices, five images
 ]
 
 
@@ -868,12 +871,13 @@ def test_wgrad9_on_small_geometries(g, dtype):
 
 def test_wgrad9_exact_integers():
     """integer operands: bit for bit against the reference (tap <-> wave row tile map, channel halves, shifted patch rows, slab sums in fixed order)."""
-    for g in [(2, 16, 16, 160, 160, 3, 1, 1), (3, 8, 8, 320, 320, 3, 1, 1), (2, 32, 32, 64, 160, 3, 1, 1)]:
+    for g in [(2, 16, 16, 160, 160, 3, 1, 1), (3, 8, 8, 320, 320, 3, 1, 1), (2, 32, 32, 64, 160, 3, 1, 1), (2, 32, 32, 96, 160, 3, 2, 1), (3, 16, 16, 32, 320, 3, 2, 1)]:
         N, Hh, W, C, K, k, s_, p = g
-        eng, sl = _one_op_engine(ir.OP_CONV_WGRAD, g, dict(x=((N, Hh, W, C), 'T'), dy=((N, Hh, W, K), 'T'), dw=((K, 3, 3, C), 'f32'), ws=((0,), 'u8')))
+        P, Q = Hh // s_, W // s_
+        eng, sl = _one_op_engine(ir.OP_CONV_WGRAD, g, dict(x=((N, Hh, W, C), 'T'), dy=((N, P, Q, K), 'T'), dw=((K, 3, 3, C), 'f32'), ws=((0,), 'u8')))
         rng = np.random.RandomState(0)
         xv = rng.randint(-3, 4, size=(N, Hh, W, C)).astype(np.float32)
-        dv = rng.randint(-2, 3, size=(N, Hh, W, K)).astype(np.float32)
+        dv = rng.randint(-2, 3, size=(N, P, Q, K)).astype(np.float32)
         eng.tensors[sl['x']].copy_(torch.from_numpy(xv).to(torch.float16)); eng.tensors[sl['dy']].copy_(torch.from_numpy(dv).to(torch.float16))
         eng.bind({})
         L = _lib.lib()
@@ -886,5 +890,5 @@ def test_wgrad9_exact_integers():
         finally:
             L.rn_kernel_log(0)
             L.rn_set_variant2(0)
-        ref = torch.nn.grad.conv2d_weight(_nchw(torch.from_numpy(xv)), (K, C, 3, 3), _nchw(torch.from_numpy(dv)), 1, 1).permute(0, 2, 3, 1)
+        ref = torch.nn.grad.conv2d_weight(_nchw(torch.from_numpy(xv)), (K, C, 3, 3), _nchw(torch.from_numpy(dv)), s_, 1).permute(0, 2, 3, 1)
         assert torch.equal(eng.tensors[sl['dw']].cpu(), ref.contiguous()), g
