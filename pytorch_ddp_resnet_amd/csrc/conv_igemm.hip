@@ -892,6 +892,137 @@ extern "C" int rn_conv_fwd(const void* x, const void* w_fwd, void* y, const void
   return 1;
 }
 
+// ---- a parity class WITHOUT a tap (stride-2 1 x 1 data gradients: three of the four classes) ----------------------------------------
+// Such a class has no product to add: its pixels of dx keep their value (accumulating launch), or take the residual / zero -- but a fused BatchNorm-backward
+// reduction still has to see them.  As a convolution launch that was a tile machine with an empty K loop around three operand reads (WRN-50-2-B: 1.04 ms at
+// 56 x 56 against 0.46 of traffic).  Here: one workgroup per statistics row block (RN_CONV_STATS_ROWS = 128 class pixels), thread = (16-byte channel chunk
+// column, row lane), two rows of operands in flight; the same values, sums and partial-row slots as the convolution epilogue writes (igemm_shared.h), and
+// NO store where nothing changes (accumulate without a residual).
+template <typename T>
+__global__ __launch_bounds__(256) void dgrad_notap_kernel(const IgemmClasses p) {
+  constexpr int CE = Elem<T>::CE;
+  __shared__ float red[2][256][CE + 1];
+  int ci = 0;
+  while (ci + 1 < p.n && (int)blockIdx.x >= p.first[ci + 1]) ++ci;         // workgroup-uniform: the classes of one data gradient as ONE grid
+  const IgemmArgs& a = p.a[ci];
+  const int blk = (int)blockIdx.x - p.first[ci];
+  const int tid = threadIdx.x;
+  const int CC = a.Kd / CE;
+  const int cols = CC < 256 ? CC : 256;                     // chunk columns per pass
+  const int lanes = 256 / cols;                             // row lanes per column
+  const int rl = tid / cols, cl = tid - rl * cols;
+  const int m0 = blk * RN_CONV_STATS_ROWS;
+  const int pq = a.Pc * a.Qc;
+  T* __restrict__ dst = reinterpret_cast<T*>(a.dst);
+  const bool bn_bwd = a.stats != nullptr && a.bn_x != nullptr, want_stats = a.stats != nullptr;
+  const bool res_same = a.res.mode == RN_RES_SAME, has_res = a.res.mode != RN_RES_NONE;
+  const bool store = !(a.accum && !has_res);                // accumulate without a residual: the pixel keeps its value
+  for (int cbase = 0; cbase < CC; cbase += cols) {
+    const int cg = cbase + cl;
+    const bool active = rl < lanes && cg < CC;
+    const int k0 = cg * CE;
+    float s0[CE], s1[CE], mean[CE], invstd[CE], sc[CE], sh[CE];
+#pragma unroll
+    for (int e = 0; e < CE; ++e) { s0[e] = s1[e] = 0.f; mean[e] = invstd[e] = sc[e] = sh[e] = 0.f; }
+    if (active && bn_bwd) {
+#pragma unroll
+      for (int e = 0; e < CE; ++e) {
+        sc[e] = a.bn_coef[k0 + e]; sh[e] = a.bn_coef[a.Kd + k0 + e];
+        mean[e] = a.bn_coef[2 * a.Kd + k0 + e]; invstd[e] = a.bn_coef[3 * a.Kd + k0 + e];
+      }
+    }
+    struct Row { bool ok; size_t off; int n, hd, wd; Chunk<T> cr, co, cx, cm; };
+    auto fetch = [&](int r, Row& w) {
+      const int m = m0 + r;
+      w.ok = active && r < RN_CONV_STATS_ROWS && m < a.M;
+      if (!w.ok) return;
+      int pp, q;
+      decode_row(a, m, pq, w.n, pp, q);
+      w.hd = pp * a.ds + a.oh; w.wd = q * a.ds + a.ow;
+      w.off = (((size_t)w.n * a.Hd + w.hd) * a.Wd + w.wd) * a.Kd + k0;
+      if (res_same) w.cr = load_chunk<T>(reinterpret_cast<const T*>(a.res.ptr) + w.off);
+      if (a.accum) w.co = load_chunk<T>(dst + w.off);
+      if (bn_bwd) {
+        w.cx = load_chunk<T>(reinterpret_cast<const T*>(a.bn_x) + w.off);
+        if (a.bn_mask) w.cm = load_chunk<T>(reinterpret_cast<const T*>(a.bn_mask) + w.off);
+      }
+    };
+    auto process = [&](const Row& w) {
+      if (!w.ok) return;
+      float v[CE];
+#pragma unroll
+      for (int e = 0; e < CE; ++e) v[e] = 0.f;
+      if (res_same) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(w.cr.e[e]);
+      } else if (has_res) {
+        res_add_chunk<T>(a.res, w.n, w.hd, w.wd, k0, v);
+      }
+      if (a.accum) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) v[e] += Elem<T>::to_f(w.co.e[e]);
+      }
+      Chunk<T> st;
+#pragma unroll
+      for (int e = 0; e < CE; ++e) st.e[e] = Elem<T>::from_f(v[e]);
+      if (store) store_chunk<T>(dst + w.off, st);
+      if (want_stats) {
+#pragma unroll
+        for (int e = 0; e < CE; ++e) {
+          const float vs = Elem<T>::to_f(st.e[e]);
+          if (!bn_bwd) { s0[e] += vs; s1[e] += vs * vs; continue; }
+          float g = vs * a.gscale;
+          const float xv = Elem<T>::to_f(w.cx.e[e]);
+          if (a.bn_mask ? !(Elem<T>::to_f(w.cm.e[e]) > 0.f) : (a.mask_from_x && !(fmaf(xv, sc[e], sh[e]) > 0.f))) g = 0.f;
+          s0[e] += g; s1[e] += g * ((xv - mean[e]) * invstd[e]);
+        }
+      }
+    };
+    for (int r = rl; r < RN_CONV_STATS_ROWS; r += 2 * lanes) {
+      Row w0, w1;
+      fetch(r, w0); fetch(r + lanes, w1);
+      process(w0); process(w1);
+    }
+    if (want_stats) {                                       // (uniform: every thread of the workgroup takes the same branch)
+#pragma unroll
+      for (int e = 0; e < CE; ++e) { red[0][tid][e] = s0[e]; red[1][tid][e] = s1[e]; }
+      __syncthreads();
+      if (rl == 0 && cg < CC && m0 < a.M) {
+        float t0[CE], t1[CE];
+#pragma unroll
+        for (int e = 0; e < CE; ++e) t0[e] = t1[e] = 0.f;
+        for (int l = 0; l < lanes; ++l) {
+#pragma unroll
+          for (int e = 0; e < CE; ++e) { t0[e] += red[0][l * cols + cl][e]; t1[e] += red[1][l * cols + cl][e]; }
+        }
+        float* out = a.stats + ((size_t)(a.tile_base + blk) * 2) * a.Kd + k0;
+#pragma unroll
+        for (int e = 0; e < CE; ++e) { out[e] = t0[e]; out[a.Kd + e] = t1[e]; }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+template <typename T> int launch_notap(const IgemmArgs* as, int n, hipStream_t s) {
+  IgemmClasses p{};
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    if (as[i].M <= 0) continue;
+    p.a[p.n] = as[i];
+    p.first[p.n] = blocks;
+    p.nwg[p.n] = cdiv(as[i].M, RN_CONV_STATS_ROWS);
+    blocks += p.nwg[p.n];
+    ++p.n;
+  }
+  if (!p.n) return 0;
+  rn_note_kernel("dgrad_notap");
+  if (rn_dry_run()) return 0;
+  hipLaunchKernelGGL((dgrad_notap_kernel<T>), dim3(blocks), dim3(256), 0, s, p);
+  RN_CHECK_LAUNCH("dgrad_notap");
+  return 0;
+}
+
 extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, const void* res, int res_mode, int res_C, int flags,
                              int dtype, const rn_conv_geom* g, const rn_conv_epilogue* ep, rn_stream s) {
   if (int e = check_geom(g, dtype, "rn_conv_dgrad")) return e;
@@ -940,6 +1071,18 @@ extern "C" int rn_conv_dgrad(const void* dy, const void* w_dgrad, void* dx, cons
       ++nrec;
     }
   int e = 0;
+  // classes without a tap leave the convolution kernels (rn_set_variant2 1048576: they stay, A/B)
+  if (!(g_rn_variant2 & 1048576)) {
+    IgemmArgs bare[4];
+    int keep = 0, nbare = 0;
+    for (int i = 0; i < nrec; ++i) {
+      if (recs[i].nt == 0) bare[nbare++] = recs[i];
+      else { if (keep != i) recs[keep] = recs[i]; ++keep; }
+    }
+    if (nbare) RN_BY_DTYPE(dtype, e = launch_notap<T_>(bare, nbare, as_stream(s)));
+    if (e) return e;
+    nrec = keep;
+  }
   bool merged = false;
   RN_BY_DTYPE(dtype, merged = classes_ok<T_>(recs, nrec));
   if (merged) {

@@ -200,7 +200,10 @@ def test_stride2_parity_classes_as_one_grid_and_one_by_one(g, variant, merge, dt
     ran = run_conv_case(g, dtype, variant=variant, fwd_res=False, dgrad_merge=merge)
     dgrad = [n for n in ran if n.startswith('igemm_')][1:]                     # (the first name is the forward's)
     assert len(dgrad) >= 1 and all(n.startswith(('igemm_dma<128x', 'igemm_ws<128x')) for n in dgrad), ran
-    if variant == 0:
+    if g[5] == 1:                                                              # a 1 x 1 kernel: ONE class has a tap, the other three are one launch of the tap-less pass
+        assert len(dgrad) == 1 and ran.count('dgrad_notap') == 1, ran
+    elif variant == 0:
+        assert 'dgrad_notap' not in ran, ran
         assert all(n.startswith('igemm_dma<128x') for n in dgrad), ran          # one grid: the two-workgroups-per-CU kernel, one name per class
 
 
