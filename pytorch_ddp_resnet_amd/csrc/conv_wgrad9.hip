@@ -89,17 +89,19 @@ constexpr int YB = 20480;         // bytes of a stage's dy tile; the patch regio
 // Measured in one process (tools/conv_bench.py wgrad, batch 128): first form 88.1 / 80.6 / 80.2 us on the 160 / 320 / 640-channel layers; pieces moved into
 // the MFMA segment, barriers kept 81.0 / 74.6 / 73.8; this form 75.0 / 70.5 / 72.5 (round-3 kernel: 88.3 / 79.4 / 84.5).  A second register set that holds
 // both k-steps' fragments from the head of the K tile (162 registers) lost 3-5 % against it; removed.  TWO K tiles per barrier on a ring of four stages: 77.1 / 70.1 / 69.3 us
-// against 79.3 / 72.8 / 71.3 alone (+3 %) -- but hipcc keeps 156 registers for it, and the step went 6.06 -> 6.48 ms: at most 136 registers per wave is what lets the
-// chain's BatchNorm-backward kernels run BESIDE this kernel (tests/test_abi.py holds the budget); removed.
+// against 79.3 / 72.8 / 71.3 alone (+3 %) -- but as a loop body of its own hipcc kept 156 registers for it, and the step went 6.06 -> 6.48 ms: at most 136 registers per wave
+// is what lets the chain's BatchNorm-backward kernels run BESIDE this kernel (tests/test_abi.py holds the budget).
+// SCHED 5 (shipped since; rn_set_variant2 32768 selects 2): the same idea through THIS form's k-step body -- K tile kt in stage kt % 4, both tiles of the next pair issued
+// during the pair's first K tile, vmcnt(0) + barrier behind every second K tile: 132 registers, 70.2 / 69.7 us against 74.1 / 73.6 (+5 %), the step 6.157 -> 6.059 ms.
 // STR 2 (round 4, second session): the family's stride-2 3x3 layers (padding 1, output map = input map / 2).  The patch of a K tile is then the 2 rows + 1 input rows
 // its output rows read, ALL columns (306 pixel rows for 16- and 8-wide output maps: 20 DMA pieces, a stage = 20 + 20 KiB), and a k index reads patch row
 // (2 r + 1 + dh)(W + 2) + 2 q + 1 + dw; everything else is the stride-1 kernel.
-template <typename T, int PROBE = 0, int SCHED = 2, int STR = 1>
+template <typename T, int PROBE = 0, int SCHED = 5, int STR = 1>
 __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
   constexpr int ES = 2;
   constexpr int XB = STR == 2 ? 20480 : 9216, STG = XB + YB;          // (shadow the stride-1 constants of the namespace)
   constexpr int NS = STR == 2 ? 4 : 3;                                 // DMA pieces per wave and K tile, at most
-  __shared__ uint4 smem[3 * STG / 16];
+  __shared__ uint4 smem[(SCHED == 5 ? 4 : 3) * STG / 16];
   const char* lds = reinterpret_cast<const char*>(&smem[0]);
   const unsigned lds0 = (unsigned)(size_t)(lds_ptr_t)(&smem[0]);
 
@@ -209,7 +211,7 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
     return make_uint4(lo.x, lo.y, hi.x, hi.y);
   };
   // one phase: k-step ks of the K tile in the stage at byte offset sx; second phases also issue K tile gn into the stage at dst_lds and wait for the K tile after this one
-  auto phase = [&](auto kstag, int sx, int gn, unsigned dst_lds) {
+  auto phase = [&](auto kstag, int sx, int gn, unsigned dst_lds, bool pair_end = true) {
     constexpr int ks = decltype(kstag)::value;
     if constexpr (PROBE != 3) {
 #pragma unroll
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
         wait_vm9(PROBE == 1 ? 0 : nw);                       // everything older than this K tile's own pieces: K tile kt + 1 has landed
       }
     }
-    if constexpr (SCHED != 2) bar9();
+    if constexpr (SCHED != 2 && SCHED != 5) bar9();
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_sched_barrier(0);
     __builtin_amdgcn_s_setprio(1);
@@ -239,7 +241,11 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
   } while (0)
 #pragma unroll
     for (int j = 0; j < 5; ++j) W9_MF(0, j);
-    if constexpr (ks == 1 && SCHED != 0 && PROBE != 1) {
+    if constexpr (SCHED == 5) {                              // (both tiles of the NEXT pair go out during the pair's first K tile: gn < 0 = nothing to issue)
+      __builtin_amdgcn_sched_barrier(0);
+      if (gn >= 0) issue_tile(gn, dst_lds);
+      __builtin_amdgcn_sched_barrier(0);
+    } else if constexpr (ks == 1 && SCHED != 0 && PROBE != 1) {
       __builtin_amdgcn_sched_barrier(0);
       issue_tile(gn, dst_lds);
       __builtin_amdgcn_sched_barrier(0);
@@ -250,10 +256,14 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
       for (int j = 0; j < 5; ++j) W9_MF(i, j);
 #undef W9_MF
     __builtin_amdgcn_s_setprio(0);
-    if constexpr (SCHED != 2) bar9();
+    if constexpr (SCHED != 2 && SCHED != 5) bar9();
     else if constexpr (ks == 1) {
-      wait_vm9(nw);                                          // K tile kt + 1 has landed; this K tile's own pieces (K tile kt + 2) stay in flight
-      bar9();
+      if constexpr (SCHED == 5) {                            // a barrier every SECOND K tile (ring of four stages; the next pair has landed behind vmcnt(0))
+        if (pair_end) { wait_vm9(0); bar9(); }
+      } else {
+        wait_vm9(nw);                                        // K tile kt + 1 has landed; this K tile's own pieces (K tile kt + 2) stay in flight
+        bar9();
+      }
     }
   };
   using K0 = std::integral_constant<int, 0>; using K1 = std::integral_constant<int, 1>;
@@ -310,16 +320,26 @@ __global__ __launch_bounds__(768, 3) void wgrad9_kernel(const W9Batch b) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[i][j][r] = 0.f;
     // K tile kb has landed; kb + 1's pieces (and the previous item's 15 stores, which are younger) may fly
-    wait_vm9(stores_behind ? nw + 15 : nw);
+    if constexpr (SCHED == 5) { if (stores_behind) wait_vmcnt<15>(); else wait_vmcnt<0>(); } else wait_vm9(stores_behind ? nw + 15 : nw);
     bar9();
     if (SCHED == 0 && wave >= 4) bar9();                     // waves 4-11 run one barrier behind waves 0-3
 
     const int nseg_k = kend - kb;
-    int s_cur = 0, s_nxt = STG, s_free = 2 * STG;            // stage of K tile kt, of kt + 1, and the one kt + 2 goes into (kt - 1's)
-    for (int kt = 0; kt < nseg_k; ++kt) {
-      phase(K0{}, s_cur, 0, 0u);
-      phase(K1{}, s_cur, kb + kt + 2, lds0 + (unsigned)s_free);
-      const int t = s_cur; s_cur = s_nxt; s_nxt = s_free; s_free = t;
+    if constexpr (SCHED == 5) {
+      // the prologue put K tiles kb, kb + 1 into stages 0, 1 and waited for both; K tile kt lives in stage kt % 4, K tile kt + 2 is issued during kt
+      for (int kt = 0; kt < nseg_k; ++kt) {
+        const int sc = (kt & 3) * STG;
+        const bool even = (kt & 1) == 0;
+        phase(K0{}, sc, even ? kb + kt + 2 : -1, lds0 + (unsigned)(((kt + 2) & 3) * STG));
+        phase(K1{}, sc, even ? kb + kt + 3 : -1, lds0 + (unsigned)(((kt + 3) & 3) * STG), !even || kt + 1 == nseg_k);
+      }
+    } else {
+      int s_cur = 0, s_nxt = STG, s_free = 2 * STG;          // stage of K tile kt, of kt + 1, and the one kt + 2 goes into (kt - 1's)
+      for (int kt = 0; kt < nseg_k; ++kt) {
+        phase(K0{}, s_cur, 0, 0u);
+        phase(K1{}, s_cur, kb + kt + 2, lds0 + (unsigned)s_free);
+        const int t = s_cur; s_cur = s_nxt; s_nxt = s_free; s_free = t;
+      }
     }
     if (SCHED == 0 && wave < 4) bar9();
     prec = rec; ptile = tile; psplit = split;
@@ -403,14 +423,15 @@ static void w9_fill(W9Rec& r, const void* x, const void* dy, float* out, int spl
 }
 
 template <typename T> static void w9_launch(const W9Batch& b, int grid, hipStream_t s, int stride) {
-  if (stride == 2) { hipLaunchKernelGGL((wgrad9_kernel<T, 0, 2, 2>), dim3(grid), dim3(768), 0, s, b); return; }
+  if (stride == 2) { hipLaunchKernelGGL((wgrad9_kernel<T, 0, 2, 2>), dim3(grid), dim3(768), 0, s, b); return; }      // (three stages of 40 KiB: a fourth would fill the CU's LDS)
   if constexpr (std::is_same<T, f16_t>::value) {
     const int probe = (g_rn_variant2 >> 8) & 7;
-    if (probe == 1) { hipLaunchKernelGGL((wgrad9_kernel<T, 1, 2>), dim3(grid), dim3(768), 0, s, b); return; }
-    if (probe == 2) { hipLaunchKernelGGL((wgrad9_kernel<T, 2, 2>), dim3(grid), dim3(768), 0, s, b); return; }
-    if (probe == 3) { hipLaunchKernelGGL((wgrad9_kernel<T, 3, 2>), dim3(grid), dim3(768), 0, s, b); return; }
+    if (probe == 1) { hipLaunchKernelGGL((wgrad9_kernel<T, 1, 5>), dim3(grid), dim3(768), 0, s, b); return; }
+    if (probe == 2) { hipLaunchKernelGGL((wgrad9_kernel<T, 2, 5>), dim3(grid), dim3(768), 0, s, b); return; }
+    if (probe == 3) { hipLaunchKernelGGL((wgrad9_kernel<T, 3, 5>), dim3(grid), dim3(768), 0, s, b); return; }
   }
   if (g_rn_variant2 & 8192) { hipLaunchKernelGGL((wgrad9_kernel<T, 0, 0>), dim3(grid), dim3(768), 0, s, b); return; }
+  if (g_rn_variant2 & 32768) { hipLaunchKernelGGL((wgrad9_kernel<T, 0, 2>), dim3(grid), dim3(768), 0, s, b); return; }
   hipLaunchKernelGGL((wgrad9_kernel<T>), dim3(grid), dim3(768), 0, s, b);
 }
 

@@ -177,7 +177,7 @@ def test_hot_kernels_keep_their_occupancy():
         # ... and its weight gradient: three waves per SIMD of AT MOST 136 registers, so that a fourth wave of <= 104 fits on every SIMD -- the chain's
         # BatchNorm-backward kernels run BESIDE the forked weight gradients (a 156-register form of this kernel was 3 % faster alone
         # and made the step 7 % slower); the co-runners' side of the budget follows
-        k = find(f'wgrad9_kernelI{dt}Li0ELi2ELi1E')
+        k = find(f'wgrad9_kernelI{dt}Li0ELi5ELi1E')
         assert k['Occupancy'] >= 3 and k['VGPRs'] <= 136 and k['LDS Size'] + 18 * 1024 <= LDS_CU and k['ScratchSize'] == 0, k
         k = find(f'wgrad9_kernelI{dt}Li0ELi2ELi2E')                            # its stride-2 form (two launches per WRN-28-10 step): a fourth DMA role per wave, 140 registers
         assert k['Occupancy'] >= 3 and k['LDS Size'] + 18 * 1024 <= LDS_CU and k['ScratchSize'] == 0, k
