@@ -708,6 +708,8 @@ R8_SPLIT_SMALL = [
 def test_igemm8r_split_reduction(g, merge, dtype):
     """the row-patch kernel with every tile's reduction cut into two work items (conv_igemm8r.hip, split form): group ranges that start inside a kernel row,
     the hand-off through the stream-K workspace (write-through parts, ticket, the second arriver adds both parts in slice order), every operand set."""
+    if dtype == 'bf16' and merge != 'none':
+        pytest.skip('the merged operand sets once (fp16): the suite runs close to a quarter of an hour')
     ran = run_conv_case(g, dtype, variant2=R8_ANY | R8_SPLIT_ANY, fwd_res=(merge == 'none'), dgrad_merge=merge)
     assert ran[0] == 'igemm8r<256x160/2:' + ('res>' if merge == 'none' else 'plain>'), ran
     if g[3] % 160 == 0:
